@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Run in the build container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference package's ``__init__`` imports ``two_pcf`` -> ``treecorr``/``iminuit`` and
+``meanify`` -> ``fitsio``, none of which is installed here (ordinary ModuleNotFoundError).
+Those imports are only needed by the TreeCorr-based optimisers, so this script registers
+a bare ``treegp`` package object whose ``__path__`` points at the reference and imports
+the three modules of the hot path directly -- ``treegp.kernels``, ``treegp.log_likelihood``
+and ``treegp.gp_interp`` -- which run unmodified (no stand-ins for the missing libraries).
+
+Outputs (inputs + the reference's outputs, nothing else):
+  g1_c1_rbf1d.npz       config 1: 1-D AnisotropicRBF N=512 / M=1024, alpha, y_pred, logL
+  g2_aniso2d.npz        2-D sheared AnisotropicRBF N=1024/M=2048, y_err, white_noise, cov diag
+  g3_vonkarman.npz      VonKarman + AnisotropicVonKarman GP incl. coincident X* (lim0 branch)
+  g4_kernels.npz        kernel tables K(X), K(X,Y) for RBF / AnisoRBF / VK / AnisoVK
+  g5_loglike.npz        return_log_likelihood(theta) at 5 thetas
+  g6_meanify.npz        mean-function case, X0/y0 decoded from the reference's FITS fixture
+  g7_host_scalars.npz   n_bootstrap / mask sizes, bootstrap index rows, kernel theta maps
+  g8_reftests.npz       the reference's own test problems (tests/test_gp_interp.py) end to end
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_reference():
+    pkg = types.ModuleType("treegp")
+    pkg.__path__ = [os.path.join(REF, "treegp")]
+    sys.modules["treegp"] = pkg
+    k = importlib.import_module("treegp.kernels")
+    ll = importlib.import_module("treegp.log_likelihood")
+    gi = importlib.import_module("treegp.gp_interp")
+    # what treegp/__init__.py:9-16 would have bound (hot-path names only)
+    pkg.GPInterpolation = gi.GPInterpolation
+    pkg.log_likelihood = ll.log_likelihood
+    pkg.eval_kernel = k.eval_kernel
+    pkg.AnisotropicRBF = k.AnisotropicRBF
+    pkg.VonKarman = k.VonKarman
+    pkg.AnisotropicVonKarman = k.AnisotropicVonKarman
+    return pkg
+
+
+def corr_len_matrix(size, e1, e2):
+    # same formula as tests/treegp_test_helper.py:24-44 (inputs to kernel strings only)
+    e = np.sqrt(e1 ** 2 + e2 ** 2)
+    q = (1 - e) / (1 + e)
+    phi = 0.5 * np.arctan2(e2, e1)
+    rot = np.array([[np.cos(phi), np.sin(phi)], [-np.sin(phi), np.cos(phi)]])
+    ell = np.array([[size ** 2, 0], [0, (size * q) ** 2]])
+    return np.dot(rot.T, ell.dot(rot))
+
+
+def sine_field(rng, X, nmodes=8):
+    """Smooth multi-sine field of SURVEY.md 8(d) (inputs only)."""
+    X2 = X if X.shape[1] == 2 else np.hstack([X, np.zeros_like(X)])
+    y = np.zeros(len(X2))
+    for _ in range(nmodes):
+        A = rng.uniform(0.2, 1.0)
+        f = rng.uniform(1.0, 6.0, size=2)
+        ph = rng.uniform(0, 2 * np.pi)
+        y += A * np.sin(2 * np.pi * (X2 @ f) + ph)
+    return y
+
+
+def read_fits_bintable_row0(path):
+    """Minimal FITS BINTABLE reader (one row, 'nD' columns) for the reference fixture."""
+    raw = open(path, "rb").read()
+    pos, hdus = 0, []
+    while pos < len(raw):
+        cards = {}
+        while True:
+            blk = raw[pos:pos + 2880]
+            pos += 2880
+            end = False
+            for i in range(0, 2880, 80):
+                c = blk[i:i + 80].decode("ascii")
+                if c.startswith("END"):
+                    end = True
+                    break
+                if c[8:10] == "= ":
+                    cards[c[:8].strip()] = c[10:].split("/")[0].strip().strip("'").strip()
+            if end:
+                break
+        nbytes = 0
+        if int(cards.get("NAXIS", 0)) > 0:
+            nbytes = int(cards["NAXIS1"]) * int(cards["NAXIS2"])
+        hdus.append((cards, pos))
+        pos += (nbytes + 2879) // 2880 * 2880
+    cards, start = hdus[1]
+    out, off = {}, start
+    for i in range(1, int(cards["TFIELDS"]) + 1):
+        n = int(cards["TFORM%d" % i][:-1])
+        out[cards["TTYPE%d" % i]] = np.frombuffer(raw, dtype=">f8", count=n, offset=off).astype(np.float64)
+        off += 8 * n
+    return out
+
+
+def main():
+    tg = load_reference()
+    GP = tg.GPInterpolation
+
+    # ---------------- G1: config 1 ------------------------------------------------
+    rng = np.random.default_rng(20240613)
+    N, M = 512, 1024
+    X = rng.uniform(-10, 10, (N, 1))
+    kern = "1.0**2 * AnisotropicRBF(scale_length=[2.0])"
+    noise = 0.1
+    y = sine_field(rng, X / 20.0) + noise * rng.standard_normal(N)
+    y_err = noise * np.ones(N)
+    Xs = np.linspace(-10, 10, M).reshape(M, 1)
+    gp = GP(kernel=kern, optimizer="none", normalize=True, white_noise=0.0)
+    gp.initialize(X, y, y_err=y_err)
+    yp = gp.predict(Xs)
+    np.savez(os.path.join(OUT, "g1_c1_rbf1d.npz"), kernel=kern, X=X, y=y, y_err=y_err, Xs=Xs,
+             y_pred=yp, alpha=gp._alpha, mean=gp._mean, logL=gp.return_log_likelihood())
+
+    # ---------------- G2: sheared 2-D AnisotropicRBF -------------------------------
+    rng = np.random.default_rng(7)
+    N, M = 1024, 2048
+    X = rng.uniform(0, 1, (N, 2))
+    invL = np.linalg.inv(corr_len_matrix(0.05, 0.2, 0.1))
+    kern = "0.8**2 * AnisotropicRBF(invLam={0!r})".format(invL)
+    y = 0.3 + sine_field(rng, X) + 0.03 * rng.standard_normal(N)
+    y_err = 0.03 * rng.uniform(0.8, 1.2, N)
+    Xs = rng.uniform(0, 1, (M, 2))
+    gp = GP(kernel=kern, optimizer="none", normalize=True, white_noise=0.01)
+    gp.initialize(X, y, y_err=y_err)
+    yp, cov = gp.predict(Xs[:256], return_cov=True)
+    yp_all = gp.predict(Xs)
+    invL = gp.kernel_template.k2.invLam      # the repr() in the kernel string truncated it
+    np.savez(os.path.join(OUT, "g2_aniso2d.npz"), kernel=kern, invLam=invL, amp=0.8 ** 2, X=X, y=y,
+             y_err=y_err, white_noise=0.01, Xs=Xs, y_pred=yp_all, alpha=gp._alpha, mean=gp._mean,
+             cov256=cov, y_err_eff=gp._y_err)
+
+    # ---------------- G3: von Karman kernels, with coincident prediction points -----
+    rng = np.random.default_rng(11)
+    N, M = 600, 500
+    X = rng.uniform(0, 1, (N, 2))
+    y = sine_field(rng, X) + 0.05 * rng.standard_normal(N)
+    y_err = 0.05 * rng.uniform(0.8, 1.2, N)
+    Xs = rng.uniform(0, 1, (M, 2))
+    Xs[:50] = X[:50]                                  # exercises kernels.py:274-276 / 379-381
+    out = dict(X=X, y=y, y_err=y_err, Xs=Xs)
+    invL = np.linalg.inv(corr_len_matrix(0.3, 0.2, -0.1))
+    for tag, kern in (("vk", "1.3**2 * VonKarman(length_scale=0.4)"),
+                      ("avk", "1.3**2 * AnisotropicVonKarman(invLam={0!r})".format(invL))):
+        gp = GP(kernel=kern, optimizer="none", normalize=True, white_noise=0.0)
+        gp.initialize(X, y, y_err=y_err)
+        yp, cov = gp.predict(Xs[:200], return_cov=True)
+        if tag == "avk":
+            invL = gp.kernel_template.k2.invLam
+        out.update({tag + "_kernel": kern, tag + "_y_pred": gp.predict(Xs), tag + "_alpha": gp._alpha,
+                    tag + "_cov200": cov, tag + "_logL": gp.return_log_likelihood()})
+    out["avk_invLam"] = invL
+    np.savez(os.path.join(OUT, "g3_vonkarman.npz"), **out)
+
+    # ---------------- G4: kernel tables ------------------------------------------------
+    rng = np.random.default_rng(3)
+    n = 64
+    # distances spanning ~1e-7 .. 1e3 so that Bessel arguments cover 1e-6 .. > 698 (exact 0)
+    rad = 10.0 ** rng.uniform(-7, 2.3, n)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    X = np.array([rad * np.cos(ang), rad * np.sin(ang)]).T
+    Y = np.vstack([X[:16], rng.uniform(-3, 3, (32, 2))])      # 16 coincident rows
+    invL = np.linalg.inv(corr_len_matrix(1.7, 0.3, -0.2))
+    kerns = {
+        "rbf": "2.0**2 * RBF(0.45)",
+        "arbf": "0.5**2 * AnisotropicRBF(invLam={0!r})".format(invL),
+        "vk": "1.5**2 * VonKarman(length_scale=3.0)",
+        "avk": "0.7**2 * AnisotropicVonKarman(invLam={0!r})".format(invL),
+        "vk_noamp": "VonKarman(length_scale=0.02)",
+    }
+    out = dict(X=X, Y=Y, invLam=invL)
+    for tag, s in kerns.items():
+        k = tg.eval_kernel(s)
+        out[tag + "_str"] = s
+        out[tag + "_self"] = k(X)
+        out[tag + "_cross"] = k(Y, Y=X)
+        out[tag + "_theta"] = k.theta
+        if hasattr(getattr(k, "k2", None), "invLam"):
+            out[tag + "_invLam"] = k.k2.invLam      # as parsed back from the repr() string
+    X1 = np.sort(rng.uniform(-10, 10, 48)).reshape(-1, 1)
+    out["X1"] = X1
+    for tag, s in (("rbf1d", "2.0**2 * RBF(2.0)"), ("vk1d", "2.0**2 * VonKarman(2.0)"),
+                   ("arbf1d", "1.0**2 * AnisotropicRBF(scale_length=[2.0])")):
+        k = tg.eval_kernel(s)
+        out[tag + "_str"] = s
+        out[tag + "_self"] = k(X1)
+        out[tag + "_cross"] = k(X1[:10] + 0.5, Y=X1)
+    np.savez(os.path.join(OUT, "g4_kernels.npz"), **out)
+
+    # ---------------- G5: log-likelihood at several thetas -----------------------------
+    rng = np.random.default_rng(5)
+    N = 400
+    X = rng.uniform(0, 1, (N, 2))
+    y = sine_field(rng, X) + 0.05 * rng.standard_normal(N)
+    y_err = 0.05 * rng.uniform(0.8, 1.2, N)
+    invL = np.linalg.inv(corr_len_matrix(0.2, 0.1, 0.1))
+    kern = "1.0**2 * AnisotropicRBF(invLam={0!r})".format(invL)
+    gp = GP(kernel=kern, optimizer="none", normalize=True)
+    gp.initialize(X, y, y_err=y_err)
+    th0 = gp.kernel.theta.copy()
+    invL = gp.kernel_template.k2.invLam
+    thetas = np.array([th0, th0 + 0.1, th0 - 0.2, th0 * 1.1, th0 + np.array([0.5, -0.1, 0.1, 0.3])])
+    lls = np.array([gp.return_log_likelihood(theta=t) for t in thetas])
+    # a theta that makes K numerically singular with zero noise -> -inf (log_likelihood.py:38-39)
+    gp2 = GP(kernel="1.0**2 * AnisotropicRBF(scale_length=[50., 50.])", optimizer="none", normalize=False)
+    gp2.initialize(X, y, y_err=np.zeros(N))
+    ll_bad = gp2.return_log_likelihood()
+    np.savez(os.path.join(OUT, "g5_loglike.npz"), kernel=kern, invLam=invL, X=X, y=y, y_err=y_err, thetas=thetas,
+             logL=lls, mean=gp._mean, logL_singular=ll_bad)
+
+    # ---------------- G6: mean-function (meanify output) case ---------------------------
+    fx = read_fits_bintable_row0(os.path.join(REF, "tests", "inputs", "mean_gp_stat_mean.fits"))
+    X0 = fx["COORDS0"].reshape(2500, 2)             # TDIM (2,2500): fastest axis first
+    y0 = fx["PARAMS0"]
+    rng = np.random.default_rng(13)
+    N, M = 800, 600
+    X = rng.uniform(0, 2048, (N, 2))
+    avg = 0.02 + 5e-8 * (X[:, 0] - 1024) ** 2 + 5e-8 * (X[:, 1] - 1024) ** 2
+    y = avg + 0.03 * sine_field(rng, X / 2048.0) + 0.003 * rng.standard_normal(N)
+    y_err = 0.003 * rng.uniform(0.8, 1.2, N)
+    Xs = rng.uniform(0, 2048, (M, 2))
+    invL = np.linalg.inv(corr_len_matrix(300.0, 0.2, 0.1))
+    kern = "0.03**2 * AnisotropicRBF(invLam={0!r})".format(invL)
+    gp = GP(kernel=kern, optimizer="none", normalize=True, n_neighbors=4)
+    gp._X0, gp._y0 = X0, y0                      # what gp_interp.py:100-107 does with fitsio
+    gp.initialize(X, y, y_err=y_err)
+    yp = gp.predict(Xs)
+    np.savez(os.path.join(OUT, "g6_meanify.npz"), kernel=kern, invLam=gp.kernel_template.k2.invLam, X0=X0, y0=y0, X=X, y=y, y_err=y_err, Xs=Xs,
+             spatial_average=gp._spatial_average, mean=gp._mean, y_pred=yp, alpha=gp._alpha,
+             spatial_average_Xs=gp._build_average_meanify(Xs))
+
+    # ---------------- G7: host-side scalars ----------------------------------------------
+    # two_pcf.py cannot be imported (treecorr), so these restate its few NumPy/SciPy lines
+    # verbatim in behaviour: mask two_pcf.py:311-321, n_bootstrap :375-383, rng :264-281.
+    from scipy import optimize
+    out = {}
+    for nb in (15, 20, 21):
+        mask = np.ones((nb, nb), dtype=bool)
+        nmask = int((nb / 2) + nb % 2)
+        mask[nmask:, :] = False
+        mask[nmask - 1][nmask:] = (nb % 2 == 0)
+        npix = int(mask.sum())
+
+        def f_bias(x, npixel=npix):
+            return ((x - 1.0) / (x - npixel - 2.0)) - 2.0
+        out["npix_%d" % nb] = npix
+        out["nboot_%d" % nb] = int(optimize.fsolve(f_bias, npix + 10)[0])
+        out["mask_%d" % nb] = mask.reshape(-1)
+    r = np.random.default_rng(610639139)
+    out["boot_n10"] = np.stack([r.integers(0, 9, size=10) for _ in range(4)])
+    r = np.random.default_rng(610639139)
+    out["boot_n1000"] = np.stack([r.integers(0, 999, size=1000) for _ in range(3)])
+    np.savez(os.path.join(OUT, "g7_host_scalars.npz"), **out)
+
+    # ---------------- G8: the reference's own GP test problems (tests/test_gp_interp.py) ---
+    out = {}
+    np.random.seed(42)
+    npts = 40
+    x = np.random.uniform(-10, 10, npts).reshape((npts, 1))
+    for tag, kern in (("rbf", "1.000000**2 * RBF(2.000000)"), ("vk", "2.000000**2 * VonKarman(2.000000)")):
+        K = tg.eval_kernel(kern)(x)
+        np.random.seed(43)
+        yy = np.random.multivariate_normal(np.zeros(npts), K) + np.random.normal(scale=0.1, size=npts)
+        gp = GP(kernel=kern, optimizer="none", white_noise=0.0)
+        gp.initialize(x, yy, y_err=0.1 * np.ones(npts))
+        yp, cov = gp.predict(x, return_cov=True)
+        new_x = np.linspace(np.max(x) + 12.0, np.max(x) + 14.0, npts).reshape((npts, 1))
+        gpb = GP(kernel=kern, optimizer="none", normalize=False, white_noise=0.0)
+        gpb.initialize(x, yy, y_err=0.1 * np.ones(npts))
+        ypb, covb = gpb.predict(new_x, return_cov=True)
+        out.update({tag + "_kernel": kern, tag + "_y": yy, tag + "_y_pred": yp, tag + "_cov": cov,
+                    tag + "_new_x": new_x, tag + "_y_far": ypb, tag + "_cov_far": covb})
+    out["x"] = x
+    np.savez(os.path.join(OUT, "g8_reftests.npz"), **out)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""Pins oracle/gp_oracle.py against the golden vectors produced by the reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+
+from oracle import gp_oracle as O
+
+
+def _inv3(invL):
+    return dict(a=invL[0, 0], b=invL[0, 1], c=invL[1, 1])
+
+
+def test_kernel_tables(golden):
+    g = golden("g4_kernels.npz")
+    X, Y, invL = g["X"], g["Y"], g["invLam"]
+    cases = {
+        "rbf": dict(kind="gauss", amp=4.0, a=1 / 0.45 ** 2, b=0.0, c=1 / 0.45 ** 2),
+        "arbf": dict(kind="gauss", amp=0.25, **_inv3(g["arbf_invLam"])),
+        "vk": dict(kind="vk", amp=2.25, ell=3.0),
+        "avk": dict(kind="avk", amp=0.7 ** 2, **_inv3(g["avk_invLam"])),
+        "vk_noamp": dict(kind="vk", amp=1.0, ell=0.02),
+    }
+    for tag, p in cases.items():
+        np.testing.assert_allclose(O.kernel_matrix(X=X, **p), g[tag + "_self"], rtol=2e-12, atol=1e-14, err_msg=tag)
+        np.testing.assert_allclose(O.kernel_matrix(X=Y, Y=X, **p), g[tag + "_cross"], rtol=2e-12, atol=1e-14, err_msg=tag)
+    X1 = g["X1"]
+    for tag, p in {"rbf1d": dict(kind="gauss", amp=4.0, a=0.25, b=0.0, c=0.0),
+                   "vk1d": dict(kind="vk", amp=4.0, ell=2.0),
+                   "arbf1d": dict(kind="gauss", amp=1.0, a=0.25, b=0.0, c=0.0)}.items():
+        np.testing.assert_allclose(O.kernel_matrix(X=X1, **p), g[tag + "_self"], rtol=2e-12, atol=1e-14)
+        np.testing.assert_allclose(O.kernel_matrix(X=X1[:10] + 0.5, Y=X1, **p), g[tag + "_cross"], rtol=2e-12, atol=1e-14)
+
+
+def test_config1_rbf1d(golden):
+    g = golden("g1_c1_rbf1d.npz")
+    p = dict(kind="gauss", amp=1.0, a=0.25, b=0.0, c=0.0)
+    K = O.kernel_matrix(X=g["X"], **p)
+    mean = np.mean(g["y"])
+    np.testing.assert_allclose(mean, g["mean"], rtol=1e-15)
+    alpha, logdet = O.gp_solve(K, g["y"] - mean, g["y_err"])
+    np.testing.assert_allclose(alpha, g["alpha"], rtol=1e-9, atol=1e-9 * np.abs(g["alpha"]).max())
+    yp = O.gp_predict(O.kernel_matrix(X=g["Xs"], Y=g["X"], **p), alpha) + mean
+    np.testing.assert_allclose(yp, g["y_pred"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(O.log_likelihood(K, g["y"] - mean, g["y_err"]), g["logL"], rtol=1e-12)
+
+
+def test_aniso2d_with_cov(golden):
+    g = golden("g2_aniso2d.npz")
+    p = dict(kind="gauss", amp=float(g["amp"]), **_inv3(g["invLam"]))
+    yerr = np.sqrt(g["y_err"] ** 2 + float(g["white_noise"]) ** 2)
+    np.testing.assert_allclose(yerr, g["y_err_eff"], rtol=1e-15)
+    mean = np.mean(g["y"])
+    K = O.kernel_matrix(X=g["X"], **p)
+    alpha, _ = O.gp_solve(K, g["y"] - mean, yerr)
+    HT = O.kernel_matrix(X=g["Xs"], Y=g["X"], **p)
+    np.testing.assert_allclose(O.gp_predict(HT, alpha) + mean, g["y_pred"], rtol=1e-10, atol=1e-10)
+    cov = O.gp_predict_cov(K, yerr, HT[:256], O.kernel_matrix(X=g["Xs"][:256], **p))
+    np.testing.assert_allclose(cov, g["cov256"], rtol=1e-9, atol=1e-11)
+
+
+def test_vonkarman_gp(golden):
+    g = golden("g3_vonkarman.npz")
+    mean = np.mean(g["y"])
+    for tag, p in (("vk", dict(kind="vk", amp=1.69, ell=0.4)),
+                   ("avk", dict(kind="avk", amp=1.69, **_inv3(g["avk_invLam"])))):
+        K = O.kernel_matrix(X=g["X"], **p)
+        alpha, _ = O.gp_solve(K, g["y"] - mean, g["y_err"])
+        HT = O.kernel_matrix(X=g["Xs"], Y=g["X"], **p)
+        np.testing.assert_allclose(O.gp_predict(HT, alpha) + mean, g[tag + "_y_pred"], rtol=1e-10, atol=1e-10)
+        cov = O.gp_predict_cov(K, g["y_err"], HT[:200], O.kernel_matrix(X=g["Xs"][:200], **p))
+        np.testing.assert_allclose(cov, g[tag + "_cov200"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(O.log_likelihood(K, g["y"] - mean, g["y_err"]), g[tag + "_logL"], rtol=1e-12)
+
+
+def test_meanify_case(golden):
+    g = golden("g6_meanify.npz")
+    sa = O.knn_mean(g["X0"], g["y0"], g["X"], k=4)
+    np.testing.assert_allclose(sa, g["spatial_average"], rtol=1e-13)
+    np.testing.assert_allclose(O.knn_mean(g["X0"], g["y0"], g["Xs"], k=4), g["spatial_average_Xs"], rtol=1e-13)
+    mean = np.mean(g["y"] - sa)
+    np.testing.assert_allclose(mean, g["mean"], rtol=1e-13)
+
+
+def test_host_scalars(golden):
+    g = golden("g7_host_scalars.npz")
+    for nb in (15, 20, 21):
+        m = O.twod_mask(nb)
+        assert np.array_equal(m, g["mask_%d" % nb])
+        assert int(m.sum()) == int(g["npix_%d" % nb])
+        assert O.n_bootstrap(int(m.sum())) == int(g["nboot_%d" % nb])
+    assert np.array_equal(O.bootstrap_indices(10, 4), g["boot_n10"])
+    assert np.array_equal(O.bootstrap_indices(1000, 3), g["boot_n1000"])
+    assert int(g["nboot_21"]) == 444 and int(g["npix_21"]) == 221
+
+
+def test_kk_twod_vs_naive_loop():
+    """Exact pair binner against a pure-Python double loop (small n)."""
+    rng = np.random.default_rng(0)
+    n, nb, mx = 60, 7, 0.4
+    x, y = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    k = rng.standard_normal(n); w = rng.uniform(0.5, 2, n)
+    xi, wt, npairs = O.kk_twod(x, y, k, w, 0.0, mx, nb)
+    bs = 2 * mx / nb
+    s_wkk = np.zeros(nb * nb); s_w = np.zeros(nb * nb); s_n = np.zeros(nb * nb)
+    for i in range(n):
+        for j in range(i + 1, n):
+            dx, dy = x[j] - x[i], y[j] - y[i]
+            if dx == 0 and dy == 0:
+                continue
+            if max(abs(dx), abs(dy)) >= mx:
+                continue
+            for s in (1, -1):
+                ix, iy = int((s * dx + mx) / bs), int((s * dy + mx) / bs)
+                if 0 <= ix < nb and 0 <= iy < nb:
+                    s_wkk[iy * nb + ix] += w[i] * w[j] * k[i] * k[j]
+                    s_w[iy * nb + ix] += w[i] * w[j]
+                    s_n[iy * nb + ix] += 1
+    assert np.array_equal(npairs, s_n)
+    np.testing.assert_allclose(wt, s_w, rtol=1e-13)
+    np.testing.assert_allclose(xi[s_w > 0], (s_wkk / np.where(s_w > 0, s_w, 1))[s_w > 0], rtol=1e-12, atol=1e-15)
+    # point symmetry the reference relies on (two_pcf.py:306-310)
+    np.testing.assert_allclose(xi.reshape(nb, nb), xi.reshape(nb, nb)[::-1, ::-1], rtol=1e-12, atol=1e-15)
