@@ -1,0 +1,150 @@
+/* tgp.h -- C-ABI of libtgp.so: the MI355X-native GP hot path behind treegp's Python API.
+ *
+ * The reference (PFLeget/treegp, pure Python) has no FFI of its own; it calls SciPy /
+ * TreeCorr at three seams.  Each entry point below replaces one of those seams and cites
+ * the reference lines it stands in for (paths relative to the reference root).
+ *
+ *   S1  kernel.__call__(X[,Y])           treegp/kernels.py:114-126, 249-276, 355-381
+ *   S2  cholesky + cho_solve (+ logdet)  treegp/gp_interp.py:180-182, treegp/log_likelihood.py:29-33
+ *   S3  HT @ alpha                       treegp/gp_interp.py:177,183
+ *   S3b posterior covariance             treegp/gp_interp.py:184-192
+ *   S4  treecorr KKCorrelation.process   treegp/two_pcf.py:297-305, 330-334, 342-362
+ *
+ * Conventions
+ *   - plain C types only; every array is C-contiguous float64 (or int64 where named so).
+ *   - pointers are HOST pointers unless the parameter name starts with d_ (device pointer).
+ *     The library never keeps a host pointer after the call returns.
+ *   - coordinates are always passed as (n, 2) row-major; 1-D problems pass a zero second
+ *     column (what treegp/two_pcf.py:250-251 does for the pair counter).
+ *   - return 0 = ok; > 0 = LAPACK-style "leading minor of order i is not positive definite"
+ *     (the Python shim raises numpy.linalg.LinAlgError, as scipy.linalg.cholesky does at
+ *     gp_interp.py:181); < 0 = argument / HIP error, text in tgp_last_error().
+ *   - a tgp_ctx owns one device, one stream and a grow-only workspace; it is not re-entrant.
+ */
+#ifndef TGP_H
+#define TGP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tgp_ctx tgp_ctx;
+typedef struct tgp_factor tgp_factor;
+
+/* kernel kinds (treegp/kernels.py + sklearn RBF); amp = sigma^2 of sklearn's
+ * Product(ConstantKernel(sigma^2), k) folded in: value = amp * k(x, x').               */
+enum {
+    TGP_RBF = 0,      /* sklearn RBF(l): a = c = 1/l^2, b = 0 filled by the caller       */
+    TGP_ARBF = 1,     /* AnisotropicRBF: exp(-0.5 q), q = a dx^2 + 2 b dx dy + c dy^2   */
+    TGP_VK = 2,       /* VonKarman(l):  u = |d|/l                                       */
+    TGP_AVK = 3       /* AnisotropicVonKarman: u = sqrt(q)                              */
+};                    /* von Karman: u^(5/6) K_{5/6}(2 pi u) / lim0, 1 at u == 0        */
+
+typedef struct {
+    int32_t kind;
+    int32_t _pad;
+    double amp;       /* sigma^2                                                       */
+    double a, b, c;   /* invLam[0,0], invLam[0,1], invLam[1,1]                          */
+    double ell;       /* VonKarman length_scale                                         */
+} tgp_kernel;
+
+/* ---- context ------------------------------------------------------------------------ */
+int tgp_init(const int *devices, int ndev, tgp_ctx **out);   /* ndev must be 1 (one process per GPU) */
+void tgp_destroy(tgp_ctx *ctx);
+const char *tgp_last_error(tgp_ctx *ctx);
+const char *tgp_version(void);
+int tgp_device_count(void);
+
+/* phase timings (ms, hipEvent on the ctx stream) of the last call that recorded them:
+ * [0] K build  [1] Cholesky total  [2] triangular solves  [3] predict  [4] pair binning
+ * [5] trailing-update (syrk) kernel time summed  [6] number of trailing-update launches
+ * [7] trailing-update flops (sum over launches)  [8] K-build bytes written  [9] H2D+D2H  */
+#define TGP_NTIMINGS 10
+int tgp_last_timings(tgp_ctx *ctx, double *ms, int n);
+/* when on (default off) the Cholesky brackets every trailing-update launch with events */
+int tgp_set_profiling(tgp_ctx *ctx, int on);
+
+/* ---- S1: kernel matrix (host buffers) --------------------------------------------------
+ * out (n, m) row-major = amp * k(X_i, Y_j).  Y == NULL: self kernel, out is (n, n) and the
+ * diagonal is exactly amp (kernels.py:121,261,367).                                      */
+int tgp_kernel_matrix(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n,
+                      const double *Y, int64_t m, double *out);
+
+/* ---- S2: alpha = (K + diag(yerr^2))^-1 y, logdet = sum 2 log diag(chol) ------------------
+ * K never leaves the device.  keep != NULL receives a handle on the device-resident factor
+ * (free with tgp_factor_free).  alpha may be NULL (log-likelihood only needs y.alpha, which
+ * is returned in *ydota when ydota != NULL).                                               */
+int tgp_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n,
+                 const double *y, const double *yerr, double *alpha, double *logdet,
+                 double *ydota, tgp_factor **keep);
+void tgp_factor_free(tgp_ctx *ctx, tgp_factor *f);
+
+/* ---- S3: ys[j] = sum_i amp k(Xs_j, X_i) alpha_i, HT never materialised -------------------*/
+int tgp_gp_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n,
+                   const double *alpha, const double *Xs, int64_t m, double *ys);
+
+/* ---- S3b: cov (m, m) = k(Xs,Xs) - HT K^-1 HT^T using a kept factor ------------------------*/
+int tgp_gp_predict_cov(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel *k, const double *X,
+                       int64_t n, const double *Xs, int64_t m, double *cov);
+
+/* ---- S4: binned scalar pair correlation, exact binning -----------------------------------
+ * w == NULL: unit weights.  TwoD: nbins x nbins pixels over [-max_sep, max_sep]^2, outputs
+ * of length nbins^2 (flat index iy*nbins+ix).  Log: nbins log-spaced bins in
+ * [min_sep, max_sep).  xi = sum(w_i w_j k_i k_j)/sum(w_i w_j), 0 where the weight is 0.     */
+int tgp_kk_twod(tgp_ctx *ctx, const double *x, const double *y, const double *k,
+                const double *w, int64_t n, double min_sep, double max_sep, int nbins,
+                double *xi, double *weight, double *npairs);
+int tgp_kk_log(tgp_ctx *ctx, const double *x, const double *y, const double *k,
+               const double *w, int64_t n, double min_sep, double max_sep, int nbins,
+               double *xi, double *weight, double *meanr, double *meanlogr, double *npairs);
+/* bootstrap (two_pcf.py:269-281, 342-362): idx is (n_boot, n) int64; resample b uses points
+ * idx[b,:], k = yv[idx] - mean(yv[idx]), w = 1/yerr[idx]^2 (unit weights if yerr == NULL or
+ * sum(yerr[idx]) == 0).  xi_out is (n_boot, nbins^2).                                       */
+int tgp_kk_twod_bootstrap(tgp_ctx *ctx, const double *x, const double *y, const double *yv,
+                          const double *yerr, int64_t n, const int64_t *idx, int64_t n_boot,
+                          double min_sep, double max_sep, int nbins, double *xi_out);
+
+/* ---- device-resident tier (bench / multi-GPU): same maths, d_ pointers, ctx stream --------*/
+int tgp_dev_alloc(tgp_ctx *ctx, int64_t bytes, void **d_out);
+int tgp_dev_free(tgp_ctx *ctx, void *d_ptr);
+int tgp_h2d(tgp_ctx *ctx, void *d_dst, const void *src, int64_t bytes);
+int tgp_d2h(tgp_ctx *ctx, void *dst, const void *d_src, int64_t bytes);
+int tgp_sync(tgp_ctx *ctx);
+void *tgp_stream(tgp_ctx *ctx);          /* the hipStream_t every kernel is launched on */
+
+/* d_X (n,2), d_y, d_yerr, d_alpha (n): resident inputs/outputs */
+int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,
+                   const double *d_y, const double *d_yerr, double *d_alpha, double *logdet,
+                   double *ydota, tgp_factor **keep);
+int tgp_d_gp_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,
+                     const double *d_alpha, const double *d_Xs, int64_t m, double *d_ys);
+
+/* ---- factor storage: packed lower panels ("panel-major") -----------------------------------
+ * Np = n rounded up to 256.  Panel p (p = 0 .. Np/256-1) holds rows 256p .. Np-1 of columns
+ * 256p .. 256p+255, row-major with leading dimension 256; panels are stored back to back.
+ * tgp_panel_elems(Np) doubles in total.  Element (i, j), i >= 256*(j/256):
+ *   off = tgp_panel_off(j/256, Np) + (i - 256*(j/256))*256 + j%256                            */
+int64_t tgp_panel_off(int64_t p, int64_t Np);
+int64_t tgp_panel_elems(int64_t Np);
+int64_t tgp_padded_n(int64_t n);
+
+/* building blocks, exposed for parity tests, profiling and the multi-GPU driver */
+int tgp_d_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,
+                       const double *d_yerr, double *d_A);
+/* in-place Cholesky of the packed lower matrix; d_W receives (Np/128) inverted 128x128
+ * diagonal blocks of L.  Returns 0 or the 1-based index of the first non-positive pivot. */
+int tgp_d_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W);
+/* d_b (Np) <- L^-T L^-1 d_b */
+int tgp_d_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b);
+/* unpack the lower triangle into a dense (n, n) row-major host matrix (upper part zero) */
+int tgp_d_unpack_lower(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *out);
+/* test hook: tile enumeration of the trailing update over T x T 128-tiles; fills (ti, tj)
+ * for every block id (-1 = empty slot) and returns the grid size, or -1 if cap is too small */
+int tgp_debug_tilemap(int64_t T, int32_t *ti, int32_t *tj, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGP_H */

@@ -1,0 +1,140 @@
+"""GPU parity tests of the C-ABI seams against the oracle (tests/ only use of oracle/)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tg():
+    from treegp_amd import _lib, ops
+    ctx = _lib.get_ctx()
+    return _lib, ops, ctx
+
+
+def _inv(size=0.05, e1=0.2, e2=0.1):
+    return np.linalg.inv(O.correlation_length_matrix(size, e1, e2))
+
+
+def _field(rng, n):
+    X = rng.uniform(0, 1, (n, 2))
+    y = np.sin(7 * X[:, 0]) * np.cos(5 * X[:, 1]) + 0.03 * rng.standard_normal(n)
+    yerr = 0.03 * rng.uniform(0.8, 1.2, n)
+    return X, y, yerr
+
+
+def test_mfma_layout_and_tilemap(tg):
+    """every lower-triangular tile is visited exactly once by the XCD-aware enumeration"""
+    _lib, ops, ctx = tg
+    lib = _lib.load_library()
+    for T in (1, 2, 7, 8, 9, 30, 64, 100):
+        cap = 4 * (T + 16) * (T + 16) + 4096
+        ti = np.empty(cap, np.int32); tj = np.empty(cap, np.int32)
+        g = lib.tgp_debug_tilemap(T, ti.ctypes.data_as(C.c_void_p), tj.ctypes.data_as(C.c_void_p), cap)
+        assert g > 0
+        ok = ti[:g] >= 0
+        pairs = set(zip(ti[:g][ok].tolist(), tj[:g][ok].tolist()))
+        assert len(pairs) == ok.sum() == T * (T + 1) // 2
+        assert all(0 <= b <= a < T for a, b in pairs)
+
+
+@pytest.mark.parametrize("kind", ["gauss", "vk", "avk"])
+def test_kernel_matrix_vs_oracle(tg, kind):
+    _lib, ops, ctx = tg
+    rng = np.random.default_rng(1)
+    X = rng.uniform(0, 1, (300, 2)); Y = rng.uniform(0, 1, (170, 2)); Y[:20] = X[:20]
+    invL = _inv(0.3, 0.2, -0.1)
+    kw = dict(amp=1.7, a=invL[0, 0], b=invL[0, 1], c=invL[1, 1], ell=0.4)
+    spec = ops.KernelSpec({"gauss": _lib.TGP_ARBF, "vk": _lib.TGP_VK, "avk": _lib.TGP_AVK}[kind], **kw)
+    np.testing.assert_allclose(ops.kernel_matrix(spec, X), O.kernel_matrix(kind, X, **kw), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(ops.kernel_matrix(spec, Y, X), O.kernel_matrix(kind, Y, X, **kw), rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("n", [200, 512, 1000])
+def test_kbuild_and_potrf_vs_numpy(tg, n):
+    _lib, ops, ctx = tg
+    lib = _lib.load_library()
+    rng = np.random.default_rng(n)
+    X, y, yerr = _field(rng, n)
+    invL = _inv()
+    spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=invL[0, 0], b=invL[0, 1], c=invL[1, 1])
+    Np = lib.tgp_padded_n(n)
+    dX = ops.DeviceBuffer.from_array(ctx, X); de = ops.DeviceBuffer.from_array(ctx, yerr)
+    dA = ops.DeviceBuffer(ctx, lib.tgp_panel_elems(Np) * 8); dW = ops.DeviceBuffer(ctx, Np * 128 * 8)
+    _lib.check(ctx, lib.tgp_d_kbuild_lower(ctx, C.byref(spec.to_c()), dX.ptr, n, de.ptr, dA.ptr), "kbuild")
+    Kd = np.empty((n, n))
+    _lib.check(ctx, lib.tgp_d_unpack_lower(ctx, dA.ptr, Np, n, Kd.ctypes.data_as(C.c_void_p)), "unpack")
+    Kref = O.kernel_matrix("gauss", X, amp=1.0, a=invL[0, 0], b=invL[0, 1], c=invL[1, 1]) + np.diag(yerr ** 2)
+    np.testing.assert_allclose(Kd, np.tril(Kref), rtol=1e-13, atol=1e-15)
+    info = lib.tgp_d_potrf(ctx, dA.ptr, Np, dW.ptr)
+    assert info == 0
+    Ld = np.empty((n, n))
+    _lib.check(ctx, lib.tgp_d_unpack_lower(ctx, dA.ptr, Np, n, Ld.ctypes.data_as(C.c_void_p)), "unpack")
+    Lref = np.linalg.cholesky(Kref)
+    np.testing.assert_allclose(Ld, Lref, rtol=0, atol=1e-11 * np.abs(Lref).max())
+    np.testing.assert_allclose(Ld @ Ld.T, Kref, rtol=0, atol=1e-13 * n)
+    # inverted diagonal blocks
+    W = dW.to_array((Np // 128, 128, 128))
+    L0 = Lref[:128, :128] if n >= 128 else None
+    if L0 is not None:
+        np.testing.assert_allclose(W[0] @ L0, np.eye(128), atol=1e-10)
+    # triangular solves on the padded right-hand side
+    b = np.zeros(Np); b[:n] = y
+    db = ops.DeviceBuffer.from_array(ctx, b)
+    _lib.check(ctx, lib.tgp_d_potrs(ctx, dA.ptr, dW.ptr, Np, db.ptr), "potrs")
+    alpha = db.to_array((Np,))[:n]
+    ref = np.linalg.solve(Kref, y)
+    np.testing.assert_allclose(alpha, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n,m", [(40, 33), (777, 1500), (2048, 4096)])
+def test_gp_solve_predict_vs_oracle(tg, n, m):
+    _lib, ops, ctx = tg
+    rng = np.random.default_rng(n + m)
+    X, y, yerr = _field(rng, n)
+    Xs = rng.uniform(0, 1, (m, 2))
+    invL = _inv()
+    kw = dict(amp=0.9, a=invL[0, 0], b=invL[0, 1], c=invL[1, 1])
+    spec = ops.KernelSpec(_lib.TGP_ARBF, **kw)
+    alpha, logdet, ydota, _ = ops.gp_solve(spec, X, y, yerr)
+    K = O.kernel_matrix("gauss", X, **kw)
+    a_ref, ld_ref = O.gp_solve(K, y, yerr)
+    np.testing.assert_allclose(alpha, a_ref, rtol=0, atol=1e-9 * np.abs(a_ref).max())
+    np.testing.assert_allclose(logdet, ld_ref, rtol=1e-12)
+    np.testing.assert_allclose(ydota, y @ a_ref, rtol=1e-10)
+    yp = ops.gp_predict(spec, X, alpha, Xs)
+    yp_ref = O.gp_predict(O.kernel_matrix("gauss", Xs, X, **kw), a_ref)
+    # north-star tolerance: 1e-10 relative on predicted values
+    np.testing.assert_allclose(yp, yp_ref, rtol=0, atol=1e-10 * np.abs(yp_ref).max())
+
+
+def test_not_positive_definite_raises(tg):
+    _lib, ops, ctx = tg
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0, 1, (300, 2))
+    spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=1e-4, b=0.0, c=1e-4)     # near-constant kernel, no noise
+    with pytest.raises(np.linalg.LinAlgError):
+        ops.gp_solve(spec, X, np.ones(300), np.zeros(300))
+
+
+def test_golden_config1_and_aniso2d(tg, golden):
+    _lib, ops, ctx = tg
+    g = golden("g1_c1_rbf1d.npz")
+    spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=0.25, b=0.0, c=0.0)
+    mean = np.mean(g["y"])
+    alpha, logdet, ydota, _ = ops.gp_solve(spec, g["X"], g["y"] - mean, g["y_err"])
+    yp = ops.gp_predict(spec, g["X"], alpha, g["Xs"]) + mean
+    np.testing.assert_allclose(yp, g["y_pred"], rtol=0, atol=1e-10 * np.abs(g["y_pred"]).max())
+    ll = -0.5 * ydota - 0.5 * len(alpha) * np.log(2 * np.pi) - 0.5 * logdet
+    np.testing.assert_allclose(ll, g["logL"], rtol=1e-11)
+    g = golden("g2_aniso2d.npz")
+    iL = g["invLam"]
+    spec = ops.KernelSpec(_lib.TGP_ARBF, amp=float(g["amp"]), a=iL[0, 0], b=iL[0, 1], c=iL[1, 1])
+    mean = np.mean(g["y"])
+    alpha, _, _, _ = ops.gp_solve(spec, g["X"], g["y"] - mean, g["y_err_eff"])
+    yp = ops.gp_predict(spec, g["X"], alpha, g["Xs"]) + mean
+    np.testing.assert_allclose(yp, g["y_pred"], rtol=0, atol=1e-10 * np.abs(g["y_pred"]).max())

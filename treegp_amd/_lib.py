@@ -1,0 +1,139 @@
+"""ctypes binding of libtgp.so (include/tgp.h).  Thin plumbing only: no arithmetic here.
+
+The library is the product; there is no CPU fallback.  ``get_ctx()`` raises RuntimeError when
+the shared object is missing or no HIP device is present.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtgp.so")
+
+TGP_RBF, TGP_ARBF, TGP_VK, TGP_AVK = 0, 1, 2, 3
+NTIMINGS = 10
+
+
+class TgpKernel(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("amp", C.c_double), ("a", C.c_double),
+                ("b", C.c_double), ("c", C.c_double), ("ell", C.c_double)]
+
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); must list every function declared in include/tgp.h
+SIGNATURES = {
+    "tgp_init": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
+    "tgp_destroy": (None, [_vp]),
+    "tgp_last_error": (C.c_char_p, [_vp]),
+    "tgp_version": (C.c_char_p, []),
+    "tgp_device_count": (C.c_int, []),
+    "tgp_last_timings": (C.c_int, [_vp, _dp, C.c_int]),
+    "tgp_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "tgp_kernel_matrix": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _i64, _vp]),
+    "tgp_gp_solve": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp, _vp, _dp, _dp, C.POINTER(_vp)]),
+    "tgp_factor_free": (None, [_vp, _vp]),
+    "tgp_gp_predict": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp, _i64, _vp]),
+    "tgp_gp_predict_cov": (C.c_int, [_vp, _vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _i64, _vp]),
+    "tgp_kk_twod": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp]),
+    "tgp_kk_log": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "tgp_kk_twod_bootstrap": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, C.c_double, C.c_double, C.c_int, _vp]),
+    "tgp_dev_alloc": (C.c_int, [_vp, _i64, C.POINTER(_vp)]),
+    "tgp_dev_free": (C.c_int, [_vp, _vp]),
+    "tgp_h2d": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "tgp_d2h": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "tgp_sync": (C.c_int, [_vp]),
+    "tgp_stream": (_vp, [_vp]),
+    "tgp_d_gp_solve": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp, _vp, _dp, _dp, C.POINTER(_vp)]),
+    "tgp_d_gp_predict": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp, _i64, _vp]),
+    "tgp_panel_off": (_i64, [_i64, _i64]),
+    "tgp_panel_elems": (_i64, [_i64]),
+    "tgp_padded_n": (_i64, [_i64]),
+    "tgp_d_kbuild_lower": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp]),
+    "tgp_d_potrf": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "tgp_d_potrs": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "tgp_d_unpack_lower": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    "tgp_debug_tilemap": (C.c_int, [_i64, _vp, _vp, _i64]),
+}
+
+_lib = None
+_ctx = {}
+_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libtgp.so and set the prototypes.  Works without a GPU (no HIP call is made)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libtgp.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C treegp_amd/csrc`" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            if not hasattr(lib, name) and name in ("tgp_gp_predict_cov", "tgp_kk_twod", "tgp_kk_log", "tgp_kk_twod_bootstrap"):
+                continue      # TEMP while kk.hip / cov.hip are being written
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class TgpError(RuntimeError):
+    pass
+
+
+def get_ctx(device=None):
+    """One context per (process, device).  Raises if there is no HIP device -- by design."""
+    lib = load_library()
+    if device is None:
+        device = int(os.environ.get("TGP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    with _lock:
+        if device not in _ctx:
+            if lib.tgp_device_count() <= 0:
+                raise RuntimeError("treegp_amd needs an AMD GPU (HIP device); none found and there is no CPU path")
+            h = _vp()
+            dev = (C.c_int * 1)(device)
+            rc = lib.tgp_init(dev, 1, C.byref(h))
+            if rc != 0:
+                raise RuntimeError("tgp_init(device=%d) failed with code %d" % (device, rc))
+            _ctx[device] = h
+        return _ctx[device]
+
+
+def check(ctx, rc, what):
+    """rc < 0 -> TgpError with the library's message; rc > 0 is returned to the caller."""
+    if rc < 0:
+        msg = load_library().tgp_last_error(ctx)
+        raise TgpError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+    return rc
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def as_xy(X):
+    """(n, ndim in {1,2}) -> contiguous (n, 2) float64, zero second column for 1-D."""
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim == 1:
+        X = X.reshape(-1, 1)
+    if X.shape[1] == 1:
+        X = np.hstack([X, np.zeros_like(X)])
+    elif X.shape[1] != 2:
+        raise ValueError("only 1-D and 2-D coordinates are supported, got ndim=%d" % X.shape[1])
+    return np.ascontiguousarray(X)
+
+
+def timings(ctx):
+    buf = (C.c_double * NTIMINGS)()
+    load_library().tgp_last_timings(ctx, buf, NTIMINGS)
+    return list(buf)

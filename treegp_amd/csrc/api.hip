@@ -1,0 +1,378 @@
+// C-ABI glue of libtgp.so (include/tgp.h): context, staging of host buffers, phase timings.
+#include "tgp_internal.h"
+
+namespace {
+struct Arena {               // bump allocator over the ctx staging buffer (sized up front)
+    char *base;
+    size_t off = 0;
+    template <typename T> T *take(size_t count) {
+        T *p = reinterpret_cast<T *>(base + off);
+        off += (count * sizeof(T) + 255) / 256 * 256;
+        return p;
+    }
+};
+inline size_t rup(size_t b) { return (b + 255) / 256 * 256; }
+
+struct Staging {
+    void *buf = nullptr;
+    size_t bytes = 0;
+};
+Staging g_dummy;
+}  // namespace
+
+// per-ctx staging lives in a side table keyed by ctx (keeps tgp_ctx POD-ish)
+struct tgp_ctx_ext {
+    Staging io;
+    double *A_cache = nullptr;   // packed lower panels, reused across solves of the same size
+    double *W_cache = nullptr;
+    int64_t cache_Np = 0;
+};
+static tgp_ctx_ext *ext_of(tgp_ctx *ctx);
+
+struct tgp_ctx_full : tgp_ctx {
+    tgp_ctx_ext ext;
+};
+static tgp_ctx_ext *ext_of(tgp_ctx *ctx) { return &static_cast<tgp_ctx_full *>(ctx)->ext; }
+
+int tgp_ensure_scratch(tgp_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_bytes) return 0;
+    if (ctx->scratch) TGP_HIP(hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    TGP_HIP(hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return 0;
+}
+
+static int ensure_io(tgp_ctx *ctx, size_t bytes) {
+    Staging &s = ext_of(ctx)->io;
+    if (bytes <= s.bytes) return 0;
+    if (s.buf) TGP_HIP(hipFree(s.buf));
+    s.buf = nullptr;
+    s.bytes = 0;
+    TGP_HIP(hipMalloc(&s.buf, bytes));
+    s.bytes = bytes;
+    return 0;
+}
+
+static int ensure_factor_cache(tgp_ctx *ctx, int64_t Np) {
+    tgp_ctx_ext *e = ext_of(ctx);
+    if (e->A_cache && e->cache_Np == Np) return 0;
+    if (e->A_cache) TGP_HIP(hipFree(e->A_cache));
+    if (e->W_cache) TGP_HIP(hipFree(e->W_cache));
+    e->A_cache = e->W_cache = nullptr;
+    e->cache_Np = 0;
+    TGP_HIP(hipMalloc((void **)&e->A_cache, (size_t)tgp_panel_elems(Np) * sizeof(double)));
+    TGP_HIP(hipMalloc((void **)&e->W_cache, (size_t)Np * TGP_TB * sizeof(double)));
+    e->cache_Np = Np;
+    return 0;
+}
+
+extern "C" {
+
+const char *tgp_version(void) { return "treegp_amd libtgp 0.1 (gfx950)"; }
+
+int tgp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int tgp_init(const int *devices, int ndev, tgp_ctx **out) {
+    if (!out || ndev != 1 || !devices) return -1;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -3;   // no HIP device: fail loudly
+    if (devices[0] < 0 || devices[0] >= n) return -1;
+    tgp_ctx_full *ctx = new tgp_ctx_full();
+    ctx->device = devices[0];
+    if (hipSetDevice(ctx->device) != hipSuccess) { delete ctx; return -2; }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return -2; }
+    for (auto &e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete ctx; return -2; }
+    if (hipMalloc((void **)&ctx->d_info, 256) != hipSuccess) { delete ctx; return -2; }
+    if (hipHostMalloc((void **)&ctx->h_info, 256, hipHostMallocDefault) != hipSuccess) { delete ctx; return -2; }
+    if (hipMalloc((void **)&ctx->d_scal, 16 * sizeof(double)) != hipSuccess) { delete ctx; return -2; }
+    if (hipHostMalloc((void **)&ctx->h_scal, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess) { delete ctx; return -2; }
+    *out = ctx;
+    return 0;
+}
+
+void tgp_destroy(tgp_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    tgp_ctx_ext *e = ext_of(ctx);
+    if (e->io.buf) (void)hipFree(e->io.buf);
+    if (e->A_cache) (void)hipFree(e->A_cache);
+    if (e->W_cache) (void)hipFree(e->W_cache);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->d_info) (void)hipFree(ctx->d_info);
+    if (ctx->h_info) (void)hipHostFree(ctx->h_info);
+    if (ctx->d_scal) (void)hipFree(ctx->d_scal);
+    if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
+    for (auto &ev : ctx->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : ctx->prof_events) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete static_cast<tgp_ctx_full *>(ctx);
+}
+
+const char *tgp_last_error(tgp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int tgp_last_timings(tgp_ctx *ctx, double *ms, int n) {
+    if (!ctx || !ms) return -1;
+    for (int i = 0; i < n && i < TGP_NTIMINGS; ++i) ms[i] = ctx->timings[i];
+    return 0;
+}
+
+int tgp_set_profiling(tgp_ctx *ctx, int on) {
+    if (!ctx) return -1;
+    ctx->profiling = on;
+    return 0;
+}
+
+int64_t tgp_panel_off(int64_t p, int64_t Np) { return panel_off(p, Np); }
+int64_t tgp_panel_elems(int64_t Np) { return panel_off(Np / TGP_PW, Np); }
+int64_t tgp_padded_n(int64_t n) { return padded_n(n); }
+
+int tgp_dev_alloc(tgp_ctx *ctx, int64_t bytes, void **d_out) {
+    TGP_ARG(bytes > 0 && d_out);
+    TGP_HIP(hipSetDevice(ctx->device));
+    TGP_HIP(hipMalloc(d_out, (size_t)bytes));
+    return 0;
+}
+int tgp_dev_free(tgp_ctx *ctx, void *d_ptr) {
+    TGP_HIP(hipStreamSynchronize(ctx->stream));
+    TGP_HIP(hipFree(d_ptr));
+    return 0;
+}
+int tgp_h2d(tgp_ctx *ctx, void *d_dst, const void *src, int64_t bytes) {
+    TGP_HIP(hipMemcpyAsync(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    TGP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int tgp_d2h(tgp_ctx *ctx, void *dst, const void *d_src, int64_t bytes) {
+    TGP_HIP(hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TGP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int tgp_sync(tgp_ctx *ctx) {
+    TGP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+void *tgp_stream(tgp_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ---- building blocks ---------------------------------------------------------------------
+int tgp_d_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_yerr,
+                       double *d_A) {
+    TGP_ARG(k && d_X && d_A && n > 0);
+    TGP_HIP(hipSetDevice(ctx->device));
+    const int64_t Np = padded_n(n);
+    TGP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    int rc = launch_kbuild_lower(ctx, k, d_X, n, Np, d_yerr, d_A);
+    if (rc) return rc;
+    TGP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    TGP_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timings[0] = ms;
+    ctx->timings[8] = 8.0 * ((double)Np * (Np + 1) / 2.0) + 16.0 * (double)Np;
+    return 0;
+}
+
+int tgp_d_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
+    TGP_ARG(d_A && d_W);
+    TGP_HIP(hipSetDevice(ctx->device));
+    TGP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    int info = launch_potrf(ctx, d_A, Np, d_W);
+    if (info < 0) return info;
+    TGP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    TGP_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timings[1] = ms;
+    return info;
+}
+
+int tgp_d_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b) {
+    TGP_ARG(d_A && d_W && d_b && Np % TGP_PW == 0);
+    TGP_HIP(hipSetDevice(ctx->device));
+    TGP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    int rc = launch_potrs(ctx, d_A, d_W, Np, d_b);
+    if (rc) return rc;
+    TGP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    TGP_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timings[2] = ms;
+    return 0;
+}
+
+int tgp_d_unpack_lower(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *out) {
+    TGP_ARG(d_A && out && n > 0 && n <= Np);
+    TGP_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_io(ctx, (size_t)n * n * sizeof(double));
+    if (rc) return rc;
+    double *d_out = (double *)ext_of(ctx)->io.buf;
+    rc = launch_unpack_lower(ctx, d_A, Np, n, d_out);
+    if (rc) return rc;
+    TGP_HIP(hipMemcpyAsync(out, d_out, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TGP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- S2 -------------------------------------------------------------------------------------
+int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_y,
+                   const double *d_yerr, double *d_alpha, double *logdet, double *ydota, tgp_factor **keep) {
+    TGP_ARG(k && d_X && d_y && n > 0);
+    TGP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t Np = padded_n(n);
+    int rc = ensure_factor_cache(ctx, Np);
+    if (rc) return rc;
+    tgp_ctx_ext *e = ext_of(ctx);
+    double *d_A = e->A_cache, *d_W = e->W_cache;
+    rc = tgp_ensure_scratch(ctx, (size_t)Np * sizeof(double));
+    if (rc) return rc;
+    double *d_b = (double *)ctx->scratch;
+
+    TGP_HIP(hipEventRecord(ctx->ev[0], st));
+    rc = launch_kbuild_lower(ctx, k, d_X, n, Np, d_yerr, d_A);
+    if (rc) return rc;
+    TGP_HIP(hipEventRecord(ctx->ev[1], st));
+    int info = launch_potrf(ctx, d_A, Np, d_W);      // synchronises
+    if (info < 0) return info;
+    TGP_HIP(hipEventRecord(ctx->ev[2], st));
+    if (info == 0) {
+        TGP_HIP(hipMemsetAsync(d_b, 0, (size_t)Np * sizeof(double), st));
+        TGP_HIP(hipMemcpyAsync(d_b, d_y, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        rc = launch_potrs(ctx, d_A, d_W, Np, d_b);
+        if (rc) return rc;
+        rc = launch_logdet(ctx, d_A, Np, n, ctx->d_scal);
+        if (rc) return rc;
+        rc = launch_dot(ctx, d_y, d_b, n, ctx->d_scal + 1);
+        if (rc) return rc;
+        if (d_alpha) TGP_HIP(hipMemcpyAsync(d_alpha, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        TGP_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    TGP_HIP(hipEventRecord(ctx->ev[3], st));
+    TGP_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timings[0] = ms;
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+    ctx->timings[1] = ms;
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+    ctx->timings[2] = ms;
+    ctx->timings[8] = 8.0 * ((double)Np * (Np + 1) / 2.0) + 16.0 * (double)Np;
+    if (info > 0) {
+        if (info > n) info = (int)n;     // cannot happen (padding is the identity); defensive
+        return info;
+    }
+    if (logdet) *logdet = ctx->h_scal[0];
+    if (ydota) *ydota = ctx->h_scal[1];
+    if (keep) {
+        tgp_factor *f = new tgp_factor();
+        f->n = n;
+        f->Np = Np;
+        f->d_A = d_A;
+        f->d_W = d_W;
+        e->A_cache = e->W_cache = nullptr;      // ownership moves to the handle
+        e->cache_Np = 0;
+        *keep = f;
+    }
+    return 0;
+}
+
+int tgp_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n, const double *y,
+                 const double *yerr, double *alpha, double *logdet, double *ydota, tgp_factor **keep) {
+    TGP_ARG(k && X && y && n > 0);
+    TGP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc = ensure_io(ctx, rup(2 * n * 8) + 3 * rup(n * 8));
+    if (rc) return rc;
+    Arena ar{(char *)ext_of(ctx)->io.buf};
+    double *d_X = ar.take<double>(2 * n), *d_y = ar.take<double>(n), *d_e = ar.take<double>(n),
+           *d_a = ar.take<double>(n);
+    TGP_HIP(hipMemcpyAsync(d_X, X, 2 * n * 8, hipMemcpyHostToDevice, st));
+    TGP_HIP(hipMemcpyAsync(d_y, y, n * 8, hipMemcpyHostToDevice, st));
+    if (yerr) TGP_HIP(hipMemcpyAsync(d_e, yerr, n * 8, hipMemcpyHostToDevice, st));
+    rc = tgp_d_gp_solve(ctx, k, d_X, n, d_y, yerr ? d_e : nullptr, d_a, logdet, ydota, keep);
+    if (rc) return rc;
+    if (alpha) {
+        TGP_HIP(hipMemcpyAsync(alpha, d_a, n * 8, hipMemcpyDeviceToHost, st));
+        TGP_HIP(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+void tgp_factor_free(tgp_ctx *ctx, tgp_factor *f) {
+    if (!f) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (f->d_A) (void)hipFree(f->d_A);
+    if (f->d_W) (void)hipFree(f->d_W);
+    delete f;
+}
+
+// ---- S3 ---------------------------------------------------------------------------------------
+int tgp_d_gp_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_alpha,
+                     const double *d_Xs, int64_t m, double *d_ys) {
+    TGP_ARG(k && d_X && d_alpha && d_Xs && d_ys);
+    TGP_HIP(hipSetDevice(ctx->device));
+    TGP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    int rc = launch_predict(ctx, k, d_X, n, d_alpha, d_Xs, m, d_ys);
+    if (rc) return rc;
+    TGP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    TGP_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timings[3] = ms;
+    return 0;
+}
+
+int tgp_gp_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n, const double *alpha,
+                   const double *Xs, int64_t m, double *ys) {
+    TGP_ARG(k && X && alpha && Xs && ys && n > 0 && m > 0);
+    TGP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc = ensure_io(ctx, rup(2 * n * 8) + rup(n * 8) + rup(2 * m * 8) + rup(m * 8));
+    if (rc) return rc;
+    Arena ar{(char *)ext_of(ctx)->io.buf};
+    double *d_X = ar.take<double>(2 * n), *d_a = ar.take<double>(n), *d_Xs = ar.take<double>(2 * m),
+           *d_ys = ar.take<double>(m);
+    TGP_HIP(hipMemcpyAsync(d_X, X, 2 * n * 8, hipMemcpyHostToDevice, st));
+    TGP_HIP(hipMemcpyAsync(d_a, alpha, n * 8, hipMemcpyHostToDevice, st));
+    TGP_HIP(hipMemcpyAsync(d_Xs, Xs, 2 * m * 8, hipMemcpyHostToDevice, st));
+    rc = tgp_d_gp_predict(ctx, k, d_X, n, d_a, d_Xs, m, d_ys);
+    if (rc) return rc;
+    TGP_HIP(hipMemcpyAsync(ys, d_ys, m * 8, hipMemcpyDeviceToHost, st));
+    TGP_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ---- S1 ---------------------------------------------------------------------------------------
+int tgp_kernel_matrix(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n, const double *Y, int64_t m,
+                      double *out) {
+    TGP_ARG(k && X && out && n > 0);
+    const int self = (Y == nullptr);
+    if (self) m = n;
+    TGP_ARG(m > 0);
+    TGP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc = ensure_io(ctx, rup(2 * n * 8) + rup(2 * m * 8) + rup((size_t)n * m * 8));
+    if (rc) return rc;
+    Arena ar{(char *)ext_of(ctx)->io.buf};
+    double *d_X = ar.take<double>(2 * n), *d_Y = ar.take<double>(2 * m), *d_o = ar.take<double>((size_t)n * m);
+    TGP_HIP(hipMemcpyAsync(d_X, X, 2 * n * 8, hipMemcpyHostToDevice, st));
+    if (!self) TGP_HIP(hipMemcpyAsync(d_Y, Y, 2 * m * 8, hipMemcpyHostToDevice, st));
+    rc = launch_kernel_dense(ctx, k, d_X, n, self ? d_X : d_Y, m, self, d_o);
+    if (rc) return rc;
+    TGP_HIP(hipMemcpyAsync(out, d_o, (size_t)n * m * 8, hipMemcpyDeviceToHost, st));
+    TGP_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// Kernel-matrix build (seam S1 of include/tgp.h).
+//   kbuild_lower : K + diag(yerr^2) written straight into the packed lower panels the
+//                  Cholesky consumes (treegp/gp_interp.py:180 fused with kernels.py:114-121);
+//                  HBM-write-bound for the Gaussian kernel, VALU-bound for von Karman.
+//   kernel_dense : dense (n, m) k(X, Y) for the host-facing kernel.__call__ replacement.
+#include "tgp_internal.h"
+#include "kernel_eval.h"
+
+// One 128x128 tile per workgroup of 256 threads.  Lane l of wave w owns columns 2l, 2l+1 and
+// rows w, w+4, ... of the tile, so each wave-instruction stores one full 1 KiB row segment.
+template <int KE>
+__global__ __launch_bounds__(256) void kbuild_lower_kernel(KParams p, const double *__restrict__ X, int64_t n,
+                                                           int64_t Np, const double *__restrict__ yerr,
+                                                           double *__restrict__ A) {
+    // triangular tile enumeration: b -> (ti, tj), tj <= ti
+    const int64_t b = blockIdx.x;
+    int64_t ti = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > b) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    const int64_t tj = b - ti * (ti + 1) / 2;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t pj = tj >> 1;
+    double *tile = A + panel_off(pj, Np) + (ti * TGP_TB - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
+
+    const int64_t j0 = tj * TGP_TB + 2 * lane;
+    double xj0 = 0, yj0 = 0, xj1 = 0, yj1 = 0;
+    if (j0 < n) { xj0 = X[2 * j0]; yj0 = X[2 * j0 + 1]; }
+    if (j0 + 1 < n) { xj1 = X[2 * j0 + 2]; yj1 = X[2 * j0 + 3]; }
+
+    const bool diag_tile = (ti == tj);
+    const bool pad_tile = (ti * TGP_TB + TGP_TB > n);   // rows (and maybe columns) beyond n
+
+#pragma unroll 4
+    for (int r = wave; r < TGP_TB; r += 4) {
+        const int64_t i = ti * TGP_TB + r;
+        double2 v;
+        if (!pad_tile || i < n) {
+            const double xi = X[2 * (i < n ? i : 0)], yi = X[2 * (i < n ? i : 0) + 1];   // wave-uniform
+            v.x = kernel_value<KE>(p, xi - xj0, yi - yj0);
+            v.y = kernel_value<KE>(p, xi - xj1, yi - yj1);
+            if (diag_tile) {
+                // exact diagonal (kernels.py:121) + noise (gp_interp.py:180)
+                if (i == j0) { const double e = yerr ? yerr[i] : 0.0; v.x = p.amp + e * e; }
+                if (i == j0 + 1) { const double e = yerr ? yerr[i] : 0.0; v.y = p.amp + e * e; }
+            }
+            if (pad_tile) {
+                if (j0 >= n) v.x = 0.0;
+                if (j0 + 1 >= n) v.y = 0.0;
+            }
+        } else {
+            // padded rows: identity, so the padded factor is [[L, 0], [0, I]]
+            v.x = (i == j0) ? 1.0 : 0.0;
+            v.y = (i == j0 + 1) ? 1.0 : 0.0;
+        }
+        *reinterpret_cast<double2 *>(tile + (int64_t)r * TGP_PW + 2 * lane) = v;
+    }
+}
+
+int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,
+                        const double *d_yerr, double *d_A) {
+    const int ke = kind_to_ke(k->kind);
+    TGP_ARG(ke >= 0);
+    const KParams p = make_kparams(k);
+    const int64_t T = Np / TGP_TB;
+    const int64_t nt = T * (T + 1) / 2;
+    dim3 grid((unsigned)nt), block(256);
+    switch (ke) {
+        case KE_GAUSS: kbuild_lower_kernel<KE_GAUSS><<<grid, block, 0, ctx->stream>>>(p, d_X, n, Np, d_yerr, d_A); break;
+        case KE_VK: kbuild_lower_kernel<KE_VK><<<grid, block, 0, ctx->stream>>>(p, d_X, n, Np, d_yerr, d_A); break;
+        default: kbuild_lower_kernel<KE_AVK><<<grid, block, 0, ctx->stream>>>(p, d_X, n, Np, d_yerr, d_A); break;
+    }
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+
+// dense out[i*m + j] = amp k(X_i, Y_j); self != 0: Y == X and the diagonal is exactly amp.
+template <int KE>
+__global__ __launch_bounds__(256) void kernel_dense_kernel(KParams p, const double *__restrict__ X, int64_t n,
+                                                           const double *__restrict__ Y, int64_t m, int self,
+                                                           double *__restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.y * 16;
+    if (j >= m) return;
+    const double xj = Y[2 * j], yj = Y[2 * j + 1];
+    for (int r = 0; r < 16; ++r) {
+        const int64_t i = i0 + r;
+        if (i >= n) break;
+        double v = kernel_value<KE>(p, X[2 * i] - xj, X[2 * i + 1] - yj);
+        if (self && i == j) v = p.amp;
+        out[i * m + j] = v;
+    }
+}
+
+int launch_kernel_dense(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_Y,
+                        int64_t m, int self, double *d_out) {
+    const int ke = kind_to_ke(k->kind);
+    TGP_ARG(ke >= 0);
+    const KParams p = make_kparams(k);
+    dim3 grid((unsigned)((m + 255) / 256), (unsigned)((n + 15) / 16)), block(256);
+    switch (ke) {
+        case KE_GAUSS: kernel_dense_kernel<KE_GAUSS><<<grid, block, 0, ctx->stream>>>(p, d_X, n, d_Y, m, self, d_out); break;
+        case KE_VK: kernel_dense_kernel<KE_VK><<<grid, block, 0, ctx->stream>>>(p, d_X, n, d_Y, m, self, d_out); break;
+        default: kernel_dense_kernel<KE_AVK><<<grid, block, 0, ctx->stream>>>(p, d_X, n, d_Y, m, self, d_out); break;
+    }
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+
+// packed lower panels -> dense (n, n) row-major, upper part zero (tests / posterior cov)
+__global__ __launch_bounds__(256) void unpack_lower_kernel(const double *__restrict__ A, int64_t Np, int64_t n,
+                                                           double *__restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.y * 256 + threadIdx.x;
+    const int64_t i = blockIdx.x;
+    if (j >= n) return;
+    double v = 0.0;
+    if (j <= i) {
+        const int64_t p = j >> 8;
+        v = A[panel_off(p, Np) + (i - p * TGP_PW) * TGP_PW + (j & 255)];
+    }
+    out[i * n + j] = v;
+}
+
+int launch_unpack_lower(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out) {
+    dim3 grid((unsigned)n, (unsigned)((n + 255) / 256)), block(256);
+    unpack_lower_kernel<<<grid, block, 0, ctx->stream>>>(d_A, Np, n, d_out);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}

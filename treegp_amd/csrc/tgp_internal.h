@@ -1,0 +1,99 @@
+// Internal declarations shared by the HIP translation units of libtgp.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/tgp.h"
+
+#define TGP_TB 128            // tile / diagonal-block size
+#define TGP_PW 256            // panel width = trailing-update depth
+
+struct tgp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    double timings[TGP_NTIMINGS] = {0};
+    int profiling = 0;
+    hipEvent_t ev[8] = {nullptr};
+    // grow-only scratch
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int *d_info = nullptr;        // first failing pivot (1-based), 0 = ok
+    int *h_info = nullptr;        // pinned mirror
+    double *d_scal = nullptr;     // small device scalars (logdet, dot, ...)
+    double *h_scal = nullptr;     // pinned mirror (16 doubles)
+    std::vector<hipEvent_t> prof_events;
+};
+
+struct tgp_factor {
+    int64_t n = 0, Np = 0;
+    double *d_A = nullptr;        // packed lower panels
+    double *d_W = nullptr;        // inverted 128x128 diagonal blocks
+};
+
+#define TGP_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);               \
+            return -2;                                                                  \
+        }                                                                               \
+    } while (0)
+
+#define TGP_ARG(cond)                                                                   \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            ctx->err = std::string("bad argument: ") + #cond;                           \
+            return -1;                                                                  \
+        }                                                                               \
+    } while (0)
+
+__host__ __device__ inline int64_t panel_off(int64_t p, int64_t Np) {
+    return (int64_t)TGP_PW * (p * Np - (int64_t)(TGP_PW / 2) * p * (p - 1));
+}
+__host__ __device__ inline int64_t padded_n(int64_t n) {
+    return (n + TGP_PW - 1) / TGP_PW * TGP_PW;
+}
+
+// trailing-update tile enumeration (XCD-aware): see chol.hip
+__host__ __device__ inline int64_t tilemap_grid(int64_t T) {
+    int64_t S = (T + 7) / 8;                 // super-tiles per side
+    int64_t ns = S * (S + 1) / 2;            // lower-triangular super-tiles
+    return ((ns + 7) / 8) * 8 * 64;
+}
+// block id -> (ti, tj), or ti = -1 when the slot is empty
+__host__ __device__ inline void tilemap(int64_t b, int64_t T, int &ti, int &tj) {
+    int64_t S = (T + 7) / 8;
+    int64_t ns = S * (S + 1) / 2;
+    int xcd = (int)(b & 7);                  // blocks b, b+8, ... share an XCD (speed only)
+    int64_t slot = b >> 3;
+    int64_t st = (slot >> 6) * 8 + xcd;      // super-tile handled by this XCD group
+    int within = (int)(slot & 63);
+    if (st >= ns) { ti = -1; tj = -1; return; }
+    // st -> (Si, Sj), Sj <= Si, row-major triangular enumeration
+    int64_t Si = (int64_t)((sqrt(8.0 * (double)st + 1.0) - 1.0) * 0.5);
+    while (Si * (Si + 1) / 2 > st) --Si;
+    while ((Si + 1) * (Si + 2) / 2 <= st) ++Si;
+    int64_t Sj = st - Si * (Si + 1) / 2;
+    int i = (int)(Si * 8 + (within >> 3));
+    int j = (int)(Sj * 8 + (within & 7));
+    if (j > i || i >= T) { ti = -1; tj = -1; return; }
+    ti = i; tj = j;
+}
+
+// implemented across the .hip files
+int tgp_ensure_scratch(tgp_ctx *ctx, size_t bytes);
+int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,
+                        const double *d_yerr, double *d_A);
+int launch_kernel_dense(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,
+                        const double *d_Y, int64_t m, int self, double *d_out);
+int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W);
+int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b);
+int launch_logdet(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out);
+int launch_dot(tgp_ctx *ctx, const double *d_a, const double *d_b, int64_t n, double *d_out);
+int launch_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_alpha,
+                   const double *d_Xs, int64_t m, double *d_ys);
+int launch_unpack_lower(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out);

@@ -1,0 +1,146 @@
+// Triangular solves with the packed factor (scipy.linalg.cho_solve at treegp/gp_interp.py:182,
+// log_likelihood.py:31), log-determinant (log_likelihood.py:33) and y.alpha (log_likelihood.py:32).
+// HBM-bound: L is read once per sweep.  The 128x128 diagonal blocks were inverted by potrf128,
+// so each block step is a small GEMV with W followed by a streaming GEMV over the blocks below
+// (forward) or to the left (backward).
+#include "tgp_internal.h"
+
+namespace {
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// y <- W y   (W lower-triangular 128x128, ld 128), one workgroup
+__global__ __launch_bounds__(256) void diag_gemv_n_kernel(const double *__restrict__ W, double *y) {
+    __shared__ double ys[128];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < 128) ys[tid] = y[tid];
+    __syncthreads();
+    const double y0 = ys[2 * lane], y1 = ys[2 * lane + 1];
+    for (int r = w; r < 128; r += 4) {
+        const double2 a = *reinterpret_cast<const double2 *>(W + r * 128 + 2 * lane);
+        const double s = wave_sum(a.x * y0 + a.y * y1);
+        if (lane == 0) y[r] = s;
+    }
+}
+
+// y <- W^T y
+__global__ __launch_bounds__(256) void diag_gemv_t_kernel(const double *__restrict__ W, double *y) {
+    __shared__ double ys[128];
+    __shared__ double part[256];
+    const int tid = threadIdx.x;
+    if (tid < 128) ys[tid] = y[tid];
+    __syncthreads();
+    const int c = tid & 127, h = tid >> 7;
+    double s = 0.0;
+    for (int i = h * 64; i < h * 64 + 64; ++i) s += W[i * 128 + c] * ys[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid < 128) y[tid] = part[tid] + part[tid + 128];
+}
+
+// forward: y[r] -= L[r, 0:128] . z   for the rows below block kb; one wave per row
+__global__ __launch_bounds__(256) void fwd_update_kernel(const double *__restrict__ Lcol, int64_t rows,
+                                                         const double *__restrict__ z, double *y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const double2 zz = *reinterpret_cast<const double2 *>(z + 2 * lane);
+    for (int64_t r = wv; r < rows; r += (int64_t)gridDim.x * 4) {
+        const double2 a = *reinterpret_cast<const double2 *>(Lcol + r * TGP_PW + 2 * lane);
+        const double s = wave_sum(a.x * zz.x + a.y * zz.y);
+        if (lane == 0) y[r] -= s;
+    }
+}
+
+// backward: z[128 cb + c] -= sum_r L[128 kb + r, 128 cb + c] alpha_kb[r]   for cb = blockIdx.x < kb
+__global__ __launch_bounds__(256) void bwd_update_kernel(const double *__restrict__ A, int64_t Np, int kb,
+                                                         const double *__restrict__ akb, double *z) {
+    __shared__ double as[128];
+    __shared__ double part[256];
+    const int tid = threadIdx.x;
+    const int cb = blockIdx.x;
+    if (tid < 128) as[tid] = akb[tid];
+    __syncthreads();
+    const int64_t p = cb >> 1;
+    const double *blk = A + panel_off(p, Np) + ((int64_t)kb * TGP_TB - p * TGP_PW) * TGP_PW + (cb & 1) * TGP_TB;
+    const int c = tid & 127, h = tid >> 7;
+    double s = 0.0;
+#pragma unroll 8
+    for (int r = h * 64; r < h * 64 + 64; ++r) s += blk[(int64_t)r * TGP_PW + c] * as[r];
+    part[tid] = s;
+    __syncthreads();
+    if (tid < 128) z[(int64_t)cb * TGP_TB + tid] -= part[tid] + part[tid + 128];
+}
+
+__global__ __launch_bounds__(1024) void logdet_kernel(const double *__restrict__ A, int64_t Np, int64_t n,
+                                                      double *out) {
+    __shared__ double part[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int64_t p = i >> 8;
+        s += 2.0 * log(A[panel_off(p, Np) + (i - p * TGP_PW) * TGP_PW + (i & 255)]);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += part[k];
+        *out = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void dot_kernel(const double *__restrict__ a, const double *__restrict__ b,
+                                                   int64_t n, double *out) {
+    __shared__ double part[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += a[i] * b[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += part[k];
+        *out = t;
+    }
+}
+}  // namespace
+
+int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b) {
+    hipStream_t st = ctx->stream;
+    const int nb = (int)(Np / TGP_TB);
+    // forward: L z = b
+    for (int kb = 0; kb < nb; ++kb) {
+        diag_gemv_n_kernel<<<1, 256, 0, st>>>(d_W + (int64_t)kb * TGP_TB * TGP_TB, d_b + (int64_t)kb * TGP_TB);
+        const int64_t rows = Np - (int64_t)(kb + 1) * TGP_TB;
+        if (rows > 0) {
+            const int64_t p = kb >> 1;
+            const double *Lcol = d_A + panel_off(p, Np) + ((int64_t)(kb + 1) * TGP_TB - p * TGP_PW) * TGP_PW +
+                                 (kb & 1) * TGP_TB;
+            const unsigned g = (unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+            fwd_update_kernel<<<g, 256, 0, st>>>(Lcol, rows, d_b + (int64_t)kb * TGP_TB,
+                                                 d_b + (int64_t)(kb + 1) * TGP_TB);
+        }
+    }
+    // backward: L^T a = z
+    for (int kb = nb - 1; kb >= 0; --kb) {
+        diag_gemv_t_kernel<<<1, 256, 0, st>>>(d_W + (int64_t)kb * TGP_TB * TGP_TB, d_b + (int64_t)kb * TGP_TB);
+        if (kb > 0) bwd_update_kernel<<<kb, 256, 0, st>>>(d_A, Np, kb, d_b + (int64_t)kb * TGP_TB, d_b);
+    }
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_logdet(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out) {
+    logdet_kernel<<<1, 1024, 0, ctx->stream>>>(d_A, Np, n, d_out);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_dot(tgp_ctx *ctx, const double *d_a, const double *d_b, int64_t n, double *d_out) {
+    dot_kernel<<<1, 1024, 0, ctx->stream>>>(d_a, d_b, n, d_out);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}

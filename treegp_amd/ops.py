@@ -1,0 +1,180 @@
+"""NumPy-facing wrappers of the C-ABI seams (include/tgp.h).  Every function runs on the GPU
+through libtgp.so; nothing here computes on the host.
+
+A kernel is described by ``KernelSpec`` -- the plain numbers the device needs -- which
+``treegp_amd.kernels.kernel_to_spec`` derives from a scikit-learn kernel object.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import TgpKernel, check, f64, ptr, as_xy
+
+
+class KernelSpec(object):
+    __slots__ = ("kind", "amp", "a", "b", "c", "ell")
+
+    def __init__(self, kind, amp=1.0, a=1.0, b=0.0, c=1.0, ell=1.0):
+        self.kind, self.amp, self.a, self.b, self.c, self.ell = int(kind), float(amp), float(a), float(b), float(c), float(ell)
+
+    def to_c(self):
+        return TgpKernel(self.kind, 0, self.amp, self.a, self.b, self.c, self.ell)
+
+    def __repr__(self):
+        return "KernelSpec(kind=%d, amp=%r, a=%r, b=%r, c=%r, ell=%r)" % (self.kind, self.amp, self.a, self.b, self.c, self.ell)
+
+
+class Factor(object):
+    """Device-resident Cholesky factor handle (tgp_factor*), freed with the object."""
+
+    def __init__(self, ctx, handle, n):
+        self._ctx, self._h, self.n = ctx, handle, n
+
+    def free(self):
+        if self._h:
+            _lib.load_library().tgp_factor_free(self._ctx, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def kernel_matrix(spec, X, Y=None, ctx=None):
+    """amp * k(X, Y) as an (n, m) array; Y=None gives the self kernel with an exact diagonal.
+    Replaces kernel.__call__ (treegp/kernels.py:114-126, 249-276, 355-381)."""
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    X2 = as_xy(X)
+    n = X2.shape[0]
+    if Y is None:
+        out = np.empty((n, n))
+        rc = lib.tgp_kernel_matrix(ctx, C.byref(spec.to_c()), ptr(X2), n, None, 0, ptr(out))
+    else:
+        Y2 = as_xy(Y)
+        m = Y2.shape[0]
+        out = np.empty((n, m))
+        rc = lib.tgp_kernel_matrix(ctx, C.byref(spec.to_c()), ptr(X2), n, ptr(Y2), m, ptr(out))
+    check(ctx, rc, "tgp_kernel_matrix")
+    return out
+
+
+def gp_solve(spec, X, y, y_err=None, keep=False, want_alpha=True, ctx=None):
+    """(alpha, logdet, y.alpha, factor|None) for K = amp k(X) + diag(y_err^2).
+    Raises numpy.linalg.LinAlgError when K is not positive definite, as scipy.linalg.cholesky
+    does at treegp/gp_interp.py:181."""
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    X2 = as_xy(X)
+    n = X2.shape[0]
+    y = f64(y)
+    e = None if y_err is None else f64(y_err)
+    alpha = np.empty(n) if want_alpha else None
+    logdet, ydota = C.c_double(0.0), C.c_double(0.0)
+    h = C.c_void_p()
+    rc = lib.tgp_gp_solve(ctx, C.byref(spec.to_c()), ptr(X2), n, ptr(y), ptr(e), ptr(alpha), C.byref(logdet),
+                          C.byref(ydota), C.byref(h) if keep else None)
+    check(ctx, rc, "tgp_gp_solve")
+    if rc > 0:
+        raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % rc)
+    return alpha, logdet.value, ydota.value, (Factor(ctx, h, n) if keep else None)
+
+
+def gp_predict(spec, X, alpha, Xs, ctx=None):
+    """ys = k(Xs, X) @ alpha without materialising the cross kernel (gp_interp.py:177,183)."""
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    X2, Xs2 = as_xy(X), as_xy(Xs)
+    alpha = f64(alpha)
+    ys = np.empty(Xs2.shape[0])
+    rc = lib.tgp_gp_predict(ctx, C.byref(spec.to_c()), ptr(X2), X2.shape[0], ptr(alpha), ptr(Xs2), Xs2.shape[0], ptr(ys))
+    check(ctx, rc, "tgp_gp_predict")
+    return ys
+
+
+def gp_predict_cov(spec, factor, X, Xs, ctx=None):
+    """Posterior covariance k(Xs,Xs) - HT K^-1 HT^T (gp_interp.py:184-192) from a kept factor."""
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    X2, Xs2 = as_xy(X), as_xy(Xs)
+    m = Xs2.shape[0]
+    cov = np.empty((m, m))
+    rc = lib.tgp_gp_predict_cov(ctx, factor._h, C.byref(spec.to_c()), ptr(X2), X2.shape[0], ptr(Xs2), m, ptr(cov))
+    check(ctx, rc, "tgp_gp_predict_cov")
+    return cov
+
+
+def kk_twod(x, y, k, w, min_sep, max_sep, nbins, ctx=None):
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    x, y, k = f64(x), f64(y), f64(k)
+    w = None if w is None else f64(w)
+    nb2 = nbins * nbins
+    xi, wt, npairs = np.empty(nb2), np.empty(nb2), np.empty(nb2)
+    rc = lib.tgp_kk_twod(ctx, ptr(x), ptr(y), ptr(k), ptr(w), len(x), float(min_sep), float(max_sep), int(nbins),
+                         ptr(xi), ptr(wt), ptr(npairs))
+    check(ctx, rc, "tgp_kk_twod")
+    return xi, wt, npairs
+
+
+def kk_log(x, y, k, w, min_sep, max_sep, nbins, ctx=None):
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    x, y, k = f64(x), f64(y), f64(k)
+    w = None if w is None else f64(w)
+    out = [np.empty(nbins) for _ in range(5)]
+    rc = lib.tgp_kk_log(ctx, ptr(x), ptr(y), ptr(k), ptr(w), len(x), float(min_sep), float(max_sep), int(nbins),
+                        *[ptr(o) for o in out])
+    check(ctx, rc, "tgp_kk_log")
+    return tuple(out)       # xi, weight, meanr, meanlogr, npairs
+
+
+def kk_twod_bootstrap(x, y, yv, y_err, idx, min_sep, max_sep, nbins, ctx=None):
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    x, y, yv = f64(x), f64(y), f64(yv)
+    e = None if y_err is None else f64(y_err)
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    n_boot, n = idx.shape
+    assert n == len(x)
+    out = np.empty((n_boot, nbins * nbins))
+    rc = lib.tgp_kk_twod_bootstrap(ctx, ptr(x), ptr(y), ptr(yv), ptr(e), n, ptr(idx), n_boot, float(min_sep),
+                                   float(max_sep), int(nbins), ptr(out))
+    check(ctx, rc, "tgp_kk_twod_bootstrap")
+    return out
+
+
+# ---- device-resident tier ---------------------------------------------------------------------
+class DeviceBuffer(object):
+    def __init__(self, ctx, nbytes):
+        self._ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        check(ctx, _lib.load_library().tgp_dev_alloc(ctx, self.nbytes, C.byref(p)), "tgp_dev_alloc")
+        self.ptr = p
+
+    @classmethod
+    def from_array(cls, ctx, a):
+        a = np.ascontiguousarray(a)
+        buf = cls(ctx, a.nbytes)
+        check(ctx, _lib.load_library().tgp_h2d(ctx, buf.ptr, ptr(a), a.nbytes), "tgp_h2d")
+        return buf
+
+    def to_array(self, shape, dtype=np.float64):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(self._ctx, _lib.load_library().tgp_d2h(self._ctx, ptr(out), self.ptr, out.nbytes), "tgp_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            _lib.load_library().tgp_dev_free(self._ctx, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
