@@ -228,7 +228,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
             if (prof) TGP_HIP(hipEventRecord(ctx->prof_events[2 * nlaunch], st));
             syrk_trailing_kernel<<<(unsigned)tilemap_grid(r2), 256, 0, st>>>(d_A, Np, k, r2);
             if (prof) TGP_HIP(hipEventRecord(ctx->prof_events[2 * nlaunch + 1], st));
-            flops += 2.0 * 128.0 * 128.0 * 256.0 * ((double)r2 * (r2 + 1) / 2.0);
+            { const double m = (double)r2 * TGP_TB; flops += (double)TGP_PW * m * (m + 1.0); }   // algorithmic: lower triangle only
             ++nlaunch;
         }
     }
