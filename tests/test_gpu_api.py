@@ -1,0 +1,337 @@
+"""GPU tests through the treegp-compatible Python API.  They read like the reference's own tests
+(tests/test_kernels.py, test_gp_interp.py, test_hyp_search.py, test_meanify.py) plus exact
+comparisons with the golden vectors the reference produced (tests/golden/*.npz)."""
+import numpy as np
+import pytest
+from scipy import special
+
+import treegp_amd as treegp
+from treegp_amd.synthetic import correlation_length_matrix as get_correlation_length_matrix
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-10          # north-star tolerance on predicted values (relative to the field scale)
+
+
+def _close_rel(a, b, rel=REL):
+    np.testing.assert_allclose(a, b, rtol=0, atol=rel * max(np.abs(b).max(), 1e-300))
+
+
+# ---------------------------------------------------------------- golden vectors ---------------
+def test_golden_g1_config1(golden):
+    g = golden("g1_c1_rbf1d.npz")
+    gp = treegp.GPInterpolation(kernel=str(g["kernel"]), optimizer="none", normalize=True, white_noise=0.0)
+    gp.initialize(g["X"], g["y"], y_err=g["y_err"])
+    _close_rel(gp.predict(g["Xs"]), g["y_pred"])
+    _close_rel(gp._alpha, g["alpha"], 1e-9)
+    np.testing.assert_allclose(gp.return_log_likelihood(), g["logL"], rtol=1e-11)
+
+
+def test_golden_g2_aniso_cov(golden):
+    g = golden("g2_aniso2d.npz")
+    gp = treegp.GPInterpolation(kernel=str(g["kernel"]), optimizer="none", normalize=True, white_noise=0.01)
+    gp.initialize(g["X"], g["y"], y_err=g["y_err"])
+    np.testing.assert_allclose(gp._y_err, g["y_err_eff"], rtol=1e-15)
+    yp, cov = gp.predict(g["Xs"][:256], return_cov=True)
+    _close_rel(yp, g["y_pred"][:256])
+    np.testing.assert_allclose(cov, g["cov256"], rtol=0, atol=1e-9 * np.abs(g["cov256"]).max())
+    _close_rel(gp.predict(g["Xs"]), g["y_pred"])            # alpha cache path
+
+
+def test_golden_g3_vonkarman(golden):
+    g = golden("g3_vonkarman.npz")
+    for tag in ("vk", "avk"):
+        gp = treegp.GPInterpolation(kernel=str(g[tag + "_kernel"]), optimizer="none", normalize=True)
+        gp.initialize(g["X"], g["y"], y_err=g["y_err"])
+        _close_rel(gp.predict(g["Xs"]), g[tag + "_y_pred"])
+        yp, cov = gp.predict(g["Xs"][:200], return_cov=True)
+        np.testing.assert_allclose(cov, g[tag + "_cov200"], rtol=0, atol=1e-9 * np.abs(g[tag + "_cov200"]).max())
+        np.testing.assert_allclose(gp.return_log_likelihood(), g[tag + "_logL"], rtol=1e-11)
+
+
+def test_golden_g4_kernel_tables(golden):
+    g = golden("g4_kernels.npz")
+    for tag in ("rbf", "arbf", "vk", "avk", "vk_noamp"):
+        k = treegp.eval_kernel(str(g[tag + "_str"]))
+        if tag == "rbf":
+            from treegp_amd import ops
+            spec = treegp.kernel_to_spec(k)      # sklearn's own RBF.__call__ is host code; check the device path
+            Kself, Kx = ops.kernel_matrix(spec, g["X"]), ops.kernel_matrix(spec, g["Y"], g["X"])
+        else:
+            Kself, Kx = k(g["X"]), k(g["Y"], Y=g["X"])
+        np.testing.assert_allclose(Kself, g[tag + "_self"], rtol=2e-12, atol=1e-12, err_msg=tag)   # test_kernels.py atol
+        np.testing.assert_allclose(Kx, g[tag + "_cross"], rtol=2e-12, atol=1e-12, err_msg=tag)
+    for tag in ("vk1d", "arbf1d"):
+        k = treegp.eval_kernel(str(g[tag + "_str"]))
+        np.testing.assert_allclose(k(g["X1"]), g[tag + "_self"], rtol=2e-12, atol=1e-12)
+        np.testing.assert_allclose(k(g["X1"][:10] + 0.5, Y=g["X1"]), g[tag + "_cross"], rtol=2e-12, atol=1e-12)
+
+
+def test_golden_g5_loglike(golden):
+    g = golden("g5_loglike.npz")
+    gp = treegp.GPInterpolation(kernel=str(g["kernel"]), optimizer="none", normalize=True)
+    gp.initialize(g["X"], g["y"], y_err=g["y_err"])
+    for t, ll in zip(g["thetas"], g["logL"]):
+        np.testing.assert_allclose(gp.return_log_likelihood(theta=t), ll, rtol=1e-11)
+    gp2 = treegp.GPInterpolation(kernel="1.0**2 * AnisotropicRBF(scale_length=[50., 50.])", optimizer="none", normalize=False)
+    gp2.initialize(g["X"], g["y"], y_err=np.zeros(len(g["y"])))
+    assert gp2.return_log_likelihood() == -np.inf == float(g["logL_singular"])      # log_likelihood.py:38-39
+
+
+def test_golden_g6_meanify(golden, tmp_path):
+    from treegp_amd.fits_io import write_bintable_row
+    g = golden("g6_meanify.npz")
+    p = str(tmp_path / "mean.fits")
+    write_bintable_row(p, {"COORDS0": g["X0"], "PARAMS0": g["y0"]})
+    gp = treegp.GPInterpolation(kernel=str(g["kernel"]), optimizer="none", normalize=True, n_neighbors=4, average_fits=p)
+    gp.initialize(g["X"], g["y"], y_err=g["y_err"])
+    np.testing.assert_allclose(gp._spatial_average, g["spatial_average"], rtol=1e-13)
+    np.testing.assert_allclose(gp._mean, g["mean"], rtol=1e-12)
+    _close_rel(gp.predict(g["Xs"]), g["y_pred"])
+
+
+def test_golden_g8_reference_test_problems(golden):
+    g = golden("g8_reftests.npz")
+    x = g["x"]
+    for tag in ("rbf", "vk"):
+        kern = str(g[tag + "_kernel"])
+        gp = treegp.GPInterpolation(kernel=kern, optimizer="none", white_noise=0.0)
+        gp.initialize(x, g[tag + "_y"], y_err=0.1 * np.ones(len(x)))
+        yp, cov = gp.predict(x, return_cov=True)
+        _close_rel(yp, g[tag + "_y_pred"])
+        np.testing.assert_allclose(cov, g[tag + "_cov"], rtol=0, atol=1e-9 * np.abs(g[tag + "_cov"]).max())
+        gpb = treegp.GPInterpolation(kernel=kern, optimizer="none", normalize=False, white_noise=0.0)
+        gpb.initialize(x, g[tag + "_y"], y_err=0.1 * np.ones(len(x)))
+        ypb, covb = gpb.predict(g[tag + "_new_x"], return_cov=True)
+        np.testing.assert_allclose(ypb, g[tag + "_y_far"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(covb, g[tag + "_cov_far"], rtol=0, atol=1e-9 * np.abs(g[tag + "_cov_far"]).max())
+
+
+# ---------------------------------------------------------------- tests/test_kernels.py --------
+def test_anisotropic_kernels_closed_form():
+    corr_length = [1.0, 30.0, 30.0, 30.0, 30.0]
+    g1 = [0, 0.4, 0.4, -0.4, -0.4]
+    g2 = [0, 0.4, -0.4, 0.4, -0.4]
+    kernel_amp = [1e-4, 1e-3, 1e-2, 1.0, 1.0]
+    dist = np.linspace(0, 10, 100)
+    coord = np.array([dist, dist]).T
+    d21 = np.linspace(-10, 10, 21)
+    XX, YY = np.meshgrid(d21, d21)
+    x, y = XX.reshape(-1), YY.reshape(-1)
+    coord_corr = np.array([x, y]).T
+    lim0 = special.gamma(5.0 / 6.0) / (2 * (np.pi ** (5.0 / 6.0)))
+    for i in range(5):
+        inv_L = np.linalg.inv(get_correlation_length_matrix(corr_length[i], g1[i], g2[i]))
+        q = inv_L[0, 0] * x * x + 2 * inv_L[0, 1] * x * y + inv_L[1, 1] * y * y
+        ker = kernel_amp[i] ** 2 * treegp.AnisotropicRBF(invLam=inv_L)
+        np.testing.assert_allclose(ker(coord_corr, Y=np.zeros_like(coord_corr))[:, 0],
+                                   kernel_amp[i] ** 2 * np.exp(-0.5 * q), atol=1e-12)
+        dd = coord[:, None, :] - coord[None, :, :]
+        qq = np.einsum("ijk,kl,ijl->ij", dd, inv_L, dd)
+        Kt = kernel_amp[i] ** 2 * np.exp(-0.5 * qq)
+        np.testing.assert_allclose(ker(coord), Kt, atol=1e-12)
+        kvk = kernel_amp[i] ** 2 * treegp.AnisotropicVonKarman(invLam=inv_L)
+        z = np.ones_like(q)
+        nz = q != 0
+        z[nz] = q[nz] ** (5.0 / 12.0) * special.kv(5.0 / 6.0, 2 * np.pi * np.sqrt(q[nz])) / lim0
+        np.testing.assert_allclose(kvk(coord_corr, Y=np.zeros_like(coord_corr))[:, 0], kernel_amp[i] ** 2 * z, atol=1e-12)
+
+
+def test_vonkarman_kernel_closed_form():
+    dist = np.linspace(0.01, 10, 100)
+    coord_corr = np.array([dist, np.zeros_like(dist)]).T
+    div = 5.0 / 6.0
+    lim0 = (2 * (np.pi ** div)) / special.gamma(div)
+    for corr in [1.0, 10.0, 100.0, 1000.0]:
+        for amp in [1e-4, 1e-3, 1e-2, 1.0]:
+            kernel = "%.10f * VonKarman(length_scale=%f)" % ((amp ** 2, corr))
+            interp = treegp.GPInterpolation(kernel=kernel, normalize=False, white_noise=0.0)
+            ker = interp.kernel_template
+            got = ker(coord_corr, Y=np.zeros_like(coord_corr))[:, 0]
+            want = amp ** 2 * lim0 * ((dist / corr) ** (5.0 / 6.0)) * special.kv(-5.0 / 6.0, 2 * np.pi * dist / corr)
+            np.testing.assert_allclose(got, want, atol=1e-12)
+
+
+def test_anisotropic_limit():
+    np.random.seed(42)
+    gp1 = treegp.GPInterpolation(kernel="RBF(0.45)")
+    gp2 = treegp.GPInterpolation(kernel="AnisotropicRBF(scale_length=[0.45, 0.45])")
+    X = np.random.rand(1000, 2)
+    np.testing.assert_allclose(gp1.kernel_template(X), gp2.kernel_template(X))
+    from treegp_amd import ops
+    np.testing.assert_allclose(ops.kernel_matrix(treegp.kernel_to_spec(gp1.kernel_template), X), gp2.kernel_template(X), rtol=1e-12)
+    k3 = treegp.eval_kernel("VonKarman(0.45)")
+    k4 = treegp.eval_kernel("AnisotropicVonKarman(scale_length=[0.45, 0.45])")
+    np.testing.assert_allclose(k3(X), k4(X), rtol=1e-11, atol=1e-14)
+
+
+# ---------------------------------------------------------------- tests/test_gp_interp.py ------
+def _grf(kernel_skl, noise, npoints, ndim, seed=42):
+    """Gaussian random field drawn the way tests/treegp_test_helper.py:47-104 draws it (legacy
+    NumPy global stream, uniform coordinates in [-10, 10], optional white noise)."""
+    np.random.seed(seed)
+    if ndim == 1:
+        x = np.random.uniform(-10, 10, npoints).reshape((npoints, 1))
+    else:
+        x1 = np.random.uniform(-10, 10, npoints)
+        x2 = np.random.uniform(-10, 10, npoints)
+        x = np.array([x1, x2]).T
+    K = kernel_skl(x)
+    y = np.random.multivariate_normal(np.zeros(npoints), K)
+    if noise is not None:
+        y += np.random.normal(scale=noise, size=npoints)
+        return x, y, np.ones_like(y) * noise
+    return x, y, None
+
+
+def _check_interp(kernel, x, y, y_err, white_noise, sigma, new_x, noise):
+    npoints = len(y)
+    gp = treegp.GPInterpolation(kernel=kernel, optimizer="none", white_noise=white_noise)
+    gp.initialize(x, y, y_err=y_err)
+    y_predict, y_cov = gp.predict(x, return_cov=True)
+    y_std = np.sqrt(np.diag(y_cov))
+    pull = y - y_predict
+    if noise is not None:
+        pull /= np.sqrt(y_err ** 2 + y_std ** 2)
+    else:
+        np.testing.assert_allclose(y, y_predict, atol=3.0 * white_noise)
+        np.testing.assert_allclose(np.zeros_like(y_std), y_std, atol=3.0 * white_noise)
+    np.testing.assert_allclose(0.0, np.mean(pull), atol=3.0 * np.std(pull) / np.sqrt(npoints))
+    assert np.std(pull) <= 1.0
+    gp = treegp.GPInterpolation(kernel=kernel, optimizer="none", normalize=False, white_noise=white_noise)
+    gp.initialize(x, y, y_err=y_err)
+    y_predict, y_cov = gp.predict(new_x, return_cov=True)
+    y_std = np.sqrt(np.diag(y_cov))
+    np.testing.assert_allclose(np.zeros_like(y_predict), y_predict, atol=1e-5)
+    np.testing.assert_allclose(sigma * np.ones_like(y_std), y_std, atol=1e-5)
+
+
+def test_gp_interp_1d():
+    npoints = 40
+    noise = [None, 0.1]
+    white_noise = [1e-5, 0.0]
+    sigma = [1.0, 2.0]
+    l = [2.0, 2.0]
+    for ker in ["RBF", "VonKarman"]:
+        for i in range(2):
+            kernel = "%f**2 * %s(%f)" % ((sigma[i], ker, l[i]))
+            x, y, y_err = _grf(treegp.eval_kernel(kernel), noise[i], npoints, 1)
+            new_x = np.linspace(np.max(x) + 6.0 * l[i], np.max(x) + 7.0 * l[i], npoints).reshape((npoints, 1))
+            _check_interp(kernel, x, y, y_err, white_noise[i], sigma[i], new_x, noise[i])
+
+
+def test_gp_interp_2d():
+    npoints = 200
+    noise = [None, 0.1]
+    white_noise = [1e-5, 0.0]
+    size = [2.0, 4.0]
+    g1 = [0.0, 0.2]
+    g2 = [0.0, 0.2]
+    for ker in ["AnisotropicRBF", "AnisotropicVonKarman"]:
+        for i in range(2):
+            invL = np.linalg.inv(get_correlation_length_matrix(size[i], g1[i], g2[i]))
+            kernel = "%f**2*%s" % ((1.0, ker)) + "(invLam={0!r})".format(invL)
+            x, y, y_err = _grf(treegp.eval_kernel(kernel), noise[i], npoints, 2)
+            far = np.max(x) + 6.0 * size[i]
+            new_x = np.full((npoints, 2), far)
+            _check_interp(kernel, x, y, y_err, white_noise[i], 1.0, new_x, noise[i])
+
+
+# ---------------------------------------------------------------- tests/test_hyp_search.py -----
+def test_hyperparameter_search_loglikelihood():
+    for ker, sig, ell in (("RBF", 1.0, 0.5), ("RBF", 2.0, 0.8), ("VonKarman", 1.0, 8.0), ("VonKarman", 2.0, 10.0)):
+        kernel = "%f**2 * %s(%f)" % (sig, ker, ell)
+        kernel_skl = treegp.eval_kernel(kernel)
+        x, y, y_err = _grf(kernel_skl, 0.01, 100, 1)
+        gp = treegp.GPInterpolation(kernel=kernel, optimizer="log-likelihood", normalize=True)
+        gp.initialize(x, y, y_err=y_err)
+        gp.solve()
+        np.testing.assert_allclose(kernel_skl.theta, gp.kernel.theta, atol=7e-1)          # test_hyp_search.py:43
+        np.testing.assert_allclose(gp.return_log_likelihood(), gp._optimizer._logL, atol=1e-10)   # :49-50
+        assert gp._alpha is None
+    invL = np.linalg.inv(get_correlation_length_matrix(0.5, 0.2, 0.2))
+    kernel = "%f**2*%s" % (2.0, "AnisotropicRBF") + "(invLam={0!r})".format(invL)
+    kernel_skl = treegp.eval_kernel(kernel)
+    x, y, y_err = _grf(kernel_skl, 0.01, 600, 2)
+    gp = treegp.GPInterpolation(kernel=kernel, optimizer="log-likelihood", normalize=True)
+    gp.initialize(x, y, y_err=y_err)
+    gp.solve()
+    np.testing.assert_allclose(kernel_skl.theta, gp.kernel.theta, atol=5e-1)               # :141
+
+
+def test_hyperparameter_search_two_pcf_1d():
+    for ker, sig, ell, max_sep in (("RBF", 1.0, 0.5, 1.75), ("RBF", 2.0, 0.8, 1.75), ("VonKarman", 1.0, 8.0, 1.25),
+                                   ("VonKarman", 2.0, 10.0, 1.25)):
+        kernel = "%f**2 * %s(%f)" % (sig, ker, ell)
+        kernel_skl = treegp.eval_kernel(kernel)
+        x, y, y_err = _grf(kernel_skl, 0.01, 2000, 1)
+        gp = treegp.GPInterpolation(kernel=kernel, optimizer="two-pcf", normalize=True, nbins=15, min_sep=0.1, max_sep=max_sep)
+        gp.initialize(x, y, y_err=y_err)
+        gp.solve()
+        np.testing.assert_allclose(kernel_skl.theta, gp.kernel.theta, atol=7e-1)
+        xi, xi_weight, distance, coord, mask = gp.return_2pcf()
+        np.testing.assert_allclose(xi, gp._optimizer._2pcf, atol=1e-10)                     # :46-47
+
+
+def test_hyperparameter_search_anisotropic():
+    invL = np.linalg.inv(get_correlation_length_matrix(0.5, 0.2, 0.2))
+    kernel = "%f**2*%s" % (2.0, "AnisotropicRBF") + "(invLam={0!r})".format(invL)
+    kernel_skl = treegp.eval_kernel(kernel)
+    x, y, y_err = _grf(kernel_skl, 0.01, 2000, 2)
+    gp = treegp.GPInterpolation(kernel=kernel, optimizer="anisotropic", normalize=True, nbins=21, min_sep=0.0,
+                                max_sep=1.0, p0=[0.3, 0.0, 0.0])
+    gp.initialize(x, y, y_err=y_err)
+    gp.solve()
+    assert gp._optimizer._2pcf_weight.shape == (221, 221)
+    np.testing.assert_allclose(kernel_skl.theta, gp.kernel.theta, atol=5e-1)
+    y_predict, y_cov = gp.predict(x, return_cov=True)
+    pull = (y - y_predict) / np.sqrt(y_err ** 2 + np.diag(y_cov))
+    np.testing.assert_allclose(0.0, np.mean(pull), atol=3.0 * np.std(pull) / np.sqrt(2000))
+    assert np.std(pull) <= 1.0
+
+
+# ---------------------------------------------------------------- pair binning vs oracle -------
+def test_kk_twod_and_log_vs_oracle():
+    from oracle import gp_oracle as O
+    from treegp_amd import ops
+    rng = np.random.default_rng(3)
+    for n in (50, 257, 1500):
+        x, y = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+        k = rng.standard_normal(n)
+        for w in (None, rng.uniform(0.5, 2.0, n)):
+            for nb, mn, mx in ((7, 0.0, 0.4), (21, 0.05, 0.15), (20, 0.0, 0.3)):
+                xi, wt, npairs = ops.kk_twod(x, y, k, w, mn, mx, nb)
+                xo, wo, no = O.kk_twod(x, y, k, w, mn, mx, nb)
+                assert np.array_equal(npairs, no)                                    # exact pair counts
+                np.testing.assert_allclose(wt, wo, rtol=1e-12)
+                np.testing.assert_allclose(xi, xo, rtol=1e-10, atol=1e-12 * np.abs(xo).max())
+            xi, wt, mr, mlr, npairs = ops.kk_log(x, y, k, w, 0.01, 0.5, 15)
+            xo, wo, ro, lo, no = O.kk_log(x, y, k, w, 0.01, 0.5, 15)
+            assert np.array_equal(npairs, no)
+            np.testing.assert_allclose(wt, wo, rtol=1e-12)
+            np.testing.assert_allclose(xi, xo, rtol=1e-10, atol=1e-12 * np.abs(xo).max())
+            np.testing.assert_allclose(mr, ro, rtol=1e-12)
+            np.testing.assert_allclose(mlr, lo, rtol=1e-11)
+
+
+def test_kk_bootstrap_vs_oracle_loop():
+    from oracle import gp_oracle as O
+    from treegp_amd import ops
+    rng = np.random.default_rng(5)
+    n, nb, mx = 600, 9, 0.3
+    X = rng.uniform(0, 1, (n, 2)); yv = rng.standard_normal(n) + 1.0; yerr = rng.uniform(0.05, 0.1, n)
+    idx = O.bootstrap_indices(n, 5)
+    got = ops.kk_twod_bootstrap(X[:, 0], X[:, 1], yv, yerr, idx, 0.0, mx, nb)
+    got_unw = ops.kk_twod_bootstrap(X[:, 0], X[:, 1], yv, np.zeros(n), idx, 0.0, mx, nb)
+    for b in range(5):
+        ii = idx[b]
+        xo, _, _, _ = O.comp_2pcf(X[ii], yv[ii], yerr[ii], 0.0, mx, nb, True)
+        np.testing.assert_allclose(got[b], xo, rtol=1e-10, atol=1e-12 * np.abs(xo).max())
+        xo, _, _, _ = O.comp_2pcf(X[ii], yv[ii], np.zeros(n), 0.0, mx, nb, True)
+        np.testing.assert_allclose(got_unw[b], xo, rtol=1e-10, atol=1e-12 * np.abs(xo).max())
+    # the host class reproduces the reference's bootstrap stream and covariance recipe
+    t = treegp.two_pcf(X, yv, yerr, 0.0, mx, nbins=nb, anisotropic=True)
+    cov = t.comp_xi_covariance(n_bootstrap=5, mask=O.twod_mask(nb))
+    sel = got[:, O.twod_mask(nb)]
+    d = sel - sel.mean(axis=0)
+    np.testing.assert_allclose(cov, d.T @ d / 4.0, rtol=1e-9, atol=1e-14)

@@ -1,0 +1,164 @@
+"""CPU-only checks: C-ABI surface, host-side mirror of the reference interface (no compute)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import treegp_amd as tg
+from treegp_amd import _lib
+from treegp_amd.fits_io import read_bintable_row, write_bintable_row
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tgp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tgp_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = _lib.load_library()
+    for name in declared:
+        assert hasattr(lib, name), "libtgp.so does not export %s" % name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert b"gfx950" in lib.tgp_version()
+    # layout helpers are pure host functions
+    assert lib.tgp_padded_n(1) == 256 and lib.tgp_padded_n(256) == 256 and lib.tgp_padded_n(257) == 512
+    assert lib.tgp_panel_elems(512) == 512 * 256 + 256 * 256
+    assert lib.tgp_panel_off(1, 512) == 512 * 256
+
+
+def test_no_gpu_fails_loudly():
+    lib = _lib.load_library()
+    if lib.tgp_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _lib.get_ctx()
+    k = tg.eval_kernel("RBF(1)")
+    gp = tg.GPInterpolation(kernel="1.0**2 * AnisotropicRBF(scale_length=[2.0])", optimizer="none")
+    X = np.random.rand(8, 1)
+    gp.initialize(X, X[:, 0])
+    with pytest.raises(RuntimeError):
+        gp.predict(X)
+
+
+def test_kernel_strings_and_theta(golden):
+    g = golden("g4_kernels.npz")
+    for tag in ("rbf", "arbf", "vk", "avk", "vk_noamp"):
+        k = tg.eval_kernel(str(g[tag + "_str"]))
+        np.testing.assert_allclose(k.theta, g[tag + "_theta"], rtol=1e-14)
+        k2 = k.clone_with_theta(k.theta)
+        np.testing.assert_allclose(k2.theta, k.theta, rtol=1e-13)
+    k = tg.eval_kernel(str(g["arbf_str"]))
+    s = tg.kernel_to_spec(k)
+    iL = g["arbf_invLam"]
+    assert (s.kind, s.amp) == (_lib.TGP_ARBF, 0.25)
+    np.testing.assert_allclose([s.a, s.b, s.c], [iL[0, 0], iL[0, 1], iL[1, 1]], rtol=1e-15)
+    # theta <-> invLam round trip (tests/test_kernels.py:60-66)
+    theta = k.theta[1:]
+    L1 = np.zeros((2, 2)); L1[np.diag_indices(2)] = np.exp(theta[:2]); L1[np.tril_indices(2, -1)] = theta[2:]
+    np.testing.assert_allclose(L1 @ L1.T, iL, atol=1e-12)
+    s = tg.kernel_to_spec(tg.eval_kernel("2.0**2 * VonKarman(length_scale=3.0)"))
+    assert (s.kind, s.amp, s.ell) == (_lib.TGP_VK, 4.0, 3.0)
+    s = tg.kernel_to_spec(tg.eval_kernel("RBF(0.5)"))
+    assert s.kind == _lib.TGP_RBF and s.a == s.c == 4.0 and s.b == 0.0
+    s = tg.kernel_to_spec(tg.eval_kernel("1.0**2 * AnisotropicRBF(scale_length=[2.0])"))
+    assert (s.a, s.b, s.c) == (0.25, 0.0, 0.0)
+    # clone resets bounds to the default (-5, 5) because get_params only returns invLam
+    kb = tg.AnisotropicRBF(scale_length=[1.0, 2.0], bounds=(-3, 3))
+    assert np.all(kb.bounds == [-3, 3]) and np.all(kb.clone_with_theta(kb.theta).bounds == [-5, 5])
+
+
+def test_error_behaviour():
+    with pytest.raises(TypeError):
+        tg.GPInterpolation(kernel=tg.eval_kernel("RBF(1)"))                    # gp_interp.py:87-89
+    with pytest.raises(ValueError):
+        tg.GPInterpolation(kernel="RBF(1)", optimizer="nope")                  # gp_interp.py:91-95
+    with pytest.raises(RuntimeError):
+        tg.eval_kernel("NotAKernel(1)")                                        # kernels.py:51-55
+    with pytest.raises(TypeError):
+        tg.AnisotropicRBF(invLam=np.eye(2), scale_length=[1, 1])               # kernels.py:97-100
+    with pytest.raises(NotImplementedError):
+        tg.kernel_to_spec(tg.eval_kernel("RBF(1) + WhiteKernel(1)"))
+    with pytest.raises(ValueError):
+        tg.two_pcf(np.zeros((4, 3)), np.zeros(4), np.zeros(4), 0.1, 1.0)       # two_pcf.py:243-247
+    from treegp_amd.two_pcf import get_kernel_class, get_correlation_length_matrix
+    with pytest.raises(ValueError):
+        get_kernel_class(tg.eval_kernel("RBF(1)"))
+    assert get_kernel_class(tg.eval_kernel("2.0 * AnisotropicVonKarman(scale_length=[1., 1.])")) is tg.AnisotropicVonKarman
+    with pytest.raises(ValueError):
+        get_correlation_length_matrix(1.0, 1.5, 0.0)
+
+
+def test_initialize_semantics():
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0, 1, (50, 2)); y = rng.standard_normal(50) + 3.0; e = 0.1 * np.ones(50)
+    gp = tg.GPInterpolation(kernel="1.0**2 * AnisotropicRBF(scale_length=[0.2, 0.2])", optimizer="none", white_noise=0.05)
+    gp.initialize(X, y, y_err=e)
+    np.testing.assert_allclose(gp._y_err, np.sqrt(e ** 2 + 0.05 ** 2))          # gp_interp.py:217-219
+    assert gp._mean == np.mean(y) and gp._alpha is None
+    assert np.all(gp._spatial_average == 0) and np.all(gp._X0 == 0)             # gp_interp.py:212-215
+    gp2 = tg.GPInterpolation(kernel="RBF(1)", optimizer="none", normalize=False)
+    gp2.initialize(X, y)
+    assert gp2._mean == 0.0 and np.all(gp2._y_err == 0)
+    assert gp.kernel is not gp.kernel_template
+
+
+def test_two_pcf_geometry_and_bootstrap_stream(golden):
+    g = golden("g7_host_scalars.npz")
+    X = np.random.default_rng(1).uniform(0, 1, (10, 2))
+    for nb in (15, 20, 21):
+        t = tg.two_pcf(X, np.zeros(10), np.zeros(10), 0.0, 0.3, nbins=nb, anisotropic=True)
+        mask, dist = t._twod_geometry()
+        assert np.array_equal(mask, g["mask_%d" % nb])
+        bs = 0.6 / nb
+        np.testing.assert_allclose(dist[:nb, 0], -0.3 + bs * (np.arange(nb) + 0.5), rtol=1e-13, atol=1e-15)   # dx varies fastest
+        np.testing.assert_allclose(dist[::nb, 1], -0.3 + bs * (np.arange(nb) + 0.5), rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(dist, -dist[::-1], atol=1e-15)
+    t = tg.two_pcf(X, np.arange(10.0), np.ones(10), 0.0, 0.3)
+    rows = np.stack([t._bootstrap_index() for _ in range(4)])
+    assert np.array_equal(rows, g["boot_n10"])
+    t = tg.two_pcf(X, np.arange(10.0), np.ones(10), 0.0, 0.3)
+    u, v, yy, ee = t.resample_bootstrap()
+    assert np.array_equal(yy, np.arange(10.0)[g["boot_n10"][0]])
+    # 1-D inputs get a zero second coordinate (two_pcf.py:250-251)
+    t1 = tg.two_pcf(X[:, :1], np.zeros(10), np.zeros(10), 0.1, 1.0)
+    assert t1.X.shape == (10, 2) and np.all(t1.X[:, 1] == 0)
+
+
+def test_fits_reader_roundtrip(tmp_path, golden):
+    g = golden("g6_meanify.npz")
+    p = str(tmp_path / "mean.fits")
+    write_bintable_row(p, {"COORDS0": g["X0"], "PARAMS0": g["y0"]})
+    d = read_bintable_row(p)
+    assert np.array_equal(d["COORDS0"], g["X0"]) and np.array_equal(d["PARAMS0"], g["y0"])
+    assert os.path.getsize(p) % 2880 == 0
+    gp = tg.GPInterpolation(kernel="RBF(1)", optimizer="none", average_fits=p)
+    assert gp._X0.shape == (2500, 2) and gp._y0.shape == (2500,)
+
+
+def test_device_bessel_function_on_host():
+    """bessel_k56.h compiled with g++ against scipy.special.kv (the reference's dependency)."""
+    import ctypes
+    import subprocess
+    import tempfile
+    from scipy import special
+    d = tempfile.mkdtemp()
+    src = os.path.join(d, "t.cpp")
+    open(src, "w").write('#include "%s"\nextern "C" void vk(const double* u, double* o, long n)'
+                         '{ for (long i = 0; i < n; ++i) o[i] = vonkarman_unit(u[i]); }\n'
+                         % os.path.join(ROOT, "treegp_amd", "csrc", "bessel_k56.h"))
+    so = os.path.join(d, "libvk.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", so, src])
+    lib = ctypes.CDLL(so)
+    rng = np.random.default_rng(0)
+    u = np.concatenate([[0.0], 10 ** rng.uniform(-9, 2.05, 20000), [1 / (2 * np.pi), 32 / (2 * np.pi), 111.0, 111.08, 200.0]])
+    out = np.empty_like(u)
+    lib.vk(u.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(len(u)))
+    lim0 = special.gamma(5 / 6) / (2 * np.pi ** (5 / 6))
+    ref = np.ones_like(u)
+    nz = u != 0
+    ref[nz] = u[nz] ** (5 / 6) * special.kv(5 / 6, 2 * np.pi * u[nz]) / lim0
+    assert out[0] == 1.0
+    np.testing.assert_allclose(out, ref, rtol=2e-13, atol=1e-13)      # kernel tables are pinned at atol 1e-12
+    assert np.all(out[2 * np.pi * u > 697.874] == 0.0) and np.all(ref[2 * np.pi * u > 697.874] == 0.0)

@@ -74,8 +74,6 @@ def load_library():
                                "or `make -C treegp_amd/csrc`" % LIB_PATH)
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            if not hasattr(lib, name) and name in ("tgp_gp_predict_cov", "tgp_kk_twod", "tgp_kk_log", "tgp_kk_twod_bootstrap"):
-                continue      # TEMP while kk.hip / cov.hip are being written
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args

@@ -1,0 +1,216 @@
+"""Covariance functions with treegp's interface, evaluated on the GPU.
+
+Mirrors ``treegp/kernels.py`` of the reference: ``eval_kernel`` (:17-59), ``AnisotropicRBF``
+(:62-186), ``VonKarman`` (:189-301), ``AnisotropicVonKarman`` (:304-420).  The classes stay
+scikit-learn ``Kernel`` objects (theta, bounds, clone_with_theta, ``amp * kernel`` products all
+work as in the reference) but ``__call__`` goes to ``tgp_kernel_matrix`` (include/tgp.h, seam
+S1) instead of scipy ``pdist/cdist`` + ``special.kv``.  There is no host evaluation path.
+
+``kernel_to_spec`` turns a kernel object tree into the plain numbers the device kernels take.
+"""
+import numpy as np
+from sklearn.gaussian_process.kernels import (ConstantKernel, Hyperparameter, Kernel, NormalizedKernelMixin,
+                                              Product, RBF, StationaryKernelMixin)
+
+from . import _lib
+from . import ops
+
+
+def _all_kernel_classes(cls=Kernel):
+    found = []
+    for sub in cls.__subclasses__():
+        found.append(sub)
+        found.extend(_all_kernel_classes(sub))
+    return found
+
+
+def eval_kernel(kernel):
+    """Build a kernel object from its repr-like string, e.g. ``"0.5**2 * AnisotropicRBF(invLam=array(...))"``.
+
+    Same contract as the reference (kernels.py:17-59): every scikit-learn ``Kernel`` subclass
+    (which includes the classes of this module) and ``array`` are visible to the expression;
+    a failing expression raises RuntimeError, an un-instantiated class raises TypeError.
+    """
+    scope = {c.__name__: c for c in _all_kernel_classes()}
+    scope["array"] = np.array
+    try:
+        k = eval(kernel, scope)
+    except Exception as e:
+        raise RuntimeError("Failed to evaluate kernel string {0!r}.  Original exception: {1}".format(kernel, e))
+    if isinstance(k.theta, property):
+        raise TypeError("String provided was not initialized properly")
+    return k
+
+
+class _CholeskyParametrised(StationaryKernelMixin, NormalizedKernelMixin, Kernel):
+    """Shared parametrisation of the two invLam kernels (kernels.py:95-112,154-186 and
+    :336-353,388-420): invLam = L L^T, theta = [log diag(L), strictly-lower L row-wise]."""
+
+    _tgp_kind = None
+
+    def __init__(self, invLam=None, scale_length=None, bounds=(-5, 5)):
+        if scale_length is not None:
+            if invLam is not None:
+                raise TypeError("Cannot set both invLam and scale_length in %s." % type(self).__name__)
+            invLam = np.diag(1.0 / np.array(scale_length) ** 2)
+        self.ndim = invLam.shape[0]
+        self.ntheta = self.ndim * (self.ndim + 1) // 2
+        self._d = np.diag_indices(self.ndim)
+        self._t = np.tril_indices(self.ndim, -1)
+        self.set_params(invLam)
+        bounds = np.array(bounds)
+        if bounds.ndim == 1:
+            bounds = np.repeat(bounds[None, :], self.ntheta, axis=0)
+        assert bounds.shape == (self.ntheta, 2)
+        self._bounds = bounds
+
+    # -- scikit-learn plumbing -------------------------------------------------------------
+    @property
+    def hyperparameter_cholesky_factor(self):
+        return Hyperparameter("CholeskyFactor", "numeric", (1e-5, 1e5), int(self.ntheta))
+
+    def get_params(self, deep=True):
+        # only invLam: a clone therefore comes back with the default bounds (reference quirk)
+        return {"invLam": self.invLam}
+
+    def set_params(self, invLam=None):
+        if invLam is not None:
+            self.invLam = invLam
+            self._L = np.linalg.cholesky(self.invLam)
+            self._theta = np.hstack([np.log(self._L[self._d]), self._L[self._t]])
+
+    @property
+    def theta(self):
+        return self._theta
+
+    @theta.setter
+    def theta(self, theta):
+        self._theta = theta
+        self._L = np.zeros_like(self.invLam)
+        self._L[np.diag_indices(self.ndim)] = np.exp(theta[:self.ndim])
+        self._L[np.tril_indices(self.ndim, -1)] = theta[self.ndim:]
+        self.invLam = np.dot(self._L, self._L.T)
+
+    @property
+    def bounds(self):
+        return self._bounds
+
+    def __repr__(self):
+        return "{0}(invLam={1!r})".format(self.__class__.__name__, self.invLam)
+
+    # -- evaluation ------------------------------------------------------------------------
+    def _spec(self):
+        return _invlam_spec(self._tgp_kind, self.invLam, 1.0)
+
+    def __call__(self, X, Y=None, eval_gradient=False):
+        X = np.atleast_2d(X)
+        if eval_gradient:
+            if Y is not None:
+                raise ValueError("Gradient can only be evaluated when Y is None.")
+            raise NotImplementedError("kernel gradients are outside the GPU hot path "
+                                      "(no treegp optimiser requests them: log_likelihood.py:57 passes no jac)")
+        if X.shape[1] != self.ndim:
+            raise ValueError("X has %d columns, kernel has ndim=%d" % (X.shape[1], self.ndim))
+        return ops.kernel_matrix(self._spec(), X, None if Y is None else np.atleast_2d(Y))
+
+
+class AnisotropicRBF(_CholeskyParametrised):
+    """exp(-0.5 (x-x')^T invLam (x-x'))  -- treegp/kernels.py:62-186.
+
+    :param invLam:        inverse covariance matrix (ndim x ndim, ndim in {1, 2} on the GPU).
+    :param scale_length:  axis-aligned scale lengths instead of invLam (exactly one of the two).
+    :param bounds:        bounds on theta, (2,) or (ntheta, 2).
+    """
+    _tgp_kind = _lib.TGP_ARBF
+
+
+class AnisotropicVonKarman(_CholeskyParametrised):
+    """d^(5/6) K_{5/6}(2 pi d) / lim0 with the Mahalanobis distance d -- treegp/kernels.py:304-420."""
+    _tgp_kind = _lib.TGP_AVK
+
+
+class VonKarman(StationaryKernelMixin, NormalizedKernelMixin, Kernel):
+    """(d/l)^(5/6) K_{5/6}(2 pi d/l) / lim0, Euclidean d -- treegp/kernels.py:189-301.
+
+    :param length_scale:         scalar length scale (theta = log length_scale).
+    :param length_scale_bounds:  bounds on length_scale.
+    """
+
+    def __init__(self, length_scale=1.0, length_scale_bounds=(1e-5, 1e5)):
+        self.length_scale = length_scale
+        self.length_scale_bounds = length_scale_bounds
+
+    @property
+    def anisotropic(self):
+        return np.iterable(self.length_scale) and len(self.length_scale) > 1
+
+    @property
+    def hyperparameter_length_scale(self):
+        if self.anisotropic:
+            return Hyperparameter("length_scale", "numeric", self.length_scale_bounds, len(self.length_scale))
+        return Hyperparameter("length_scale", "numeric", self.length_scale_bounds)
+
+    def _spec(self):
+        if self.anisotropic:
+            raise NotImplementedError("per-axis length scales are not defined for VonKarman distances")
+        return ops.KernelSpec(_lib.TGP_VK, amp=1.0, ell=float(np.ravel(self.length_scale)[0]))
+
+    def __call__(self, X, Y=None, eval_gradient=False):
+        X = np.atleast_2d(X)
+        if eval_gradient:
+            if Y is not None:
+                raise ValueError("Gradient can only be evaluated when Y is None.")
+            raise NotImplementedError("kernel gradients are outside the GPU hot path")
+        return ops.kernel_matrix(self._spec(), X, None if Y is None else np.atleast_2d(Y))
+
+    def __repr__(self):
+        if self.anisotropic:
+            return "{0}(length_scale=[{1}])".format(self.__class__.__name__,
+                                                    ", ".join(map("{0:.3g}".format, self.length_scale)))
+        return "{0}(length_scale={1:.3g})".format(self.__class__.__name__, np.ravel(self.length_scale)[0])
+
+
+# ---- kernel object -> device description ---------------------------------------------------
+def _invlam_spec(kind, invLam, amp):
+    invLam = np.asarray(invLam, dtype=np.float64)
+    nd = invLam.shape[0]
+    if nd == 1:
+        return ops.KernelSpec(kind, amp=amp, a=invLam[0, 0], b=0.0, c=0.0)
+    if nd == 2:
+        return ops.KernelSpec(kind, amp=amp, a=invLam[0, 0], b=0.5 * (invLam[0, 1] + invLam[1, 0]), c=invLam[1, 1])
+    raise NotImplementedError("the GPU kernels cover 1-D and 2-D coordinates (treegp's own scope), got ndim=%d" % nd)
+
+
+def kernel_to_spec(kernel):
+    """{kind, amp, a, b, c, ell} for the supported kernel trees:
+    [ConstantKernel *]* one of RBF / AnisotropicRBF / VonKarman / AnisotropicVonKarman
+    (what every reference test and doc string builds, e.g. tests/test_gp_interp.py:31,123).
+    Anything else raises NotImplementedError -- there is no silent host fallback."""
+    amp = 1.0
+    node = kernel
+    while isinstance(node, Product):
+        if isinstance(node.k1, ConstantKernel):
+            amp *= float(node.k1.constant_value)
+            node = node.k2
+        elif isinstance(node.k2, ConstantKernel):
+            amp *= float(node.k2.constant_value)
+            node = node.k1
+        else:
+            raise NotImplementedError("only ConstantKernel * <stationary kernel> products run on the GPU, got %r" % (kernel,))
+    if isinstance(node, AnisotropicRBF):
+        return _invlam_spec(_lib.TGP_ARBF, node.invLam, amp)
+    if isinstance(node, AnisotropicVonKarman):
+        return _invlam_spec(_lib.TGP_AVK, node.invLam, amp)
+    if isinstance(node, VonKarman):
+        s = node._spec()
+        s.amp = amp
+        return s
+    if isinstance(node, RBF):
+        ls = np.ravel(np.asarray(node.length_scale, dtype=np.float64))
+        if ls.size == 1:
+            inv = 1.0 / ls[0] ** 2
+            return ops.KernelSpec(_lib.TGP_RBF, amp=amp, a=inv, b=0.0, c=inv)
+        if ls.size == 2:
+            return ops.KernelSpec(_lib.TGP_RBF, amp=amp, a=1.0 / ls[0] ** 2, b=0.0, c=1.0 / ls[1] ** 2)
+        raise NotImplementedError("RBF with %d length scales" % ls.size)
+    raise NotImplementedError("kernel %r is not supported by the GPU hot path" % (kernel,))

@@ -1,0 +1,306 @@
+"""Hyper-parameter estimation from the binned 2-point correlation function.
+
+Mirrors ``treegp/two_pcf.py`` of the reference: ``get_correlation_length_matrix`` (:12-31),
+``robust_2dfit`` (:68-206) and ``two_pcf`` (:209-464).  The pair binning that the reference
+delegates to TreeCorr (``kk.process``, :297-305 and :330-334) and the bootstrap loop around
+it (:342-362) run on the GPU through ``tgp_kk_twod`` / ``tgp_kk_log`` /
+``tgp_kk_twod_bootstrap`` (include/tgp.h, seam S4) with exact binning; all resamples of the
+bootstrap are one batched launch.  The chi^2 minimisers evaluate the model at <= nbins^2
+points per step and stay host-side drivers, as in the reference.
+"""
+from __future__ import print_function
+
+import copy
+import warnings
+
+import numpy as np
+import sklearn
+from scipy import optimize
+
+from . import kernels as _kernels
+from . import ops
+from .synthetic import correlation_length_matrix as get_correlation_length_matrix  # same formula as two_pcf.py:12-31
+
+try:                                   # the reference requires iminuit (two_pcf.py:6); it is
+    import iminuit                     # optional here because this image does not ship it
+except ImportError:                    # pragma: no cover
+    iminuit = None
+
+
+def get_kernel_class(A):
+    """AnisotropicRBF / AnisotropicVonKarman class of a kernel or of a Product holding one
+    (two_pcf.py:34-65); anything else is a ValueError."""
+    ok_classes = (_kernels.AnisotropicVonKarman, _kernels.AnisotropicRBF)
+    msg = "Work only with treegp.kernels.AnisotropicVonKarman and treegp.kernels.AnisotropicRBF"
+    if A.__class__ in ok_classes:
+        return A.__class__
+    if A.__class__ is sklearn.gaussian_process.kernels.Product:
+        found = None
+        for key in A.__dict__:
+            if A.__dict__[key].__class__ in ok_classes:
+                found = A.__dict__[key].__class__
+        if found is None:
+            raise ValueError(msg)
+        return found
+    raise ValueError(msg)
+
+
+class robust_2dfit(object):
+    """Fit (size, g1, g2) of an anisotropic kernel to the 2-D correlation function; amplitude and
+    additive constant are linear and solved in closed form inside chi2 (two_pcf.py:68-206).
+
+    :param kernel: kernel whose class fixes the radial profile  :param flat_data: flattened xi
+    :param x, y: pixel coordinates  :param W: inverse covariance of xi  :param mask: pixels to use
+    """
+
+    def __init__(self, kernel, flat_data, x, y, W, mask=None):
+        self.kernel_class = get_kernel_class(kernel)
+        self.mask = np.ones(len(x), dtype=bool) if mask is None else mask
+        self.flat_data, self.x, self.y, self.W = flat_data, x, y, W
+        self.coord = np.column_stack([x, y])
+        self.N = int(np.sqrt(len(x)))
+
+    def _model_skl(self, sigma, corr_length, g1, g2):
+        """sigma^2 * kernel_class(invLam(corr_length, g1, g2)) sampled at the pixel centres; None
+        outside |g| <= 1 (two_pcf.py:96-113)."""
+        if max(abs(g1), abs(g2)) > 1:
+            return None
+        invLam = np.linalg.inv(get_correlation_length_matrix(corr_length, g1, g2))
+        self.kernel_fit = sigma ** 2 * self.kernel_class(invLam=invLam)
+        return self.kernel_fit(self.coord, Y=np.zeros_like(self.coord))[:, 0]
+
+    def chi2(self, param):
+        """chi^2 over the non-linear parameters; the best amplitude (made positive) and constant
+        for them are kept in self.alpha (two_pcf.py:115-148)."""
+        bad = not np.isfinite(np.sum(param))
+        model = None if bad else self._model_skl(1.0, param[0], param[1], param[2])
+        if model is None:
+            self.chi2_value = [np.inf]
+            return np.inf
+        m = model[self.mask]
+        data = self.flat_data[self.mask]
+        F = np.column_stack([m, np.ones_like(m)])
+        FtW = F.T.dot(self.W)
+        self.alpha = np.linalg.inv(FtW.dot(F)).dot(FtW.dot(data.reshape(-1, 1)))
+        self.alpha[0] = abs(self.alpha[0])
+        self.residuals = data - (self.alpha[0] * m + self.alpha[1])
+        self.chi2_value = self.residuals.dot(self.W).dot(self.residuals.reshape(-1, 1))
+        return self.chi2_value[0]
+
+    def _minimize_minuit(self, p0=[3000.0, 0.2, 0.2]):
+        """One minimisation from p0: MIGRAD when iminuit is installed (what the reference uses,
+        two_pcf.py:150-176), otherwise Nelder-Mead polished by BFGS on the same 3-parameter chi2."""
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if iminuit is None:
+                nm = optimize.minimize(self.chi2, np.asarray(p0, float), method="Nelder-Mead",
+                                       options=dict(xatol=1e-6, fatol=1e-8, maxiter=2000))
+                pol = optimize.minimize(self.chi2, nm.x, method="BFGS")
+                best = pol if (np.isfinite(pol.fun) and pol.fun <= nm.fun) else nm
+                results = list(best.x)
+                self._fit_ok = bool(nm.success and np.isfinite(best.fun))
+            elif int(iminuit.__version__[0]) >= 2:
+                self.m = iminuit.Minuit(self.chi2, p0)
+                self.m.migrad()
+                results = [self.m.params[key].value for key in self.m.parameters]
+                self._fit_ok = self.m.accurate
+            else:
+                self.m = iminuit.Minuit.from_array_func(self.chi2, p0, print_level=0)
+                self.m.migrad()
+                results = [self.m.values[key] for key in self.m.values.keys()]
+                self._fit_ok = self.m.migrad_ok()
+            self.chi2(results)              # leaves self.alpha at the solution
+        self._minuit_result = results
+        self.result = [np.sqrt(self.alpha[0][0])] + list(results[:3]) + [self.alpha[1][0]]
+
+    def minimize_minuit(self, p0=[3000.0, 0.2, 0.2]):
+        """Minimise from p0; on failure retry from a 3x3x3 grid of start points until one
+        converges (two_pcf.py:178-206)."""
+        self._minimize_minuit(p0=p0)
+        if not self._fit_ok:
+            shear = np.linspace(-0.3, 0.3, 3)
+            sizes = np.linspace(p0[0] - p0[0] / 10.0, 2 * p0[0], 3)
+            G1, G2, S = (a.reshape(-1) for a in np.meshgrid(shear, shear, sizes))
+            for start in zip(S, G1, G2):
+                print("restart fit because failure")
+                print(list(start))
+                self._minimize_minuit(p0=list(start))
+                if self._fit_ok:
+                    break
+        self._model_skl(*self.result[:4])
+
+
+class two_pcf(object):
+    """Measured 2-point correlation function, its bootstrap covariance and the kernel fit.
+
+    :param X: coordinates (n, 1 or 2)   :param y: values   :param y_err: errors
+    :param min_sep, max_sep, nbins: binning  :param anisotropic: 2-D (TwoD pixels) correlation
+    :param robust_fit: fit (size, g1, g2) with ``robust_2dfit``  :param seed: bootstrap seed
+    """
+
+    def __init__(self, X, y, y_err, min_sep, max_sep, nbins=20, anisotropic=False, robust_fit=False,
+                 p0=[3000.0, 0.0, 0.0], seed=610639139):
+        self.ndim = np.shape(X)[1]
+        if self.ndim not in [1, 2]:
+            raise ValueError("two-pcf support only 1d and 2d modeling for the moment. curent ndim: %i" % (self.ndim))
+        if self.ndim == 2:
+            self.X = X
+        if self.ndim == 1:
+            self.X = np.array([X.T, np.zeros_like(X.T)]).T[:, 0]
+        self.y = y
+        self.y_err = y_err
+        self.min_sep = min_sep
+        self.max_sep = max_sep
+        self.nbins = nbins
+        self.anisotropic = anisotropic
+        self.robust_fit = robust_fit
+        self.p0_robust_fit = p0
+        self.seed = seed
+        self._rng = None
+
+    @property
+    def rng(self):
+        if self._rng is None:
+            self._rng = np.random.default_rng(self.seed)
+        return self._rng
+
+    def _bootstrap_index(self):
+        # two_pcf.py:273-275: `integers(0, n-1)` has an exclusive upper end, so the last point is
+        # never drawn -- kept, since it fixes the random stream and therefore the covariance
+        npsfs = len(self.y)
+        return self.rng.integers(0, npsfs - 1, size=npsfs)
+
+    def resample_bootstrap(self):
+        """One bootstrap resample u, v, y, y_err (two_pcf.py:269-281)."""
+        ind = self._bootstrap_index()
+        return self.X[:, 0][ind], self.X[:, 1][ind], self.y[ind], self.y_err[ind]
+
+    def _twod_geometry(self):
+        """mask (two_pcf.py:311-321) and pixel centres (:323-326) of the TwoD grid."""
+        nb = self.nbins
+        npixels = nb ** 2
+        mask = np.ones((nb, nb), dtype=bool)
+        nmask = int((nb / 2) + nb % 2)
+        mask[nmask:, :] = False
+        mask[nmask - 1][nmask:] = (nb % 2 == 0)
+        bs = 2.0 * self.max_sep / nb
+        bottom = np.linspace(-self.max_sep, self.max_sep, nb, endpoint=False)
+        centre = (bottom + (bottom + bs)) / 2.0
+        dy = np.repeat(centre, nb).reshape(nb, nb)       # varies along axis 0
+        dx = dy.T
+        distance = np.array([dx.reshape(npixels), dy.reshape(npixels)]).T
+        return mask.reshape(npixels), distance
+
+    def comp_2pcf(self, X, y, y_err):
+        """xi, distance, Coord, mask for one catalogue (two_pcf.py:283-340)."""
+        w = None if np.sum(y_err) == 0 else 1.0 / y_err ** 2
+        k = y - np.mean(y)
+        if self.anisotropic:
+            xi, _, _ = ops.kk_twod(X[:, 0], X[:, 1], k, w, self.min_sep, self.max_sep, self.nbins)
+            mask, distance = self._twod_geometry()
+            Coord = distance
+        else:
+            xi, _, meanr, _, _ = ops.kk_log(X[:, 0], X[:, 1], k, w, self.min_sep, self.max_sep, self.nbins)
+            distance = meanr
+            mask = np.ones_like(xi, dtype=bool)
+            Coord = np.array([distance, np.zeros_like(distance)]).T
+        return xi, distance, Coord, mask
+
+    def comp_xi_covariance(self, n_bootstrap=1000, mask=None, seed=610639139):
+        """Bootstrap covariance of xi (two_pcf.py:342-362); the n_bootstrap pair-binning passes
+        are one batched GPU launch over an (n_bootstrap, n) index matrix."""
+        self.seed = seed
+        self._rng = None
+        if not self.anisotropic:
+            xi_bootstrap = []
+            for _ in range(n_bootstrap):
+                u, v, y, y_err = self.resample_bootstrap()
+                xi, _, _, _ = self.comp_2pcf(np.array([u, v]).T, y, y_err)
+                if mask is None:
+                    mask = np.array([True] * len(xi))
+                xi_bootstrap.append(xi[mask])
+            xi_bootstrap = np.array(xi_bootstrap)
+        else:
+            idx = np.stack([self._bootstrap_index() for _ in range(n_bootstrap)])
+            xi_all = ops.kk_twod_bootstrap(self.X[:, 0], self.X[:, 1], self.y, self.y_err, idx, self.min_sep,
+                                           self.max_sep, self.nbins)
+            if mask is None:
+                mask = np.array([True] * xi_all.shape[1])
+            xi_bootstrap = xi_all[:, mask]
+        dxi = xi_bootstrap - np.mean(xi_bootstrap, axis=0)
+        return 1.0 / (len(dxi) - 1.0) * np.dot(dxi.T, dxi)
+
+    def return_2pcf(self, seed=610639139):
+        """xi, xi_weight, distance, coord, mask (two_pcf.py:364-391)."""
+        xi, distance, coord, mask = self.comp_2pcf(self.X, self.y, self.y_err)
+        if self.anisotropic:
+            # de-biasing of the inverse bootstrap covariance (Taylor et al. 2012, eq. 35)
+            def f_bias(x, npixel=len(xi[mask])):
+                return ((x - 1.0) / (x - npixel - 2.0)) - 2.0
+
+            results = optimize.fsolve(f_bias, len(xi[mask]) + 10)
+            nboot = int(results[0])
+            xi_cov = self.comp_xi_covariance(n_bootstrap=nboot, mask=mask, seed=seed)
+            bias_factor = (nboot - 1.0) / (nboot - len(xi[mask]) - 2.0)
+            xi_weight = np.linalg.inv(xi_cov) * bias_factor
+        else:
+            xi_weight = np.eye(len(xi)) * 1.0 / np.var(self.y)
+        return xi, xi_weight, distance, coord, mask
+
+    def optimizer(self, kernel):
+        """chi^2 fit of the kernel's hyper-parameters to the measured xi (two_pcf.py:393-464)."""
+        size_x = np.max(self.X[:, 0]) - np.min(self.X[:, 0])
+        if self.ndim == 2:
+            size_y = np.max(self.X[:, 1]) - np.min(self.X[:, 1])
+            rho = float(len(self.X[:, 0])) / (size_x * size_y)
+        if self.ndim == 1:
+            size_y = 0.0
+            rho = float(len(self.X[:, 0])) / size_x
+        if self.min_sep is not None:
+            min_sep = self.min_sep
+        elif self.anisotropic:
+            min_sep = 0.0
+        else:
+            min_sep = np.sqrt(1.0 / rho)          # mean separation between data points
+        if self.max_sep is not None:
+            max_sep = self.max_sep
+        else:
+            max_sep = np.sqrt(size_x ** 2 + size_y ** 2) / 2.0
+        self.min_sep = min_sep
+        self.max_sep = max_sep
+
+        xi, xi_weight, distance, coord, mask = self.return_2pcf()
+
+        def PCF(param, k=kernel):
+            kern = k.clone_with_theta(param)
+            return kern.__call__(coord, Y=np.zeros_like(coord))[:, 0]
+
+        xi_mask = xi[mask]
+
+        def chi2(param):
+            residual = xi_mask - PCF(param)[mask]
+            return residual.dot(xi_weight.dot(residual))
+
+        if self.robust_fit:
+            robust = robust_2dfit(kernel, xi, coord[:, 0], coord[:, 1], xi_weight, mask=mask)
+            robust.minimize_minuit(p0=self.p0_robust_fit)
+            kernel = copy.deepcopy(robust.kernel_fit)
+            cst = robust.result[-1]
+            self._results_robust = robust.result
+        else:
+            p0 = kernel.theta
+            results_fmin = optimize.fmin(chi2, p0, disp=False)
+            results_bfgs = optimize.minimize(chi2, p0, method="L-BFGS-B")
+            results = [results_fmin, results_bfgs["x"]]
+            chi2_min = [chi2(results[0]), chi2(results[1])]
+            results = results[chi2_min.index(min(chi2_min))]
+            kernel = kernel.clone_with_theta(results)
+            cst = 0
+
+        self._2pcf = xi
+        self._2pcf_weight = xi_weight
+        self._2pcf_dist = distance
+        self._2pcf_fit = PCF(kernel.theta) + cst
+        self._2pcf_mask = mask
+        self._kernel = copy.deepcopy(kernel)
+        return kernel
