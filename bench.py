@@ -60,8 +60,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=65536, help="training points (default: headline 65536)")
-    ap.add_argument("--m", type=int, default=0, help="prediction points (default 4 n)")
+    ap.add_argument("--ntrain", dest="n", type=int, default=65536, help="training points (default: headline 65536)")
+    ap.add_argument("--mpredict", dest="m", type=int, default=0, help="prediction points (default 4 n)")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="N of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
     n = args.n
@@ -69,6 +69,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("TGP_ONE_DEVICE") == "1":
+        local_rank = 0
     if args.gpus != world:
         if args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
@@ -88,9 +90,15 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # TGP_DIST_BACKEND=gloo + TGP_ONE_DEVICE=1: rehearsal of this code path with several ranks
+        # sharing one GPU (development boxes have one); the driver's runs use nccl = RCCL
+        backend = os.environ.get("TGP_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         from treegp_amd.dist import DistributedGP
-        dist_solver = DistributedGP(ctx, spec, X, y - ymean, y_err, Xs)
+        dist_solver = DistributedGP(ctx, spec, X, y - ymean, y_err, Xs, profile=True)
 
         def barrier():
             dist.barrier()
@@ -158,16 +166,18 @@ def main():
                        "parallelism": "single" if world == 1 else "rowcyclic%d" % world},
         }
         if acc.get("syrk_ms", 0) > 0:
-            ach = acc["syrk_flops"] / (acc["syrk_ms"] * 1e-3) / 1e12
+            ach = acc["syrk_flops"] / (acc["syrk_ms"] * 1e-3) / 1e12          # per GPU (rank 0's share when N > 1)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "kernel": "syrk_trailing_kernel", "launches": int(acc["syrk_launches"]),
+                               "kernel": "syrk_trailing_kernel" if world == 1 else "syrk_dist_kernel (rank 0)",
+                               "launches": int(acc["syrk_launches"]),
                                "avg_launch_ms": acc["syrk_ms"] / max(acc["syrk_launches"], 1)}
         if "chol_ms" in acc:
             out["cholesky_tflops_fp64"] = (n ** 3 / 3.0) * K / (acc["chol_ms"] * 1e-3) / 1e12
             out["gp_solves_per_sec"] = K / ((acc["kbuild_ms"] + acc["chol_ms"] + acc["trsv_ms"]) * 1e-3)
             out["predict_points_per_sec"] = m * K / (acc["predict_ms"] * 1e-3)
-            out["kbuild_GBps"] = acc["kbuild_bytes"] / (acc["kbuild_ms"] * 1e-3) / 1e9
+            if "kbuild_bytes" in acc:
+                out["kbuild_GBps"] = acc["kbuild_bytes"] / (acc["kbuild_ms"] * 1e-3) / 1e9
             out["phases_ms_per_step"] = {k: acc[k] / K for k in ("kbuild_ms", "chol_ms", "trsv_ms", "predict_ms", "syrk_ms")}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, max(args.cpu_sample // 4, 1))

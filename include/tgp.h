@@ -140,6 +140,40 @@ int tgp_d_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W);
 int tgp_d_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b);
 /* unpack the lower triangle into a dense (n, n) row-major host matrix (upper part zero) */
 int tgp_d_unpack_lower(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *out);
+/* ---- multi-GPU tier (one process per GPU; driver: treegp_amd/dist.py) ------------------------
+ * Row-block-cyclic over 256-row blocks: rank g of G owns blocks b = g, g+G, ...  Its share of
+ * panel p (blocks b >= p) is stored like a single-GPU panel at element offset
+ * tgp_dist_panel_off(p).  h_loff / d_loff are host / device copies of those offsets (Np/256+1
+ * entries).  These calls only enqueue work on the context stream (tgp_set_stream points it at the
+ * caller's stream so that RCCL collectives order with it); they replace, per panel, the same
+ * reference lines as tgp_gp_solve (treegp/gp_interp.py:180-182).                              */
+int tgp_set_stream(tgp_ctx *ctx, void *hip_stream);      /* launch on the caller's stream (NULL = default stream) */
+int tgp_reset_stream(tgp_ctx *ctx);                      /* back to the context's own stream */
+int64_t tgp_dist_panel_rows(int64_t p, int64_t Np, int G, int g);
+int64_t tgp_dist_panel_off(int64_t p, int64_t Np, int G, int g);
+int64_t tgp_dist_local_elems(int64_t Np, int G, int g);
+int tgp_dd_kbuild(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_yerr,
+                  double *d_Aloc, const int64_t *d_loff, int G, int g);
+/* owner of panel kpanel: factor the diagonal block, pack [L_kk(256x256) | W0 | W1] = 98304 doubles */
+int tgp_dd_factor_diag(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int64_t Np, int kpanel, int G, int g,
+                       double *d_W, double *d_bcast);
+/* every rank, after the broadcast of d_bcast: solve the local rows of panel kpanel */
+int tgp_dd_trsm(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int64_t Np, int kpanel, int G, int g,
+                double *d_W, const double *d_bcast);
+/* every rank, after the all-gather of the panel ([rank][cmax][256][256]): update the local block rows */
+int tgp_dd_update(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
+                  const double *d_gathered, int cmax);
+/* block-row-cyclic triangular solves (scipy cho_solve, gp_interp.py:182) */
+int tgp_dd_fwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_yk);
+int tgp_dd_fwd_update(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int64_t Np, int kb, int G, int g,
+                      const double *d_zk, double *d_yloc);
+int tgp_dd_bwd_partial(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int64_t Np, int kb, int G, int g,
+                       const double *d_aloc, double *d_s);
+int tgp_dd_bwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_ak);
+int tgp_dd_logdet_local(tgp_ctx *ctx, const double *d_Aloc, const int64_t *d_loff, int64_t Np, int64_t n, int G, int g,
+                        double *d_out);
+int tgp_dd_info(tgp_ctx *ctx, int reset);                /* first non-PD pivot since the last reset */
+
 /* test hook: tile enumeration of the trailing update over T x T 128-tiles; fills (ti, tj)
  * for every block id (-1 = empty slot) and returns the grid size, or -1 if cap is too small */
 int tgp_debug_tilemap(int64_t T, int32_t *ti, int32_t *tj, int64_t cap);

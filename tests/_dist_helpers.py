@@ -1,0 +1,158 @@
+"""Test-only helpers for the multi-GPU driver: an in-process communicator for virtual ranks
+(threads) and a NumPy stand-in for the per-rank arithmetic (CPU gloo tests)."""
+import threading
+
+import numpy as np
+import torch
+
+from treegp_amd.dist import BLK, BCAST_ELEMS, first_ge, panel_blocks
+
+
+class ThreadComm(object):
+    """G virtual ranks = G threads of one process sharing one GPU stream."""
+
+    class Shared(object):
+        def __init__(self, size):
+            self.size = size
+            self.slots = [None] * size
+            self.barrier = threading.Barrier(size)
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank, self.size = shared, rank, shared.size
+
+    def _exchange(self, t):
+        self.sh.slots[self.rank] = t
+        self.sh.barrier.wait()
+        vals = list(self.sh.slots)
+        return vals
+
+    def broadcast(self, t, src):
+        vals = self._exchange(t)
+        if self.rank != src:
+            t.copy_(vals[src])
+        self.sh.barrier.wait()
+
+    def all_reduce_sum(self, t):
+        vals = self._exchange(t.clone())
+        tot = vals[0].clone()
+        for v in vals[1:]:
+            tot += v
+        self.sh.barrier.wait()
+        t.copy_(tot)
+
+    def all_reduce_max(self, t):
+        vals = self._exchange(t.clone())
+        tot = vals[0].clone()
+        for v in vals[1:]:
+            tot = torch.maximum(tot, v)
+        self.sh.barrier.wait()
+        t.copy_(tot)
+
+    def all_gather(self, out, inp):
+        vals = self._exchange(inp)
+        n = inp.numel()
+        for r in range(self.size):
+            out[r * n:(r + 1) * n].copy_(vals[r])
+        self.sh.barrier.wait()
+
+
+class NumpyLocalOps(object):
+    """Same interface as treegp_amd.dist.HipLocalOps, dense NumPy rows on the CPU.  Exists only so
+    the orchestration (ownership, collectives, gather indexing) can be tested without a GPU."""
+
+    def __init__(self, Kfull, n, G, g):
+        self.n, self.G, self.g = n, G, g
+        self.Np = (n + BLK - 1) // BLK * BLK
+        self.nB = self.Np // BLK
+        self.nloc = panel_blocks(0, self.nB, g, G)
+        self.cmax0 = -(-max(self.nB - 1, 0) // G)
+        Kp = np.eye(self.Np)
+        Kp[:n, :n] = Kfull
+        self.blocks = [g + lb * G for lb in range(self.nloc)]
+        self.rows = {b: Kp[b * BLK:(b + 1) * BLK, :].copy() for b in self.blocks}     # full-width rows
+        self.bcast = torch.zeros(BCAST_ELEMS, dtype=torch.float64)
+        self._info = 0
+
+    def empty(self, n):
+        return torch.empty(n, dtype=torch.float64)
+
+    def zeros(self, n):
+        return torch.zeros(n, dtype=torch.float64)
+
+    def kbuild(self, *a):
+        pass
+
+    def factor_diag(self, k):
+        blk = self.rows[k][:, k * BLK:(k + 1) * BLK]
+        try:
+            L = np.linalg.cholesky(np.tril(blk) + np.tril(blk, -1).T)
+        except np.linalg.LinAlgError:
+            self._info = k * BLK + 1
+            L = np.eye(BLK)
+        self.rows[k][:, k * BLK:(k + 1) * BLK] = L
+        W0 = np.linalg.inv(L[:128, :128]); W1 = np.linalg.inv(L[128:, 128:])
+        self.bcast.copy_(torch.from_numpy(np.concatenate([L.ravel(), W0.ravel(), W1.ravel()])))
+
+    def trsm(self, k):
+        L = self.bcast[:BLK * BLK].numpy().reshape(BLK, BLK)
+        Li = np.linalg.inv(np.tril(L))
+        for b in self.blocks:
+            if b > k:
+                self.rows[b][:, k * BLK:(k + 1) * BLK] = self.rows[b][:, k * BLK:(k + 1) * BLK] @ Li.T
+
+    def panel_send_view(self, k, cmax):
+        out = torch.zeros(cmax * BLK * BLK, dtype=torch.float64)
+        below = [b for b in self.blocks if b > k]
+        for i, b in enumerate(below):
+            out[i * BLK * BLK:(i + 1) * BLK * BLK] = torch.from_numpy(self.rows[b][:, k * BLK:(k + 1) * BLK].ravel())
+        return out
+
+    def update(self, k, gathered, cmax):
+        G = self.G
+        P = gathered.numpy()
+
+        def blk(b):
+            r = b % G
+            idx = (b - first_ge(k + 1, r, G)) // G
+            o = (r * cmax + idx) * BLK * BLK
+            return P[o:o + BLK * BLK].reshape(BLK, BLK)
+        for bi in self.blocks:
+            if bi <= k:
+                continue
+            Pi = blk(bi)
+            for bj in range(k + 1, bi + 1):
+                self.rows[bi][:, bj * BLK:(bj + 1) * BLK] -= Pi @ blk(bj).T
+
+    def info(self):
+        i, self._info = self._info, 0
+        return i
+
+    def fwd_diag(self, k, yk):
+        L = np.tril(self.rows[k][:, k * BLK:(k + 1) * BLK])
+        yk.copy_(torch.from_numpy(np.linalg.solve(L, yk.numpy())))
+
+    def fwd_update(self, k, zk, yloc):
+        z = zk.numpy()
+        for lb, b in enumerate(self.blocks):
+            if b > k:
+                yloc[lb * BLK:(lb + 1) * BLK] -= torch.from_numpy(self.rows[b][:, k * BLK:(k + 1) * BLK] @ z)
+
+    def bwd_partial(self, k, aloc, s):
+        acc = np.zeros(BLK)
+        for lb, b in enumerate(self.blocks):
+            if b > k:
+                acc += self.rows[b][:, k * BLK:(k + 1) * BLK].T @ aloc[lb * BLK:(lb + 1) * BLK].numpy()
+        s.copy_(torch.from_numpy(acc))
+
+    def bwd_diag(self, k, ak):
+        L = np.tril(self.rows[k][:, k * BLK:(k + 1) * BLK])
+        ak.copy_(torch.from_numpy(np.linalg.solve(L.T, ak.numpy())))
+
+    def logdet_local(self, out):
+        s = 0.0
+        for b in self.blocks:
+            d = np.diag(self.rows[b][:, b * BLK:(b + 1) * BLK])
+            for r in range(BLK):
+                if b * BLK + r < self.n:
+                    s += 2.0 * np.log(d[r])
+        out[0] = s

@@ -1,0 +1,87 @@
+"""GPU tests of the multi-GPU kernels and driver on ONE GPU: world of one, and G virtual ranks
+(threads, each with its own tgp_ctx) exchanging data through an in-process communicator."""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _problem(n, m, seed=0):
+    from treegp_amd.synthetic import star_field, headline_invlam
+    from treegp_amd import _lib, ops
+    X, y, y_err, Xs = star_field(n, m, seed=seed)
+    iL = headline_invlam()
+    spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=iL[0, 0], b=iL[0, 1], c=iL[1, 1])
+    return spec, X, y - y.mean(), y_err, Xs
+
+
+def test_world_of_one_matches_single_gpu_path():
+    import torch
+    from treegp_amd import _lib, ops
+    from treegp_amd.dist import DistributedGP, SelfComm
+    spec, X, y, y_err, Xs = _problem(1900, 1000)
+    alpha_ref, logdet_ref, _, _ = ops.gp_solve(spec, X, y, y_err)
+    yp_ref = ops.gp_predict(spec, X, alpha_ref, Xs)
+    ctx = _lib.new_ctx(0)
+    gp = DistributedGP(ctx, spec, X, y, y_err, Xs, comm=SelfComm(), device=torch.device("cuda", 0))
+    alpha, dys = gp.step()
+    torch.cuda.synchronize()
+    a = alpha.cpu().numpy()[:len(y)]
+    np.testing.assert_allclose(a, alpha_ref, rtol=0, atol=1e-11 * np.abs(alpha_ref).max())
+    np.testing.assert_allclose(float(gp.logdet[0]), logdet_ref, rtol=1e-13)
+    np.testing.assert_allclose(dys.cpu().numpy(), yp_ref, rtol=0, atol=1e-11 * np.abs(yp_ref).max())
+    _lib.load_library().tgp_reset_stream(ctx)
+
+
+@pytest.mark.parametrize("G,n", [(2, 1500), (3, 2300), (4, 1100), (8, 4500)])
+def test_virtual_ranks(G, n):
+    import torch
+    from treegp_amd import _lib, ops
+    from treegp_amd.dist import DistributedGP
+    from _dist_helpers import ThreadComm
+    from oracle import gp_oracle as O
+    m = 777
+    spec, X, y, y_err, Xs = _problem(n, m, seed=G)
+    alpha_ref, logdet_ref, _, _ = ops.gp_solve(spec, X, y, y_err)
+    yp_ref = ops.gp_predict(spec, X, alpha_ref, Xs)
+    shared = ThreadComm.Shared(G)
+    results, errors = [None] * G, []
+    dev = torch.device("cuda", 0)
+
+    def run(rank):
+        try:
+            ctx = _lib.new_ctx(0)
+            gp = DistributedGP(ctx, spec, X, y, y_err, Xs, comm=ThreadComm(shared, rank), device=dev)
+            alpha, _ = gp.step()
+            full = gp.gather_predictions()
+            torch.cuda.synchronize()
+            results[rank] = (alpha.cpu().numpy()[:n], float(gp.logdet[0]), full.cpu().numpy())
+        except BaseException as e:            # noqa: BLE001 - surface any failure of a virtual rank
+            errors.append(e)
+            try:
+                shared.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for r in range(G):
+        a, ld, yp = results[r]
+        np.testing.assert_allclose(a, alpha_ref, rtol=0, atol=1e-10 * np.abs(alpha_ref).max())
+        np.testing.assert_allclose(ld, logdet_ref, rtol=1e-12)
+        np.testing.assert_allclose(yp, yp_ref, rtol=0, atol=1e-10 * np.abs(yp_ref).max())
+    # and against the oracle (north-star tolerance on predictions)
+    kw = dict(amp=spec.amp, a=spec.a, b=spec.b, c=spec.c)
+    a_o, _ = O.gp_solve(O.kernel_matrix("gauss", X, **kw), y, y_err)
+    yp_o = O.gp_predict(O.kernel_matrix("gauss", Xs, X, **kw), a_o)
+    np.testing.assert_allclose(results[0][2], yp_o, rtol=0, atol=1e-10 * np.abs(yp_o).max())

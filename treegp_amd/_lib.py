@@ -58,11 +58,47 @@ SIGNATURES = {
     "tgp_d_potrs": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "tgp_d_unpack_lower": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "tgp_debug_tilemap": (C.c_int, [_i64, _vp, _vp, _i64]),
+    # multi-GPU tier
+    "tgp_set_stream": (C.c_int, [_vp, _vp]),
+    "tgp_reset_stream": (C.c_int, [_vp]),
+    "tgp_dist_panel_rows": (_i64, [_i64, _i64, C.c_int, C.c_int]),
+    "tgp_dist_panel_off": (_i64, [_i64, _i64, C.c_int, C.c_int]),
+    "tgp_dist_local_elems": (_i64, [_i64, C.c_int, C.c_int]),
+    "tgp_dd_kbuild": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp, _vp, C.c_int, C.c_int]),
+    "tgp_dd_factor_diag": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "tgp_dd_trsm": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "tgp_dd_update": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, C.c_int]),
+    "tgp_dd_fwd_diag": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "tgp_dd_fwd_update": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "tgp_dd_bwd_partial": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "tgp_dd_bwd_diag": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "tgp_dd_logdet_local": (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp]),
+    "tgp_dd_info": (C.c_int, [_vp, C.c_int]),
 }
 
 _lib = None
 _ctx = {}
 _lock = threading.Lock()
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.  Two HIP runtimes in one process do not
+    coexist (the second one finds no device), so when torch is installed but not imported yet,
+    map its copy first; libtgp.so then binds to it and a later `import torch` (multi-GPU driver)
+    shares the same runtime.  No torch code runs here."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("TGP_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
 
 
 def load_library():
@@ -72,6 +108,7 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libtgp.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "or `make -C treegp_amd/csrc`" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
@@ -101,6 +138,19 @@ def get_ctx(device=None):
                 raise RuntimeError("tgp_init(device=%d) failed with code %d" % (device, rc))
             _ctx[device] = h
         return _ctx[device]
+
+
+def new_ctx(device=0):
+    """An additional, uncached context on `device` (each context serves one caller at a time)."""
+    lib = load_library()
+    if lib.tgp_device_count() <= 0:
+        raise RuntimeError("treegp_amd needs an AMD GPU (HIP device); none found and there is no CPU path")
+    h = _vp()
+    dev = (C.c_int * 1)(device)
+    rc = lib.tgp_init(dev, 1, C.byref(h))
+    if rc != 0:
+        raise RuntimeError("tgp_init(device=%d) failed with code %d" % (device, rc))
+    return h
 
 
 def check(ctx, rc, what):

@@ -86,10 +86,12 @@ int tgp_init(const int *devices, int ndev, tgp_ctx **out) {
     tgp_ctx_full *ctx = new tgp_ctx_full();
     ctx->device = devices[0];
     if (hipSetDevice(ctx->device) != hipSuccess) { delete ctx; return -2; }
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return -2; }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return -2; }
+    ctx->stream = ctx->own_stream;
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_info, 256) != hipSuccess) { delete ctx; return -2; }
+    if (hipMemset(ctx->d_info, 0, 256) != hipSuccess) { delete ctx; return -2; }
     if (hipHostMalloc((void **)&ctx->h_info, 256, hipHostMallocDefault) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_scal, 16 * sizeof(double)) != hipSuccess) { delete ctx; return -2; }
     if (hipHostMalloc((void **)&ctx->h_scal, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess) { delete ctx; return -2; }
@@ -113,7 +115,7 @@ void tgp_destroy(tgp_ctx *ctx) {
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->prof_events) (void)hipEventDestroy(ev);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete static_cast<tgp_ctx_full *>(ctx);
 }
 

@@ -15,113 +15,9 @@
 // workgroup's C prologue/epilogue hides behind the other's MFMAs.
 #include "tgp_internal.h"
 
-typedef double d4 __attribute__((ext_vector_type(4)));
+#include "gemm_tile.h"
 
 namespace {
-constexpr int KB = 16;         // k-chunk depth
-constexpr int LS = KB + 2;     // LDS row stride in doubles
-
-// MODE 0: C = A B^T     MODE 1: C -= A B^T      (A: 128 x kdepth, B: 128 x kdepth, row-major)
-// A and C always live in 256-wide panels (ld 256); B is a panel (LDB 256) or a W block (LDB 128).
-template <int MODE, int LDB, int KDEPTH>
-__device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double *b_ptr, double *c_ptr) {
-    constexpr int LDA = TGP_PW, LDC = TGP_PW;
-    __shared__ __attribute__((aligned(16))) double lds[2][2][128 * LS];   // [buf][A|B][row*LS + k]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1;
-    const int l15 = lane & 15, l4 = lane >> 4;
-
-    // staging map: piece s of this thread = row (tid>>3) + 32 s, doubles kp..kp+1
-    const int srow = tid >> 3;
-    const int kp = (tid & 7) * 2;
-    const double *ga = a_ptr + srow * LDA + kp;
-    const double *gb = b_ptr + srow * LDB + kp;
-
-    double2 ra[4], rb[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        ra[s] = *reinterpret_cast<const double2 *>(ga + s * 32 * LDA);
-        rb[s] = *reinterpret_cast<const double2 *>(gb + s * 32 * LDB);
-    }
-
-    d4 acc[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
-
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        *reinterpret_cast<double2 *>(&lds[0][0][(srow + 32 * s) * LS + kp]) = ra[s];
-        *reinterpret_cast<double2 *>(&lds[0][1][(srow + 32 * s) * LS + kp]) = rb[s];
-    }
-    __syncthreads();
-
-    constexpr int nchunk = KDEPTH / KB;
-    const int fa = (wr * 64 + l15) * LS + l4;      // fragment read offsets
-    const int fb = (wc * 64 + l15) * LS + l4;
-    for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
-        const bool more = (c + 1 < nchunk);
-        if (more) {
-            const int k0 = (c + 1) * KB;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                ra[s] = *reinterpret_cast<const double2 *>(ga + s * 32 * LDA + k0);
-                rb[s] = *reinterpret_cast<const double2 *>(gb + s * 32 * LDB + k0);
-            }
-        }
-        const double *As = lds[buf][0];
-        const double *Bs = lds[buf][1];
-#pragma unroll
-        for (int k4 = 0; k4 < KB / 4; ++k4) {
-            double af[4], bf[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) af[m] = As[fa + m * 16 * LS + k4 * 4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) bf[n] = Bs[fb + n * 16 * LS + k4 * 4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
-        }
-        if (more) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                *reinterpret_cast<double2 *>(&lds[buf ^ 1][0][(srow + 32 * s) * LS + kp]) = ra[s];
-                *reinterpret_cast<double2 *>(&lds[buf ^ 1][1][(srow + 32 * s) * LS + kp]) = rb[s];
-            }
-        }
-        __syncthreads();
-    }
-
-    // C fragment map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 r
-    double *cbase = c_ptr + (wr * 64 + l4) * LDC + wc * 64 + l15;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        if constexpr (MODE == 1) {
-            double old[4][4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) old[n][r] = cbase[(m * 16 + 4 * r) * LDC + n * 16];
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cbase[(m * 16 + 4 * r) * LDC + n * 16] = old[n][r] - acc[m][n][r];
-        } else {
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cbase[(m * 16 + 4 * r) * LDC + n * 16] = acc[m][n][r];
-        }
-    }
-}
-
 // a column of 128-row tiles: tile t uses A rows [128 t, +128), the fixed B block, C rows [128 t, +128)
 template <int MODE, int LDB>
 __global__ __launch_bounds__(256, 2) void gemm_col_kernel(const double *A, const double *B, double *C) {
@@ -193,6 +89,27 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
         W[idx] = (c <= i) ? T[i * TS + c] : 0.0;
     }
 }
+
+// multi-GPU trailing update: rank g updates its own block rows.  P is the all-gathered panel,
+// laid out [rank][cmax blocks][256][256]; blockIdx.y = local tile row among blocks > k,
+// blockIdx.x = trailing tile column (tiles right of the diagonal exit).
+__global__ __launch_bounds__(256, 2) void syrk_dist_kernel(double *Aloc, const int64_t *__restrict__ loff, int kpanel,
+                                                           int G, int g, int cmax, const double *P) {
+    const int lt = blockIdx.y;
+    const int64_t gtj = blockIdx.x;
+    const int64_t s0 = kpanel + 1;
+    const int64_t bi = dist_first_ge(s0, g, G) + (int64_t)(lt >> 1) * G;
+    const int64_t gti = 2 * (bi - s0) + (lt & 1);
+    if (gtj > gti) return;
+    const int64_t bj = s0 + (gtj >> 1);
+    const int rj = (int)(bj % G);
+    const int64_t idxj = (bj - dist_first_ge(s0, rj, G)) / G;
+    const double *a = P + (((int64_t)g * cmax + (lt >> 1)) * TGP_PW + (lt & 1) * TGP_TB) * TGP_PW;
+    const double *b = P + (((int64_t)rj * cmax + idxj) * TGP_PW + (gtj & 1) * TGP_TB) * TGP_PW;
+    double *c = Aloc + loff[bj] + (((bi - dist_first_ge(bj, g, G)) / G) * TGP_PW + (lt & 1) * TGP_TB) * TGP_PW +
+                (gtj & 1) * TGP_TB;
+    gemm_tile_128<1, TGP_PW, TGP_PW>(a, b, c);
+}
 }  // namespace
 
 int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
@@ -248,6 +165,42 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
         ctx->timings[5] = tot;
     }
     return *ctx->h_info;
+}
+
+
+// 256x256 diagonal block (ld 256): L in place, inverses of its two 128-blocks to W0 / W1
+int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base) {
+    hipStream_t st = ctx->stream;
+    double *R1 = blk + (int64_t)TGP_TB * TGP_PW;
+    potrf128_kernel<<<1, 256, 0, st>>>(blk, TGP_PW, W0, ctx->d_info, base);
+    gemm_col_kernel<0, TGP_TB><<<1, 256, 0, st>>>(R1, W0, R1);
+    gemm_col_kernel<1, TGP_PW><<<1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
+    potrf128_kernel<<<1, 256, 0, st>>>(R1 + TGP_TB, TGP_PW, W1, ctx->d_info, base + TGP_TB);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+
+// rows (ntiles x 128, ld 256) <- rows L_kk^-T with L_kk given by its 256x256 block and W0, W1
+int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, const double *W0, const double *W1) {
+    if (ntiles <= 0) return 0;
+    hipStream_t st = ctx->stream;
+    gemm_col_kernel<0, TGP_TB><<<ntiles, 256, 0, st>>>(rows, W0, rows);
+    gemm_col_kernel<1, TGP_PW><<<ntiles, 256, 0, st>>>(rows, Lkk + (int64_t)TGP_TB * TGP_PW, rows + TGP_TB);
+    gemm_col_kernel<0, TGP_TB><<<ntiles, 256, 0, st>>>(rows + TGP_TB, W1, rows + TGP_TB);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_syrk_dist(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
+                     const double *d_P, int cmax) {
+    const int64_t nB = Np / TGP_PW;
+    const int64_t nloc = dist_panel_blocks(kpanel + 1, nB, g, G);     // local blocks > k
+    const int64_t ncol = 2 * (nB - kpanel - 1);
+    if (nloc <= 0 || ncol <= 0) return 0;
+    dim3 grid((unsigned)ncol, (unsigned)(2 * nloc));
+    syrk_dist_kernel<<<grid, 256, 0, ctx->stream>>>(d_Aloc, d_loff, kpanel, G, g, cmax, d_P);
+    TGP_HIP(hipGetLastError());
+    return 0;
 }
 
 int tgp_debug_tilemap(int64_t T, int32_t *ti, int32_t *tj, int64_t cap) {

@@ -1,0 +1,125 @@
+// Device-pointer entry points for the multi-GPU (one process per GPU) driver, treegp_amd/dist.py.
+// Row-block-cyclic layout over 256-row blocks: rank g of G owns blocks b = g, g+G, ...; its part
+// of panel p (blocks b >= p) is stored like the single-GPU panel, back to back, at d_loff[p].
+// Nothing here synchronises: every call only enqueues work on the context's stream (which the
+// driver points at torch's current stream with tgp_set_stream, so RCCL collectives order with it).
+#include "tgp_internal.h"
+
+extern "C" {
+
+int tgp_set_stream(tgp_ctx *ctx, void *stream) {
+    if (!ctx) return -1;
+    static_cast<void>(hipSetDevice(ctx->device));
+    ctx->ext_stream = true;
+    ctx->stream = (hipStream_t)stream;          // NULL is the device's default stream
+    return 0;
+}
+
+int tgp_reset_stream(tgp_ctx *ctx) {
+    if (!ctx) return -1;
+    ctx->ext_stream = false;
+    ctx->stream = ctx->own_stream;
+    return 0;
+}
+
+int64_t tgp_dist_panel_rows(int64_t p, int64_t Np, int G, int g) {
+    return dist_panel_blocks(p, Np / TGP_PW, g, G) * TGP_PW;
+}
+
+int64_t tgp_dist_panel_off(int64_t p, int64_t Np, int G, int g) {
+    int64_t off = 0;
+    const int64_t nB = Np / TGP_PW;
+    for (int64_t q = 0; q < p && q < nB; ++q) off += dist_panel_blocks(q, nB, g, G) * TGP_PW * TGP_PW;
+    return off;
+}
+
+int64_t tgp_dist_local_elems(int64_t Np, int G, int g) { return tgp_dist_panel_off(Np / TGP_PW, Np, G, g); }
+
+int tgp_dd_kbuild(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_yerr,
+                  double *d_Aloc, const int64_t *d_loff, int G, int g) {
+    TGP_ARG(k && d_X && d_Aloc && d_loff && n > 0);
+    return launch_kbuild_lower_dist(ctx, k, d_X, n, padded_n(n), d_yerr, d_Aloc, d_loff, G, g);
+}
+
+// owner of panel kpanel: factor its 256x256 diagonal block and pack [L_kk | W0 | W1] (98304 doubles)
+int tgp_dd_factor_diag(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int64_t Np, int kpanel, int G, int g,
+                       double *d_W, double *d_bcast) {
+    TGP_ARG(d_Aloc && h_loff && d_W && d_bcast && kpanel % G == g);
+    hipStream_t st = ctx->stream;
+    double *blk = d_Aloc + h_loff[kpanel];
+    double *W0 = d_W + (int64_t)(2 * kpanel) * TGP_TB * TGP_TB;
+    int rc = launch_factor_diag256(ctx, blk, W0, W0 + TGP_TB * TGP_TB, kpanel * TGP_PW);
+    if (rc) return rc;
+    TGP_HIP(hipMemcpyAsync(d_bcast, blk, (size_t)TGP_PW * TGP_PW * 8, hipMemcpyDeviceToDevice, st));
+    TGP_HIP(hipMemcpyAsync(d_bcast + TGP_PW * TGP_PW, W0, (size_t)2 * TGP_TB * TGP_TB * 8, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// every rank: keep W0/W1 of panel kpanel and solve its own rows below the diagonal block
+int tgp_dd_trsm(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int64_t Np, int kpanel, int G, int g,
+                double *d_W, const double *d_bcast) {
+    TGP_ARG(d_Aloc && h_loff && d_W && d_bcast);
+    hipStream_t st = ctx->stream;
+    double *W0 = d_W + (int64_t)(2 * kpanel) * TGP_TB * TGP_TB;
+    if (kpanel % G != g)
+        TGP_HIP(hipMemcpyAsync(W0, d_bcast + TGP_PW * TGP_PW, (size_t)2 * TGP_TB * TGP_TB * 8, hipMemcpyDeviceToDevice, st));
+    const int64_t nB = Np / TGP_PW;
+    const int64_t below = dist_panel_blocks(kpanel + 1, nB, g, G);
+    const int64_t skip = (kpanel % G == g) ? TGP_PW : 0;          // the owner's diagonal block comes first
+    double *rows = d_Aloc + h_loff[kpanel] + skip * TGP_PW;
+    return launch_trsm_rows(ctx, rows, (int)(2 * below), d_bcast, d_bcast + TGP_PW * TGP_PW,
+                            d_bcast + TGP_PW * TGP_PW + TGP_TB * TGP_TB);
+}
+
+int tgp_dd_update(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
+                  const double *d_gathered, int cmax) {
+    TGP_ARG(d_Aloc && d_loff && d_gathered && cmax >= 0);
+    return launch_syrk_dist(ctx, d_Aloc, d_loff, Np, kpanel, G, g, d_gathered, cmax);
+}
+
+// forward sweep, block kb (owner): y_k (256) <- L_kk^-1 y_k
+int tgp_dd_fwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_yk) {
+    const double *W0 = d_W + (int64_t)(2 * kb) * TGP_TB * TGP_TB;
+    return launch_diag256_fwd(ctx, d_Aloc + h_loff[kb], W0, W0 + TGP_TB * TGP_TB, d_yk);
+}
+// forward sweep, every rank: local rows of blocks > kb:  y_loc -= L[:, kb] z_k
+int tgp_dd_fwd_update(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int64_t Np, int kb, int G, int g,
+                      const double *d_zk, double *d_yloc) {
+    const int64_t nB = Np / TGP_PW;
+    const int64_t below = dist_panel_blocks(kb + 1, nB, g, G);
+    if (below <= 0) return 0;
+    const int64_t skip = (kb % G == g) ? TGP_PW : 0;
+    const int64_t lb0 = (dist_first_ge(kb + 1, g, G) - g) / G;          // local index of the first block > kb
+    return launch_fwd_update_rows(ctx, d_Aloc + h_loff[kb] + skip * TGP_PW, below * TGP_PW, d_zk, d_yloc + lb0 * TGP_PW);
+}
+// backward sweep, every rank: s (256) = sum over local rows of blocks > kb of L[i, kb]^T a_i
+int tgp_dd_bwd_partial(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int64_t Np, int kb, int G, int g,
+                       const double *d_aloc, double *d_s) {
+    const int64_t nB = Np / TGP_PW;
+    const int64_t below = dist_panel_blocks(kb + 1, nB, g, G);
+    const int64_t skip = (kb % G == g) ? TGP_PW : 0;
+    const int64_t lb0 = (below > 0) ? (dist_first_ge(kb + 1, g, G) - g) / G : 0;
+    return launch_gemv_t_rows(ctx, d_Aloc + h_loff[kb] + skip * TGP_PW, below * TGP_PW, d_aloc + lb0 * TGP_PW, d_s);
+}
+// backward sweep, block kb (owner): a_k (256) <- L_kk^-T a_k
+int tgp_dd_bwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_ak) {
+    const double *W0 = d_W + (int64_t)(2 * kb) * TGP_TB * TGP_TB;
+    return launch_diag256_bwd(ctx, d_Aloc + h_loff[kb], W0, W0 + TGP_TB * TGP_TB, d_ak);
+}
+
+int tgp_dd_logdet_local(tgp_ctx *ctx, const double *d_Aloc, const int64_t *d_loff, int64_t Np, int64_t n, int G, int g,
+                        double *d_out) {
+    return launch_logdet_dist(ctx, d_Aloc, d_loff, Np, n, G, g, d_out);
+}
+
+// first non-positive pivot seen since the last reset (0 = none); synchronises the stream
+int tgp_dd_info(tgp_ctx *ctx, int reset) {
+    hipStream_t st = ctx->stream;
+    TGP_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+    TGP_HIP(hipStreamSynchronize(st));
+    const int info = *ctx->h_info;
+    if (reset) TGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), st));
+    return info;
+}
+
+}  // extern "C"

@@ -8,22 +8,13 @@
 
 // One 128x128 tile per workgroup of 256 threads.  Lane l of wave w owns columns 2l, 2l+1 and
 // rows w, w+4, ... of the tile, so each wave-instruction stores one full 1 KiB row segment.
+// (ti, tj) are GLOBAL 128-tile coordinates; `tile` is where the tile lives (ld 256).
 template <int KE>
-__global__ __launch_bounds__(256) void kbuild_lower_kernel(KParams p, const double *__restrict__ X, int64_t n,
-                                                           int64_t Np, const double *__restrict__ yerr,
-                                                           double *__restrict__ A) {
-    // triangular tile enumeration: b -> (ti, tj), tj <= ti
-    const int64_t b = blockIdx.x;
-    int64_t ti = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-    while (ti * (ti + 1) / 2 > b) --ti;
-    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
-    const int64_t tj = b - ti * (ti + 1) / 2;
-
+__device__ __forceinline__ void kbuild_tile(const KParams &p, const double *__restrict__ X, int64_t n,
+                                            const double *__restrict__ yerr, int64_t ti, int64_t tj,
+                                            double *__restrict__ tile) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t pj = tj >> 1;
-    double *tile = A + panel_off(pj, Np) + (ti * TGP_TB - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
-
     const int64_t j0 = tj * TGP_TB + 2 * lane;
     double xj0 = 0, yj0 = 0, xj1 = 0, yj1 = 0;
     if (j0 < n) { xj0 = X[2 * j0]; yj0 = X[2 * j0 + 1]; }
@@ -56,6 +47,56 @@ __global__ __launch_bounds__(256) void kbuild_lower_kernel(KParams p, const doub
         }
         *reinterpret_cast<double2 *>(tile + (int64_t)r * TGP_PW + 2 * lane) = v;
     }
+}
+
+template <int KE>
+__global__ __launch_bounds__(256) void kbuild_lower_kernel(KParams p, const double *__restrict__ X, int64_t n,
+                                                           int64_t Np, const double *__restrict__ yerr,
+                                                           double *__restrict__ A) {
+    // triangular tile enumeration: b -> (ti, tj), tj <= ti
+    const int64_t b = blockIdx.x;
+    int64_t ti = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > b) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    const int64_t tj = b - ti * (ti + 1) / 2;
+    const int64_t pj = tj >> 1;
+    double *tile = A + panel_off(pj, Np) + (ti * TGP_TB - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
+    kbuild_tile<KE>(p, X, n, yerr, ti, tj, tile);
+}
+
+// multi-GPU: rank g of G owns the 256-row blocks b = g, g+G, ...; blockIdx.y = local tile row,
+// blockIdx.x = global tile column (tiles right of the diagonal exit).
+template <int KE>
+__global__ __launch_bounds__(256) void kbuild_lower_dist_kernel(KParams p, const double *__restrict__ X, int64_t n,
+                                                                const double *__restrict__ yerr,
+                                                                double *__restrict__ Aloc,
+                                                                const int64_t *__restrict__ loff, int G, int g) {
+    const int64_t lt = blockIdx.y, tj = blockIdx.x;
+    const int64_t bi = g + (lt >> 1) * G;
+    const int64_t ti = 2 * bi + (lt & 1);
+    if (tj > ti) return;
+    const int64_t pj = tj >> 1;
+    const int64_t fb = dist_first_ge(pj, g, G);
+    double *tile = Aloc + loff[pj] + (((bi - fb) / G) * TGP_PW + (lt & 1) * TGP_TB) * TGP_PW + (tj & 1) * TGP_TB;
+    kbuild_tile<KE>(p, X, n, yerr, ti, tj, tile);
+}
+
+int launch_kbuild_lower_dist(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,
+                             const double *d_yerr, double *d_Aloc, const int64_t *d_loff, int G, int g) {
+    const int ke = kind_to_ke(k->kind);
+    TGP_ARG(ke >= 0 && G >= 1 && g >= 0 && g < G);
+    const KParams p = make_kparams(k);
+    const int64_t nB = Np / TGP_PW;
+    const int64_t nloc = (nB > g) ? (nB - g + G - 1) / G : 0;
+    if (nloc == 0) return 0;
+    dim3 grid((unsigned)(2 * nB), (unsigned)(2 * nloc)), block(256);
+    switch (ke) {
+        case KE_GAUSS: kbuild_lower_dist_kernel<KE_GAUSS><<<grid, block, 0, ctx->stream>>>(p, d_X, n, d_yerr, d_Aloc, d_loff, G, g); break;
+        case KE_VK: kbuild_lower_dist_kernel<KE_VK><<<grid, block, 0, ctx->stream>>>(p, d_X, n, d_yerr, d_Aloc, d_loff, G, g); break;
+        default: kbuild_lower_dist_kernel<KE_AVK><<<grid, block, 0, ctx->stream>>>(p, d_X, n, d_yerr, d_Aloc, d_loff, G, g); break;
+    }
+    TGP_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,

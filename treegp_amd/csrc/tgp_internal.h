@@ -13,7 +13,9 @@
 
 struct tgp_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every kernel is launched on
+    hipStream_t own_stream = nullptr;  // created by tgp_init
+    bool ext_stream = false;           // stream was set by tgp_set_stream
     std::string err;
     double timings[TGP_NTIMINGS] = {0};
     int profiling = 0;
@@ -58,6 +60,19 @@ __host__ __device__ inline int64_t padded_n(int64_t n) {
     return (n + TGP_PW - 1) / TGP_PW * TGP_PW;
 }
 
+// ---- multi-GPU row-block-cyclic geometry (blocks of 256 rows; rank g of G owns b = g, g+G, ...) ----
+// smallest block index >= s owned by rank r
+__host__ __device__ inline int64_t dist_first_ge(int64_t s, int r, int G) {
+    int64_t d = (r - s) % G;
+    if (d < 0) d += G;
+    return s + d;
+}
+// number of local 256-row blocks of rank g in panel p (blocks b >= p)
+__host__ __device__ inline int64_t dist_panel_blocks(int64_t p, int64_t nB, int g, int G) {
+    const int64_t fb = dist_first_ge(p, g, G);
+    return (fb < nB) ? (nB - 1 - fb) / G + 1 : 0;
+}
+
 // trailing-update tile enumeration (XCD-aware): see chol.hip
 __host__ __device__ inline int64_t tilemap_grid(int64_t T) {
     int64_t S = (T + 7) / 8;                 // super-tiles per side
@@ -91,6 +106,18 @@ int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, in
 int launch_kernel_dense(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,
                         const double *d_Y, int64_t m, int self, double *d_out);
 int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W);
+int launch_kbuild_lower_dist(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,
+                             const double *d_yerr, double *d_Aloc, const int64_t *d_loff, int G, int g);
+int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base);
+int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, const double *W0, const double *W1);
+int launch_syrk_dist(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
+                     const double *d_P, int cmax);
+int launch_diag256_fwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y);
+int launch_diag256_bwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y);
+int launch_fwd_update_rows(tgp_ctx *ctx, const double *Lrows, int64_t rows, const double *z, double *yrows);
+int launch_gemv_t_rows(tgp_ctx *ctx, const double *Lrows, int64_t rows, const double *a, double *s);
+int launch_logdet_dist(tgp_ctx *ctx, const double *d_Aloc, const int64_t *d_loff, int64_t Np, int64_t n, int G, int g,
+                       double *d_out);
 int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b);
 int launch_logdet(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out);
 int launch_dot(tgp_ctx *ctx, const double *d_a, const double *d_b, int64_t n, double *d_out);

@@ -106,6 +106,46 @@ __global__ __launch_bounds__(1024) void dot_kernel(const double *__restrict__ a,
         *out = t;
     }
 }
+
+// out[c] += sign * sum_r L[r][c] a[r] over `rows` rows of a 128-column block (ld 256); partial sums
+// per workgroup are combined with global fp64 atomics (out must be initialised by the caller)
+__global__ __launch_bounds__(256) void gemv_t_acc_kernel(const double *__restrict__ L, int64_t rows,
+                                                         const double *__restrict__ a, double *out, double sign) {
+    __shared__ double part[256];
+    const int tid = threadIdx.x, c = tid & 127, h = tid >> 7;
+    const int64_t r0 = (int64_t)blockIdx.x * 128;
+    const int64_t r1 = (r0 + 128 < rows) ? r0 + 128 : rows;
+    double s = 0.0;
+    for (int64_t r = r0 + h; r < r1; r += 2) s += L[r * TGP_PW + c] * a[r];
+    part[tid] = s;
+    __syncthreads();
+    if (tid < 128) {
+        const double v = sign * (part[tid] + part[tid + 128]);
+        __hip_atomic_fetch_add(out + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// multi-GPU log-determinant share: sum over the diagonal blocks this rank owns
+__global__ __launch_bounds__(1024) void logdet_dist_kernel(const double *__restrict__ Aloc,
+                                                           const int64_t *__restrict__ loff, int64_t nB, int64_t n,
+                                                           int G, int g, double *out) {
+    __shared__ double part[16];
+    double s = 0.0;
+    const int64_t nloc = (nB > g) ? (nB - g + G - 1) / G : 0;
+    for (int64_t t = threadIdx.x; t < nloc * TGP_PW; t += 1024) {
+        const int64_t b = g + (t >> 8) * G;
+        const int64_t r = t & 255;
+        if (b * TGP_PW + r < n) s += 2.0 * log(Aloc[loff[b] + r * TGP_PW + r]);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += part[k];
+        *out = t;
+    }
+}
 }  // namespace
 
 int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b) {
@@ -141,6 +181,53 @@ int launch_logdet(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double
 
 int launch_dot(tgp_ctx *ctx, const double *d_a, const double *d_b, int64_t n, double *d_out) {
     dot_kernel<<<1, 1024, 0, ctx->stream>>>(d_a, d_b, n, d_out);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- pieces of the block-row-cyclic triangular solves (multi-GPU driver) ---------------------
+// y (256) <- L_kk^-1 y   with L_kk = [[L00, 0], [L10, L11]] given by its block (ld 256), W0 = L00^-1, W1 = L11^-1
+int launch_diag256_fwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y) {
+    hipStream_t st = ctx->stream;
+    diag_gemv_n_kernel<<<1, 256, 0, st>>>(W0, y);
+    fwd_update_kernel<<<32, 256, 0, st>>>(Lkk + (int64_t)TGP_TB * TGP_PW, TGP_TB, y, y + TGP_TB);
+    diag_gemv_n_kernel<<<1, 256, 0, st>>>(W1, y + TGP_TB);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+// y (256) <- L_kk^-T y
+int launch_diag256_bwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y) {
+    hipStream_t st = ctx->stream;
+    diag_gemv_t_kernel<<<1, 256, 0, st>>>(W1, y + TGP_TB);
+    gemv_t_acc_kernel<<<1, 256, 0, st>>>(Lkk + (int64_t)TGP_TB * TGP_PW, TGP_TB, y + TGP_TB, y, -1.0);
+    diag_gemv_t_kernel<<<1, 256, 0, st>>>(W0, y);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+// yrows[r] -= L[r, 0:256] . z   for `rows` rows (ld 256)
+int launch_fwd_update_rows(tgp_ctx *ctx, const double *Lrows, int64_t rows, const double *z, double *yrows) {
+    if (rows <= 0) return 0;
+    hipStream_t st = ctx->stream;
+    const unsigned g = (unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+    fwd_update_kernel<<<g, 256, 0, st>>>(Lrows, rows, z, yrows);
+    fwd_update_kernel<<<g, 256, 0, st>>>(Lrows + TGP_TB, rows, z + TGP_TB, yrows);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+// s (256) = sum_r L[r, 0:256]^T a[r]   (s zeroed here)
+int launch_gemv_t_rows(tgp_ctx *ctx, const double *Lrows, int64_t rows, const double *a, double *s) {
+    hipStream_t st = ctx->stream;
+    TGP_HIP(hipMemsetAsync(s, 0, TGP_PW * sizeof(double), st));
+    if (rows <= 0) return 0;
+    const unsigned g = (unsigned)((rows + 127) / 128);
+    gemv_t_acc_kernel<<<g, 256, 0, st>>>(Lrows, rows, a, s, 1.0);
+    gemv_t_acc_kernel<<<g, 256, 0, st>>>(Lrows + TGP_TB, rows, a, s + TGP_TB, 1.0);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+int launch_logdet_dist(tgp_ctx *ctx, const double *d_Aloc, const int64_t *d_loff, int64_t Np, int64_t n, int G, int g,
+                       double *d_out) {
+    logdet_dist_kernel<<<1, 1024, 0, ctx->stream>>>(d_Aloc, d_loff, Np / TGP_PW, n, G, g, d_out);
     TGP_HIP(hipGetLastError());
     return 0;
 }

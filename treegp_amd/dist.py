@@ -1,0 +1,359 @@
+"""Multi-GPU GP solve: row-block-cyclic distributed Cholesky + triangular solves + sharded predict.
+
+One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI).  The reference has
+no distributed code; this is the N-scaling axis of SURVEY.md 8(e) for the same seams as
+``tgp_gp_solve`` / ``tgp_gp_predict`` (treegp/gp_interp.py:177-183).
+
+Layout: the N x N kernel matrix is cut into 256-row blocks; rank g of G owns block rows
+b = g, g+G, ... (their lower-triangular part, stored as packed 256-wide panels like the single-GPU
+factor).  Per panel k:
+
+    owner (k % G)   factor the 256x256 diagonal block            tgp_dd_factor_diag
+    broadcast       [L_kk | W0 | W1] = 768 KB                    dist.broadcast
+    every rank      solve its rows of panel k (GEMMs with W)     tgp_dd_trsm
+    all-gather      the panel, ((N - 256 k)/G) x 256 per rank    dist.all_gather_into_tensor
+    every rank      update its own block rows on fp64 MFMA       tgp_dd_update
+
+K build needs no communication (``tgp_dd_kbuild``).  The triangular solves move one 2 KB
+broadcast (forward) / one 2 KB all-reduce (backward) per block.  Prediction points are sharded,
+``alpha`` and the coordinates are replicated.
+
+The orchestration below is independent of where the local arithmetic runs: ``HipLocalOps`` is the
+product implementation (device pointers into libtgp.so); tests substitute a NumPy stand-in to
+exercise the communication logic under ``gloo`` on CPUs.
+"""
+import ctypes as C
+
+import numpy as np
+
+BLK = 256                      # block-row height = panel width
+BCAST_ELEMS = BLK * BLK + 2 * 128 * 128
+
+
+def first_ge(s, r, G):
+    """smallest block index >= s owned by rank r"""
+    return s + ((r - s) % G)
+
+
+def panel_blocks(p, nB, g, G):
+    fb = first_ge(p, g, G)
+    return (nB - 1 - fb) // G + 1 if fb < nB else 0
+
+
+class TorchComm(object):
+    """Collectives over torch.distributed (nccl on GPUs; gloo for the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self.native_gather = dist.get_backend(group) == "nccl"
+
+    def broadcast(self, t, src):
+        self.dist.broadcast(t, src=src, group=self.group)
+
+    def all_reduce_sum(self, t):
+        self.dist.all_reduce(t, group=self.group)
+
+    def all_reduce_max(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+
+    def all_gather(self, out, inp):
+        """out (size * len(inp)) <- concatenation of every rank's inp"""
+        if self.native_gather:
+            self.dist.all_gather_into_tensor(out, inp, group=self.group)
+        else:
+            n = inp.numel()
+            for r in range(self.size):
+                chunk = out[r * n:(r + 1) * n]
+                if r == self.rank:
+                    chunk.copy_(inp)
+                self.dist.broadcast(chunk, src=r, group=self.group)
+
+
+class SelfComm(object):
+    """World of one (lets the distributed code path run on a single GPU)."""
+    rank, size = 0, 1
+
+    def broadcast(self, t, src):
+        pass
+
+    def all_reduce_sum(self, t):
+        pass
+
+    def all_reduce_max(self, t):
+        pass
+
+    def all_gather(self, out, inp):
+        out[:inp.numel()].copy_(inp)
+
+
+class HipLocalOps(object):
+    """Local arithmetic of one rank on its GPU through the tgp_dd_* entry points."""
+
+    def __init__(self, ctx, spec, n, G, g, device):
+        import torch
+        from . import _lib
+        self.torch, self._lib, self.lib = torch, _lib, _lib.load_library()
+        self.ctx, self.spec, self.n, self.G, self.g, self.device = ctx, spec, int(n), int(G), int(g), device
+        self.Np = int(self.lib.tgp_padded_n(n))
+        self.nB = self.Np // BLK
+        self.loff = np.array([self.lib.tgp_dist_panel_off(p, self.Np, G, g) for p in range(self.nB + 1)], dtype=np.int64)
+        self.nloc = panel_blocks(0, self.nB, g, G)
+        self.cmax0 = -(-max(self.nB - 1, 0) // G)
+        slack = (self.cmax0 + 1) * BLK * BLK                   # the padded all-gather send view may overrun
+        self.A = torch.empty(int(self.loff[-1]) + slack, dtype=torch.float64, device=device)
+        self.W = torch.empty(self.Np * 128, dtype=torch.float64, device=device)
+        self.bcast = torch.empty(BCAST_ELEMS, dtype=torch.float64, device=device)
+        self.d_loff = torch.from_numpy(self.loff).to(device)
+        self.kc = spec.to_c()
+        self.lib.tgp_set_stream(ctx, C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+
+    def _chk(self, rc, what):
+        self._lib.check(self.ctx, rc, what)
+
+    def _p(self, t, off=0):
+        return C.c_void_p(t.data_ptr() + 8 * int(off))
+
+    def _hl(self):
+        return C.c_void_p(self.loff.ctypes.data)
+
+    def empty(self, n):
+        return self.torch.empty(n, dtype=self.torch.float64, device=self.device)
+
+    def zeros(self, n):
+        return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
+
+    def to_device(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+    # -- factorisation ---------------------------------------------------------------------------
+    def kbuild(self, dX, dyerr):
+        self._chk(self.lib.tgp_dd_kbuild(self.ctx, C.byref(self.kc), self._p(dX), self.n, self._p(dyerr), self._p(self.A),
+                                         self._p(self.d_loff), self.G, self.g), "tgp_dd_kbuild")
+
+    def factor_diag(self, k):
+        self._chk(self.lib.tgp_dd_factor_diag(self.ctx, self._p(self.A), self._hl(), self.Np, k, self.G, self.g,
+                                              self._p(self.W), self._p(self.bcast)), "tgp_dd_factor_diag")
+
+    def trsm(self, k):
+        self._chk(self.lib.tgp_dd_trsm(self.ctx, self._p(self.A), self._hl(), self.Np, k, self.G, self.g, self._p(self.W),
+                                       self._p(self.bcast)), "tgp_dd_trsm")
+
+    def panel_send_view(self, k, cmax):
+        skip = BLK if k % self.G == self.g else 0
+        o = int(self.loff[k]) + skip * BLK
+        return self.A[o:o + cmax * BLK * BLK]
+
+    def update(self, k, gathered, cmax):
+        self._chk(self.lib.tgp_dd_update(self.ctx, self._p(self.A), self._p(self.d_loff), self.Np, k, self.G, self.g,
+                                         self._p(gathered), cmax), "tgp_dd_update")
+
+    def info(self):
+        return int(self.lib.tgp_dd_info(self.ctx, 1))
+
+    # -- triangular solves -----------------------------------------------------------------------
+    def fwd_diag(self, k, yk):
+        self._chk(self.lib.tgp_dd_fwd_diag(self.ctx, self._p(self.A), self._hl(), k, self._p(self.W), self._p(yk)), "fwd_diag")
+
+    def fwd_update(self, k, zk, yloc):
+        self._chk(self.lib.tgp_dd_fwd_update(self.ctx, self._p(self.A), self._hl(), self.Np, k, self.G, self.g, self._p(zk),
+                                             self._p(yloc)), "fwd_update")
+
+    def bwd_partial(self, k, aloc, s):
+        self._chk(self.lib.tgp_dd_bwd_partial(self.ctx, self._p(self.A), self._hl(), self.Np, k, self.G, self.g,
+                                              self._p(aloc), self._p(s)), "bwd_partial")
+
+    def bwd_diag(self, k, ak):
+        self._chk(self.lib.tgp_dd_bwd_diag(self.ctx, self._p(self.A), self._hl(), k, self._p(self.W), self._p(ak)), "bwd_diag")
+
+    def logdet_local(self, out):
+        self._chk(self.lib.tgp_dd_logdet_local(self.ctx, self._p(self.A), self._p(self.d_loff), self.Np, self.n, self.G,
+                                               self.g, self._p(out)), "logdet_local")
+
+    def predict(self, dX, dalpha, dXs, m, dys):
+        self._chk(self.lib.tgp_d_gp_predict(self.ctx, C.byref(self.kc), self._p(dX), self.n, self._p(dalpha), self._p(dXs), m,
+                                            self._p(dys)), "tgp_d_gp_predict")
+
+
+class DistributedCholesky(object):
+    """Backend-agnostic orchestration: who owns what, what is communicated, in which order."""
+
+    def __init__(self, ops, comm, timer=None):
+        self.ops, self.comm = ops, comm
+        self.G, self.g = comm.size, comm.rank
+        assert (ops.G, ops.g) == (self.G, self.g)
+        self.nB, self.Np = ops.nB, ops.Np
+        self.gathered = ops.empty(max(self.G * ops.cmax0, 1) * BLK * BLK)
+        self.timer = timer            # optional callable(): returns an event-like with .record()/.elapsed_time()
+        self.update_ms = 0.0          # local trailing-update kernel time of the last factorize()
+        self.update_flops = 0.0       # algorithmic flops of this rank's share
+        self.update_launches = 0
+
+    def _local_update_flops(self, k):
+        """2 * 256 flops per lower-triangle element of this rank's block rows > k"""
+        elems = 0
+        b = first_ge(k + 1, self.g, self.G)
+        while b < self.nB:
+            elems += BLK * (b - k - 1) * BLK + BLK * (BLK + 1) // 2
+            b += self.G
+        return 2.0 * BLK * elems
+
+    def factorize(self):
+        ops, comm, G, g, nB = self.ops, self.comm, self.G, self.g, self.nB
+        events = []
+        self.update_flops, self.update_launches = 0.0, 0
+        for k in range(nB):
+            owner = k % G
+            if g == owner:
+                ops.factor_diag(k)
+            comm.broadcast(ops.bcast, owner)
+            ops.trsm(k)
+            rem = nB - k - 1
+            if rem == 0:
+                break
+            cmax = -(-rem // G)                                  # most blocks > k any rank holds
+            send = ops.panel_send_view(k, cmax)
+            comm.all_gather(self.gathered[:G * cmax * BLK * BLK], send)
+            if self.timer is not None:
+                e0, e1 = self.timer(), self.timer()
+                e0.record()
+                ops.update(k, self.gathered, cmax)
+                e1.record()
+                events.append((e0, e1))
+            else:
+                ops.update(k, self.gathered, cmax)
+            fl = self._local_update_flops(k)
+            if fl > 0:
+                self.update_flops += fl
+                self.update_launches += 1
+        # any rank's failure is everybody's failure; report the smallest failing index
+        big = 1e18
+        mine = ops.info()                                        # synchronises the stream
+        self.update_ms = sum(a.elapsed_time(b) for a, b in events) if events else 0.0
+        t = ops.zeros(1)
+        t[0] = -(float(mine) if mine > 0 else big)
+        comm.all_reduce_max(t)
+        first = -float(t[0])
+        return 0 if first >= big else int(first)
+
+    def solve(self, y_full):
+        """alpha (Np, replicated) = (L L^T)^-1 y; y_full is the replicated right-hand side (Np)."""
+        ops, comm, G, g, nB = self.ops, self.comm, self.G, self.g, self.nB
+        nloc = ops.nloc
+        yloc = ops.zeros(max(nloc, 1) * BLK)
+        for lb in range(nloc):
+            b = g + lb * G
+            yloc[lb * BLK:(lb + 1) * BLK].copy_(y_full[b * BLK:(b + 1) * BLK])
+        z = ops.zeros(self.Np)
+        zk = ops.zeros(BLK)
+        for k in range(nB):                                      # L z = y
+            owner = k % G
+            if g == owner:
+                lb = (k - g) // G
+                blk = yloc[lb * BLK:(lb + 1) * BLK]
+                ops.fwd_diag(k, blk)
+                zk.copy_(blk)
+            comm.broadcast(zk, owner)
+            z[k * BLK:(k + 1) * BLK].copy_(zk)
+            ops.fwd_update(k, zk, yloc)
+        aloc = ops.zeros(max(nloc, 1) * BLK)
+        s = ops.zeros(BLK)
+        for k in range(nB - 1, -1, -1):                          # L^T a = z
+            owner = k % G
+            ops.bwd_partial(k, aloc, s)
+            comm.all_reduce_sum(s)
+            if g == owner:
+                lb = (k - g) // G
+                ak = aloc[lb * BLK:(lb + 1) * BLK]
+                ak.copy_(z[k * BLK:(k + 1) * BLK] - s)
+                ops.bwd_diag(k, ak)
+        alpha = ops.zeros(self.Np)
+        for lb in range(nloc):
+            b = g + lb * G
+            alpha[b * BLK:(b + 1) * BLK].copy_(aloc[lb * BLK:(lb + 1) * BLK])
+        comm.all_reduce_sum(alpha)
+        return alpha
+
+    def logdet(self):
+        out = self.ops.zeros(1)
+        self.ops.logdet_local(out)
+        self.comm.all_reduce_sum(out)
+        return out
+
+
+class DistributedGP(object):
+    """bench.py's multi-GPU step: K build -> distributed Cholesky -> solves -> sharded predict,
+    inputs resident on every GPU."""
+
+    def __init__(self, ctx, spec, X, y, y_err, Xs, comm=None, device=None, profile=False):
+        import torch
+        self.torch = torch
+        self.profile = profile
+        if comm is None:
+            import torch.distributed as dist
+            comm = TorchComm() if dist.is_available() and dist.is_initialized() else SelfComm()
+        self.comm = comm
+        G, g = comm.size, comm.rank
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.n, self.m = len(y), len(Xs)
+        self.ops = HipLocalOps(ctx, spec, self.n, G, g, device)
+        timer = (lambda: torch.cuda.Event(enable_timing=True)) if profile else None
+        self.chol = DistributedCholesky(self.ops, comm, timer=timer)
+        o = self.ops
+        from ._lib import as_xy
+        self.dX = o.to_device(as_xy(X))
+        self.dyerr = o.to_device(y_err)
+        ypad = np.zeros(o.Np)
+        ypad[:self.n] = y
+        self.dy = o.to_device(ypad)
+        # prediction points: contiguous shards, the last one may be short
+        per = -(-self.m // G)
+        lo, hi = min(g * per, self.m), min((g + 1) * per, self.m)
+        self.shard = (lo, hi)
+        self.dXs = o.to_device(as_xy(Xs)[lo:hi]) if hi > lo else None
+        self.dys = o.zeros(max(hi - lo, 1))
+        self.alpha = None
+        self.logdet = None
+
+    def step(self, acc=None):
+        """One full pass; when `acc` is a dict and profiling is on, phase times (ms, this rank) and
+        the trailing-update roofline inputs are accumulated into it."""
+        o, torch = self.ops, self.torch
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if (self.profile and acc is not None) else None
+        if ev: ev[0].record()
+        o.kbuild(self.dX, self.dyerr)
+        if ev: ev[1].record()
+        info = self.chol.factorize()
+        if info != 0:
+            raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % info)
+        if ev: ev[2].record()
+        self.alpha = self.chol.solve(self.dy)
+        self.logdet = self.chol.logdet()
+        if ev: ev[3].record()
+        lo, hi = self.shard
+        if hi > lo:
+            o.predict(self.dX, self.alpha, self.dXs, hi - lo, self.dys)
+        if ev:
+            ev[4].record()
+            torch.cuda.synchronize()
+            for name, a, b in (("kbuild_ms", 0, 1), ("chol_ms", 1, 2), ("trsv_ms", 2, 3), ("predict_ms", 3, 4)):
+                acc[name] = acc.get(name, 0.0) + ev[a].elapsed_time(ev[b])
+            acc["syrk_ms"] = acc.get("syrk_ms", 0.0) + self.chol.update_ms
+            acc["syrk_flops"] = acc.get("syrk_flops", 0.0) + self.chol.update_flops
+            acc["syrk_launches"] = acc.get("syrk_launches", 0.0) + self.chol.update_launches
+        return self.alpha, self.dys
+
+    def gather_predictions(self):
+        """full (m,) prediction vector on every rank (tests)"""
+        per = -(-self.m // self.comm.size)
+        buf = self.ops.zeros(per * self.comm.size)
+        lo, hi = self.shard
+        mine = self.ops.zeros(per)
+        if hi > lo:
+            mine[:hi - lo].copy_(self.dys[:hi - lo])
+        self.comm.all_gather(buf, mine)
+        return buf[:self.m]
