@@ -16,6 +16,7 @@
 #include "tgp_internal.h"
 
 #include "gemm_tile.h"
+#include "potrf128.h"
 
 namespace {
 // a column of 128-row tiles: tile t uses A rows [128 t, +128), the fixed B block, C rows [128 t, +128)
@@ -26,21 +27,35 @@ __global__ __launch_bounds__(256, 2) void gemm_col_kernel(const double *A, const
 }
 
 // trailing update after panel kp: C(ti, tj) -= P_ti P_tj^T over the lower-triangular tile set
-__global__ __launch_bounds__(256, 2) void syrk_trailing_kernel(double *Abase, int64_t Np, int kpanel, int T) {
-    int ti, tj;
-    tilemap(blockIdx.x, T, ti, tj);
-    if (ti < 0) return;
+template <typename CFG, int STAGGER>
+__global__ __launch_bounds__(256, 2) void syrk_trailing_kernel(double *Abase, int64_t Np, int kpanel, int T,
+                                                               int64_t nvirt, unsigned long long *stamps = nullptr) {
+    // persistent when gridDim.x < nvirt: each workgroup walks the virtual block ids b, b + gridDim.x, ...
+    // (gridDim.x is a multiple of 8, so a workgroup keeps its XCD's share of the super-tiles)
     const double *P = Abase + panel_off(kpanel, Np) + (int64_t)TGP_PW * TGP_PW;   // rows below the diag block
-    const int64_t pj = kpanel + 1 + (tj >> 1);
-    const int64_t I = (int64_t)TGP_PW * (kpanel + 1) + (int64_t)TGP_TB * ti;
-    double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
-    gemm_tile_128<1, TGP_PW, TGP_PW>(P + (int64_t)ti * TGP_TB * TGP_PW, P + (int64_t)tj * TGP_TB * TGP_PW, C);
+    if constexpr (STAGGER > 0) {
+        if (blockIdx.x >= 256 && blockIdx.x < 512) {
+#pragma unroll 1
+            for (int i = 0; i < STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+#pragma unroll 1
+    for (int64_t vb = blockIdx.x; vb < nvirt; vb += gridDim.x) {
+        int ti, tj;
+        tilemap(vb, T, ti, tj);
+        if (ti < 0) continue;
+        const int64_t pj = kpanel + 1 + (tj >> 1);
+        const int64_t I = (int64_t)TGP_PW * (kpanel + 1) + (int64_t)TGP_TB * ti;
+        double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
+        gemm_tile_128<1, TGP_PW, TGP_PW, CFG>(P + (int64_t)ti * TGP_TB * TGP_PW, P + (int64_t)tj * TGP_TB * TGP_PW, C,
+                                              stamps ? stamps + 4 * vb : nullptr);
+    }
 }
 
-// 128x128 diagonal block: Cholesky factor written back in place (lower) and its inverse to W.
-// In-LDS Gauss-Jordan: after step j, columns <= j of T hold L^-1 rows, columns > j the Schur
+// First-generation 128x128 diagonal-block kernel (kept for A/B runs, TGP_POTRF_VARIANT=0; the
+// default is potrf_v2::potrf128_kernel in potrf128.h).  In-LDS Gauss-Jordan: after step j, columns <= j of T hold L^-1 rows, columns > j the Schur
 // complement; column j of L goes to global memory as soon as it is final.
-__global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, double *W, int *info, int base) {
+__global__ __launch_bounds__(256) void potrf128_lds_kernel(double *A, int lda, double *W, int *info, int base) {
     constexpr int TS = 129;
     __shared__ double T[128 * TS];
     __shared__ double lcol[128], vrow[128];
@@ -110,6 +125,12 @@ __global__ __launch_bounds__(256, 2) void syrk_dist_kernel(double *Aloc, const i
                 (gtj & 1) * TGP_TB;
     gemm_tile_128<1, TGP_PW, TGP_PW>(a, b, c);
 }
+
+inline void run_potrf128(hipStream_t st, double *A, int lda, double *W, int *info, int base) {
+    static const int variant = [] { const char *e = getenv("TGP_POTRF_VARIANT"); return e ? atoi(e) : 1; }();
+    if (variant == 0) potrf128_lds_kernel<<<1, 256, 0, st>>>(A, lda, W, info, base);
+    else potrf_v2::potrf128_kernel<<<1, 256, 0, st>>>(A, lda, W, info, base);
+}
 }  // namespace
 
 int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
@@ -127,6 +148,10 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
     }
     double flops = 0.0;
     int nlaunch = 0;
+    const char *sv = getenv("TGP_SYRK_VARIANT");
+    const int syrk_variant = sv ? atoi(sv) : 2;
+    const char *pv = getenv("TGP_SYRK_PERSIST");
+    const int persist = pv ? atoi(pv) : 0;          // workgroups of the persistent grid (0 = one per tile)
     for (int k = 0; k < nP; ++k) {
         double *Pk = d_A + panel_off(k, Np);
         const int64_t mk = Np - (int64_t)TGP_PW * k;
@@ -134,16 +159,51 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
         double *W1 = W0 + TGP_TB * TGP_TB;
         double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
         const int r1 = (int)((mk - TGP_TB) / TGP_TB);
-        potrf128_kernel<<<1, 256, 0, st>>>(Pk, TGP_PW, W0, ctx->d_info, (int)(k * TGP_PW));
+        run_potrf128(st, Pk, TGP_PW, W0, ctx->d_info, (int)(k * TGP_PW));
         gemm_col_kernel<0, TGP_TB><<<r1, 256, 0, st>>>(R1, W0, R1);
         gemm_col_kernel<1, TGP_PW><<<r1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
-        potrf128_kernel<<<1, 256, 0, st>>>(R1 + TGP_TB, TGP_PW, W1, ctx->d_info, (int)(k * TGP_PW + TGP_TB));
+        run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, ctx->d_info, (int)(k * TGP_PW + TGP_TB));
         const int r2 = (int)((mk - TGP_PW) / TGP_TB);
         if (r2 > 0) {
             double *R2 = Pk + (int64_t)TGP_PW * TGP_PW + TGP_TB;    // row 256, column 128
             gemm_col_kernel<0, TGP_TB><<<r2, 256, 0, st>>>(R2, W1, R2);
             if (prof) TGP_HIP(hipEventRecord(ctx->prof_events[2 * nlaunch], st));
-            syrk_trailing_kernel<<<(unsigned)tilemap_grid(r2), 256, 0, st>>>(d_A, Np, k, r2);
+            const int64_t nvirt = tilemap_grid(r2);
+            unsigned gs = (unsigned)nvirt;
+            if (persist > 0 && nvirt > persist) gs = (unsigned)persist;
+            switch (syrk_variant) {
+                case 0: syrk_trailing_kernel<TileCfg<18, false>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+                case 1: syrk_trailing_kernel<TileCfg<17, false>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+                case 2: syrk_trailing_kernel<TileCfg<17, true>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+                case 3: syrk_trailing_kernel<TileCfg<17, true>, 8><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+                case 4: syrk_trailing_kernel<TileCfg<17, true>, 4><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+                case 5: syrk_trailing_kernel<TileCfg<18, true>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+                case 18: syrk_trailing_kernel<TileCfg<17, true, 8>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+                case 19: syrk_trailing_kernel<TileCfg<17, true, 16>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+                case 20: syrk_trailing_kernel<TileCfg<17, true, 24>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+                case 11: syrk_trailing_kernel<TileCfg<17, true, 1>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+                case 12: syrk_trailing_kernel<TileCfg<17, true, 2>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+                case 16: syrk_trailing_kernel<TileCfg<17, true, 6>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+                case 17: syrk_trailing_kernel<TileCfg<17, true, 7>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+                case 30: {       // development: in-kernel stamps of the first (largest) launch
+                    static unsigned long long *d_st = nullptr;
+                    if (k == 0) {
+                        if (!d_st) (void)hipMalloc((void **)&d_st, (size_t)nvirt * 32);
+                        (void)hipMemsetAsync(d_st, 0, (size_t)nvirt * 32, st);
+                        syrk_trailing_kernel<TileCfg<17, true>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt, d_st);
+                        std::vector<unsigned long long> h((size_t)nvirt * 4);
+                        (void)hipMemcpyAsync(h.data(), d_st, (size_t)nvirt * 32, hipMemcpyDeviceToHost, st);
+                        (void)hipStreamSynchronize(st);
+                        double a = 0, b = 0, e = 0, rt = 0; long cnt = 0;
+                        for (int64_t i = 0; i < nvirt; ++i) if (h[4 * i + 1]) { a += h[4 * i]; b += h[4 * i + 1]; e += h[4 * i + 2]; rt += h[4 * i + 3]; ++cnt; }
+                        fprintf(stderr, "[stamps] tiles %ld  prologue %.0f  loop %.0f  epilogue %.0f cycles (mean); loop clock %.3f GHz\n",
+                                cnt, a / cnt, b / cnt, e / cnt, b / rt * 0.1);
+                    } else {
+                        syrk_trailing_kernel<TileCfg<17, true>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt);
+                    }
+                } break;
+                default: syrk_trailing_kernel<TileCfg<17, true>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+            }
             if (prof) TGP_HIP(hipEventRecord(ctx->prof_events[2 * nlaunch + 1], st));
             { const double m = (double)r2 * TGP_TB; flops += (double)TGP_PW * m * (m + 1.0); }   // algorithmic: lower triangle only
             ++nlaunch;
@@ -172,10 +232,10 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
 int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base) {
     hipStream_t st = ctx->stream;
     double *R1 = blk + (int64_t)TGP_TB * TGP_PW;
-    potrf128_kernel<<<1, 256, 0, st>>>(blk, TGP_PW, W0, ctx->d_info, base);
+    run_potrf128(st, blk, TGP_PW, W0, ctx->d_info, base);
     gemm_col_kernel<0, TGP_TB><<<1, 256, 0, st>>>(R1, W0, R1);
     gemm_col_kernel<1, TGP_PW><<<1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
-    potrf128_kernel<<<1, 256, 0, st>>>(R1 + TGP_TB, TGP_PW, W1, ctx->d_info, base + TGP_TB);
+    run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, ctx->d_info, base + TGP_TB);
     TGP_HIP(hipGetLastError());
     return 0;
 }

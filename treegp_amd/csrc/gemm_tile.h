@@ -12,13 +12,60 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int KB = 16;         // k-chunk depth
-constexpr int LS = KB + 2;     // LDS row stride in doubles
 
-// MODE 0: C = A B^T     MODE 1: C -= A B^T      (A: 128 x kdepth, B: 128 x kdepth, row-major)
+// Variant knobs (A/B-measured on MI355X):
+//   LSV   LDS row stride in doubles.  hipcc fuses the fragment reads of two k-steps into
+//         ds_read2_b64, whose banking is per 16-lane group with (addr/4) mod 32: an odd stride
+//         (17) is conflict-free there, the even stride 18 is 2-way.  Odd stride means 8-byte
+//         aligned rows, so staging stores are ds_write_b64 pairs.
+//   PRE   MODE 1 only: load C into the accumulators (negated) in the prologue, together with the
+//         first operand chunk (one memory latency), instead of a 4-round read-modify-write epilogue.
+template <int LSV, bool PRE, int DBGV = 0>
+struct TileCfg {
+    static constexpr int LS = LSV;
+    static constexpr bool PRELOAD = PRE;
+    static constexpr int DBG = DBGV;     // timing experiments only (wrong results): 1 no loop barrier,
+};                                       // 2 no loop global loads, 4 no loop LDS stores, 8 no C stores, 16 no C loads
+using TileDefault = TileCfg<17, true>;
+
+// buffer addressing (one wave-uniform 128-bit descriptor per operand, one 32-bit lane offset, the
+// row/column part of every access as a scalar offset): keeps the 64 C accesses and the staging
+// loads from each needing their own 64-bit address VGPR pair.
+using v2u = __attribute__((ext_vector_type(2))) unsigned;
+using v4u = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const double *p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ double buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ double2 buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st1(double x, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff, soff, 0);
+}
+
+template <int LS>
+__device__ __forceinline__ void lds_put2(double *p, const double2 &v) {
+    if constexpr ((LS & 1) == 0) {
+        *reinterpret_cast<double2 *>(p) = v;
+    } else {
+        p[0] = v.x;
+        p[1] = v.y;
+    }
+}
+
+// MODE 0: C = A B^T     MODE 1: C -= A B^T      (A: 128 x KDEPTH, B: 128 x KDEPTH, row-major)
 // A and C always live in 256-wide panels (ld 256); B is a panel (LDB 256) or a W block (LDB 128).
-template <int MODE, int LDB, int KDEPTH>
-__device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double *b_ptr, double *c_ptr) {
+template <int MODE, int LDB, int KDEPTH, typename CFG = TileDefault>
+__device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double *b_ptr, double *c_ptr,
+                                              unsigned long long *stamps = nullptr) {
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tr1 = 0, tr2 = 0;
+    if (stamps) ts0 = __builtin_amdgcn_s_memtime();
     constexpr int LDA = TGP_PW, LDC = TGP_PW;
+    constexpr int LS = CFG::LS;
+    constexpr bool PRELOAD = CFG::PRELOAD && MODE == 1;
     __shared__ __attribute__((aligned(16))) double lds[2][2][128 * LS];   // [buf][A|B][row*LS + k]
 
     const int tid = threadIdx.x;
@@ -30,41 +77,61 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
     // staging map: piece s of this thread = row (tid>>3) + 32 s, doubles kp..kp+1
     const int srow = tid >> 3;
     const int kp = (tid & 7) * 2;
-    const double *ga = a_ptr + srow * LDA + kp;
-    const double *gb = b_ptr + srow * LDB + kp;
+    const __amdgpu_buffer_rsrc_t ra_src = tile_rsrc(a_ptr, 128 * LDA * 8);
+    const __amdgpu_buffer_rsrc_t rb_src = tile_rsrc(b_ptr, 128 * LDB * 8);
+    const __amdgpu_buffer_rsrc_t rc_dst = tile_rsrc(c_ptr, 128 * LDC * 8);
+    const int va = (srow * LDA + kp) * 8, vb = (srow * LDB + kp) * 8;       // per-lane byte offsets
 
     double2 ra[4], rb[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        ra[s] = *reinterpret_cast<const double2 *>(ga + s * 32 * LDA);
-        rb[s] = *reinterpret_cast<const double2 *>(gb + s * 32 * LDB);
+        ra[s] = buf_ld2(ra_src, va, s * 32 * LDA * 8);
+        rb[s] = buf_ld2(rb_src, vb, s * 32 * LDB * 8);
     }
 
+    // C fragment map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 r
+    const int vc = ((wr * 64 + l4) * LDC + wc * 64 + l15) * 8;
     d4 acc[4][4];
+    if constexpr (PRELOAD && !(CFG::DBG & 16)) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[m][n][r] = buf_ld1(rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
 
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        *reinterpret_cast<double2 *>(&lds[0][0][(srow + 32 * s) * LS + kp]) = ra[s];
-        *reinterpret_cast<double2 *>(&lds[0][1][(srow + 32 * s) * LS + kp]) = rb[s];
+        lds_put2<LS>(&lds[0][0][(srow + 32 * s) * LS + kp], ra[s]);
+        lds_put2<LS>(&lds[0][1][(srow + 32 * s) * LS + kp], rb[s]);
     }
     __syncthreads();
+    if constexpr (PRELOAD) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = -acc[m][n];
+    }
 
+    if (stamps) { ts1 = __builtin_amdgcn_s_memtime(); tr1 = __builtin_amdgcn_s_memrealtime(); }
     constexpr int nchunk = KDEPTH / KB;
     const int fa = (wr * 64 + l15) * LS + l4;      // fragment read offsets
     const int fb = (wc * 64 + l15) * LS + l4;
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         const bool more = (c + 1 < nchunk);
-        if (more) {
+        if (more && !(CFG::DBG & 2)) {
             const int k0 = (c + 1) * KB;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                ra[s] = *reinterpret_cast<const double2 *>(ga + s * 32 * LDA + k0);
-                rb[s] = *reinterpret_cast<const double2 *>(gb + s * 32 * LDB + k0);
+                ra[s] = buf_ld2(ra_src, va, (s * 32 * LDA + k0) * 8);
+                rb[s] = buf_ld2(rb_src, vb, (s * 32 * LDB + k0) * 8);
             }
         }
         const double *As = lds[buf][0];
@@ -82,35 +149,56 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
                 for (int n = 0; n < 4; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
         }
-        if (more) {
+        // keep the staging stores (which wait for the global loads) and the barrier BEHIND the
+        // chunk's MFMAs: hipcc otherwise hoists them above two thirds of the MFMAs and every chunk
+        // stalls on memory latency
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && !(CFG::DBG & 4)) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                *reinterpret_cast<double2 *>(&lds[buf ^ 1][0][(srow + 32 * s) * LS + kp]) = ra[s];
-                *reinterpret_cast<double2 *>(&lds[buf ^ 1][1][(srow + 32 * s) * LS + kp]) = rb[s];
+                lds_put2<LS>(&lds[buf ^ 1][0][(srow + 32 * s) * LS + kp], ra[s]);
+                lds_put2<LS>(&lds[buf ^ 1][1][(srow + 32 * s) * LS + kp], rb[s]);
             }
         }
-        __syncthreads();
+        if constexpr (!(CFG::DBG & 1)) __syncthreads();
     }
 
-    // C fragment map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 r
-    double *cbase = c_ptr + (wr * 64 + l4) * LDC + wc * 64 + l15;
+    if (stamps) { ts2 = __builtin_amdgcn_s_memtime(); tr2 = __builtin_amdgcn_s_memrealtime(); }
+    if constexpr (CFG::DBG & 8) {
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+        if (s == 1.2345e-300) buf_st1(s, rc_dst, vc, 0);
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        if constexpr (MODE == 1) {
+        if constexpr (MODE == 1 && !PRELOAD) {
             double old[4][4];
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) old[n][r] = cbase[(m * 16 + 4 * r) * LDC + n * 16];
+                for (int r = 0; r < 4; ++r) old[n][r] = buf_ld1(rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cbase[(m * 16 + 4 * r) * LDC + n * 16] = old[n][r] - acc[m][n][r];
+                for (int r = 0; r < 4; ++r)
+                    buf_st1(old[n][r] - acc[m][n][r], rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
         } else {
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cbase[(m * 16 + 4 * r) * LDC + n * 16] = acc[m][n][r];
+                for (int r = 0; r < 4; ++r)
+                    buf_st1(PRELOAD ? -acc[m][n][r] : acc[m][n][r], rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
         }
+    }
+    if (stamps && threadIdx.x == 0) {
+        const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+        stamps[0] = ts1 - ts0;
+        stamps[1] = ts2 - ts1;
+        stamps[2] = ts3 - ts2;
+        stamps[3] = tr2 - tr1;
     }
 }

@@ -1,0 +1,181 @@
+// potrf128: Cholesky factor L (in place, lower) and W = L^-1 of one 128x128 diagonal block, one
+// workgroup of 4 waves, everything in LDS + registers.  This kernel is the serial critical path of
+// every panel (and, in the multi-GPU solve, of every rank), so it is built for latency:
+//
+//   phase 1, per 32-column block jb:
+//     wave 0   32x32 diagonal block in REGISTERS (lane i = row i): Gauss-Jordan elimination gives
+//              L_jj and D_j = L_jj^-1 in 32 steps with v_readlane broadcasts, no LDS, no barrier
+//     4 waves  rows below:   X = A D_j^T           (v_mfma_f64_16x16x4_f64, operands from LDS)
+//     4 waves  Schur update: T[r1:, r1:] -= X X^T  (lower 16x16 tiles)
+//   phase 2: blocked in-place inversion of the 4x4 block-lower matrix (W_ii = D_i,
+//            W_ij = -D_i sum_k L_ik W_kj), again 16x16x4 MFMA tiles from LDS.
+//
+// LDS image T: 128 rows x stride 130 doubles (MFMA fragment reads: lane (r, kq) -> slot
+// 130 r + kq, conflict-free per 32-lane group).  Explicit inverses only of well-conditioned
+// diagonal blocks: cond(L_block) <= sqrt(cond(K)).
+#pragma once
+#include "tgp_internal.h"
+
+namespace potrf_v2 {
+typedef double d4v __attribute__((ext_vector_type(4)));
+constexpr int TS = 130;
+
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// In-register Gauss-Jordan on a 32x32 SPD block: lane i holds row i in t[0..31].
+// On exit t[c] = (L^-1)[i][c] and ls[c] = L[i][c] for c <= i.  fail = first bad pivot or -1.
+__device__ __forceinline__ void gauss_jordan32(double (&t)[32], double (&ls)[32], const int i, int &fail) {
+#pragma clang loop unroll(full)
+    for (int j = 0; j < 32; ++j) {
+        const double pj = readlane_f64(t[j], j);
+        if (!(pj > 0.0) && fail < 0) fail = j;
+        const double d = sqrt(pj);
+        const double inv = 1.0 / d;
+        const double li = t[j] * inv;                       // L[i][j] for i > j
+        if (i == j) {                                       // row j of L^-1: scale the pivot row
+#pragma clang loop unroll(full)
+            for (int c = 0; c < j; ++c) t[c] *= inv;
+            t[j] = inv;
+        }
+        ls[j] = (i > j) ? li : ((i == j) ? d : 0.0);
+        if (i > j) {
+#pragma clang loop unroll(full)
+            for (int c = 0; c < 32; ++c) {
+                double vc;
+                if (c > j) vc = readlane_f64(li, c);        // L[c][j]
+                else if (c < j) vc = readlane_f64(t[c], j); // (L^-1)[j][c]
+                else vc = inv;
+                t[c] = ((c == j) ? 0.0 : t[c]) - li * vc;
+            }
+        }
+    }
+}
+
+// acc += A[ra.., ca..ca+31] (16 x 32) * B[rb.., cb..cb+31]^T (16 x 32), both row-major in T
+__device__ __forceinline__ d4v mma_nt32(const double *T, int ra, int ca, int rb, int cb, d4v acc, int l15, int l4) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const double a = T[(ra + l15) * TS + ca + 4 * ks + l4];
+        const double b = T[(rb + l15) * TS + cb + 4 * ks + l4];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+// acc += A[ra.., ca..ca+31] (16 x 32) * B[rb..rb+31, cb..] (32 x 16)
+__device__ __forceinline__ d4v mma_nn32(const double *T, int ra, int ca, int rb, int cb, d4v acc, int l15, int l4) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const double a = T[(ra + l15) * TS + ca + 4 * ks + l4];
+        const double b = T[(rb + 4 * ks + l4) * TS + cb + l15];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, double *W, int *info, int base) {
+    __shared__ double T[128 * TS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const d4v zero4 = {0.0, 0.0, 0.0, 0.0};
+
+    for (int idx = tid; idx < 128 * 64; idx += 256) {          // two columns per thread, coalesced rows
+        const int i = idx >> 6, c = (idx & 63) * 2;
+        const double2 v = *reinterpret_cast<const double2 *>(A + (int64_t)i * lda + c);
+        T[i * TS + c] = (c <= i) ? v.x : 0.0;
+        T[i * TS + c + 1] = (c + 1 <= i) ? v.y : 0.0;
+    }
+    __syncthreads();
+
+    // ---- phase 1: factorisation ---------------------------------------------------------------
+#pragma unroll 1
+    for (int jb = 0; jb < 4; ++jb) {
+        const int r0 = 32 * jb;
+        if (wave == 0 && lane < 32) {
+            const int i = lane;
+            double t[32], ls[32];
+#pragma clang loop unroll(full)
+            for (int c = 0; c < 32; ++c) t[c] = T[(r0 + i) * TS + r0 + c];
+            int fail = -1;
+            gauss_jordan32(t, ls, i, fail);
+            if (fail >= 0 && i == 0) atomicCAS(info, 0, base + r0 + fail + 1);
+#pragma clang loop unroll(full)
+            for (int c = 0; c < 32; ++c) {
+                T[(r0 + i) * TS + r0 + c] = (c <= i) ? t[c] : 0.0;                 // D_j replaces the block
+                if (c <= i) A[(int64_t)(r0 + i) * lda + r0 + c] = ls[c];           // L_jj is final
+            }
+        }
+        __syncthreads();
+        const int r1 = r0 + 32;
+        const int nr16 = (128 - r1) / 16;
+        // rows below: X = A_panel D_j^T, one 16-row strip (two 16x16 tiles) per wave at a time
+        for (int rt = wave; rt < nr16; rt += 4) {
+            const int rb = r1 + 16 * rt;
+            d4v x0 = zero4, x1 = zero4;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const double a = T[(rb + l15) * TS + r0 + 4 * ks + l4];
+                const double b0 = T[(r0 + l15) * TS + r0 + 4 * ks + l4];
+                const double b1 = T[(r0 + 16 + l15) * TS + r0 + 4 * ks + l4];
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, x1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                T[(rb + l4 + 4 * r) * TS + r0 + l15] = x0[r];
+                T[(rb + l4 + 4 * r) * TS + r0 + 16 + l15] = x1[r];
+            }
+        }
+        __syncthreads();
+        // Schur complement: lower 16x16 tiles of T[r1:, r1:] -= X X^T
+        const int ntile = nr16 * (nr16 + 1) / 2;
+        for (int tt = wave; tt < ntile; tt += 4) {
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= tt) ++ti;
+            const int tj = tt - ti * (ti + 1) / 2;
+            const d4v p = mma_nt32(T, r1 + 16 * ti, r0, r1 + 16 * tj, r0, zero4, l15, l4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(r1 + 16 * ti + l4 + 4 * r) * TS + r1 + 16 * tj + l15] -= p[r];
+        }
+        __syncthreads();
+    }
+
+    // off-diagonal blocks of L are final: write them out (diagonal blocks went out from registers)
+    for (int idx = tid; idx < 128 * 128; idx += 256) {
+        const int i = idx >> 7, c = idx & 127;
+        if ((c >> 5) < (i >> 5)) A[(int64_t)i * lda + c] = T[i * TS + c];
+    }
+    __syncthreads();
+
+    // ---- phase 2: W = L^-1 in place, block column by block column ----------------------------------
+    const int rt = wave >> 1, ct = wave & 1;           // this wave's 16x16 tile of a 32x32 block
+#pragma unroll 1
+    for (int cb = 0; cb < 3; ++cb) {
+#pragma unroll 1
+        for (int ib = cb + 1; ib < 4; ++ib) {
+            d4v s = zero4;
+            for (int kb = cb; kb < ib; ++kb)            // S = sum_k L_ik W_k,cb
+                s = mma_nn32(T, 32 * ib + 16 * rt, 32 * kb, 32 * kb, 32 * cb + 16 * ct, s, l15, l4);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(32 * ib + 16 * rt + l4 + 4 * r) * TS + 32 * cb + 16 * ct + l15] = s[r];
+            __syncthreads();
+            const d4v w = mma_nn32(T, 32 * ib + 16 * rt, 32 * ib, 32 * ib, 32 * cb + 16 * ct, zero4, l15, l4);   // D_i S
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(32 * ib + 16 * rt + l4 + 4 * r) * TS + 32 * cb + 16 * ct + l15] = -w[r];
+            __syncthreads();
+        }
+    }
+    for (int idx = tid; idx < 128 * 64; idx += 256) {
+        const int i = idx >> 6, c = (idx & 63) * 2;
+        double2 v;
+        v.x = (c <= i) ? T[i * TS + c] : 0.0;
+        v.y = (c + 1 <= i) ? T[i * TS + c + 1] : 0.0;
+        *reinterpret_cast<double2 *>(W + i * 128 + c) = v;
+    }
+}
+}  // namespace potrf_v2
