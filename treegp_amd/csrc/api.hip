@@ -44,6 +44,16 @@ int tgp_ensure_scratch(tgp_ctx *ctx, size_t bytes) {
     return 0;
 }
 
+int tgp_ensure_scratch2(tgp_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->scratch2_bytes) return 0;
+    if (ctx->scratch2) TGP_HIP(hipFree(ctx->scratch2));
+    ctx->scratch2 = nullptr;
+    ctx->scratch2_bytes = 0;
+    TGP_HIP(hipMalloc(&ctx->scratch2, bytes));
+    ctx->scratch2_bytes = bytes;
+    return 0;
+}
+
 static int ensure_io(tgp_ctx *ctx, size_t bytes) {
     Staging &s = ext_of(ctx)->io;
     if (bytes <= s.bytes) return 0;
@@ -108,6 +118,7 @@ void tgp_destroy(tgp_ctx *ctx) {
     if (e->A_cache) (void)hipFree(e->A_cache);
     if (e->W_cache) (void)hipFree(e->W_cache);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->h_info) (void)hipHostFree(ctx->h_info);
     if (ctx->d_scal) (void)hipFree(ctx->d_scal);

@@ -24,6 +24,8 @@ struct tgp_ctx {
     // grow-only scratch
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    void *scratch2 = nullptr;     // second, small scratch (partial sums) that may be live beside `scratch`
+    size_t scratch2_bytes = 0;
     int *d_info = nullptr;        // first failing pivot (1-based), 0 = ok
     int *h_info = nullptr;        // pinned mirror
     double *d_scal = nullptr;     // small device scalars (logdet, dot, ...)
@@ -102,6 +104,7 @@ __host__ __device__ inline void tilemap(int64_t b, int64_t T, int &ti, int &tj) 
 
 // implemented across the .hip files
 int tgp_ensure_scratch(tgp_ctx *ctx, size_t bytes);
+int tgp_ensure_scratch2(tgp_ctx *ctx, size_t bytes);
 int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,
                         const double *d_yerr, double *d_A);
 int launch_kernel_dense(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,
