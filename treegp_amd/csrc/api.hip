@@ -98,6 +98,11 @@ int tgp_init(const int *devices, int ndev, tgp_ctx **out) {
     if (hipSetDevice(ctx->device) != hipSuccess) { delete ctx; return -2; }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return -2; }
     ctx->stream = ctx->own_stream;
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi) != hipSuccess) { delete ctx; return -2; }
+    }
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_info, 256) != hipSuccess) { delete ctx; return -2; }
@@ -127,6 +132,7 @@ void tgp_destroy(tgp_ctx *ctx) {
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->prof_events) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     delete static_cast<tgp_ctx_full *>(ctx);
 }
 

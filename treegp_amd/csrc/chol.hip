@@ -26,30 +26,31 @@ __global__ __launch_bounds__(256, 2) void gemm_col_kernel(const double *A, const
     gemm_tile_128<MODE, LDB, TGP_TB>(A + t * 128 * TGP_PW, B, C + t * 128 * TGP_PW);
 }
 
-// trailing update after panel kp: C(ti, tj) -= P_ti P_tj^T over the lower-triangular tile set
-template <typename CFG, int STAGGER>
-__global__ __launch_bounds__(256, 2) void syrk_trailing_kernel(double *Abase, int64_t Np, int kpanel, int T,
-                                                               int64_t nvirt, unsigned long long *stamps = nullptr) {
-    // persistent when gridDim.x < nvirt: each workgroup walks the virtual block ids b, b + gridDim.x, ...
-    // (gridDim.x is a multiple of 8, so a workgroup keeps its XCD's share of the super-tiles)
-    const double *P = Abase + panel_off(kpanel, Np) + (int64_t)TGP_PW * TGP_PW;   // rows below the diag block
-    if constexpr (STAGGER > 0) {
-        if (blockIdx.x >= 256 && blockIdx.x < 512) {
-#pragma unroll 1
-            for (int i = 0; i < STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-        }
+// Trailing update C(ti, tj) -= sum over NSEG panels of P[ti] P[tj]^T on the lower-triangular tile set
+// of the trailing matrix that starts at block `ob` (256-row blocks).  P0 / P1 point at the row of
+// the factored panel(s) that corresponds to the first trailing row.
+//   strip == 0 : all tiles tj <= ti < T, XCD-aware super-tile enumeration (tilemap)
+//   strip  > 0 : only the first `strip` tile columns (the columns the next panels live in), so
+//                that their factorisation can start before the rest of the update has finished
+template <typename CFG, int NSEG>
+__global__ __launch_bounds__(256, 2) void syrk_trailing_kernel(double *Abase, int64_t Np, int ob, int T, int strip,
+                                                               const double *P0, const double *P1,
+                                                               unsigned long long *stamps = nullptr) {
+    int ti, tj;
+    if (strip == 0) {
+        tilemap(blockIdx.x, T, ti, tj);
+        if (ti < 0) return;
+    } else {
+        tj = (int)(blockIdx.x % strip);
+        ti = (int)(blockIdx.x / strip);
+        if (ti < tj || ti >= T) return;
     }
-#pragma unroll 1
-    for (int64_t vb = blockIdx.x; vb < nvirt; vb += gridDim.x) {
-        int ti, tj;
-        tilemap(vb, T, ti, tj);
-        if (ti < 0) continue;
-        const int64_t pj = kpanel + 1 + (tj >> 1);
-        const int64_t I = (int64_t)TGP_PW * (kpanel + 1) + (int64_t)TGP_TB * ti;
-        double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
-        gemm_tile_128<1, TGP_PW, TGP_PW, CFG>(P + (int64_t)ti * TGP_TB * TGP_PW, P + (int64_t)tj * TGP_TB * TGP_PW, C,
-                                              stamps ? stamps + 4 * vb : nullptr);
-    }
+    const int64_t pj = ob + (tj >> 1);
+    const int64_t I = (int64_t)TGP_PW * ob + (int64_t)TGP_TB * ti;
+    double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
+    const int64_t oa = (int64_t)ti * TGP_TB * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
+    gemm_tile_128<1, TGP_PW, TGP_PW, CFG, NSEG>(P0 + oa, P0 + obb, C, stamps ? stamps + 4 * blockIdx.x : nullptr,
+                                                NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
 }
 
 // First-generation 128x128 diagonal-block kernel (kept for A/B runs, TGP_POTRF_VARIANT=0; the
@@ -133,6 +134,39 @@ inline void run_potrf128(hipStream_t st, double *A, int lda, double *W, int *inf
 }
 }  // namespace
 
+namespace {
+// factor one 256-wide panel: the two 128x128 diagonal blocks (L + inverse) and the rows below them
+void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_info, int base) {
+    double *W1 = W0 + TGP_TB * TGP_TB;
+    double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
+    const int r1 = (int)((mk - TGP_TB) / TGP_TB);
+    run_potrf128(st, Pk, TGP_PW, W0, d_info, base);
+    gemm_col_kernel<0, TGP_TB><<<r1, 256, 0, st>>>(R1, W0, R1);
+    gemm_col_kernel<1, TGP_PW><<<r1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
+    run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, d_info, base + TGP_TB);
+    const int r2 = (int)((mk - TGP_PW) / TGP_TB);
+    if (r2 > 0) {
+        double *R2 = Pk + (int64_t)TGP_PW * TGP_PW + TGP_TB;    // row 256, column 128
+        gemm_col_kernel<0, TGP_TB><<<r2, 256, 0, st>>>(R2, W1, R2);
+    }
+}
+
+template <int NSEG>
+void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int strip, const double *P0, const double *P1,
+                 unsigned long long *stamps = nullptr) {
+    if (T <= 0) return;
+    const unsigned gs = strip == 0 ? (unsigned)tilemap_grid(T) : (unsigned)((int64_t)T * strip);
+    syrk_trailing_kernel<TileDefault, NSEG><<<gs, 256, 0, st>>>(d_A, Np, ob, T, strip, P0, P1, stamps);
+}
+}  // namespace
+
+// Right-looking factorisation.  Panels are taken in pairs so that the bulk of the trailing matrix is
+// updated once per 512 columns (half the C traffic and half the tile prologues of a depth-256
+// update):   F(k) -> U1: panel k+1 only, depth 256 -> F(k+1) -> U2: everything right of it, depth 512.
+// Default (TGP_CHOL_MODE=2) adds look-ahead: the update is split into the tile columns of the next pair
+// (U2a) and the rest (U2b), and the next pair is factored on a high-priority side stream under U2b.
+// TGP_CHOL_MODE=1: pairs without look-ahead; =0: plain depth-256 schedule (both kept for A/B runs:
+// N=65536 Cholesky 1694 / 1571 / 1551 ms for modes 0 / 1 / 2).
 int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
     TGP_ARG(Np > 0 && Np % TGP_PW == 0);
     hipStream_t st = ctx->stream;
@@ -146,67 +180,101 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
             ctx->prof_events.push_back(e);
         }
     }
+    static const int mode = [] { const char *e = getenv("TGP_CHOL_MODE"); return e ? atoi(e) : 2; }();
+    static const bool want_stamps = getenv("TGP_SYRK_STAMPS") != nullptr;      // development diagnostics
     double flops = 0.0;
     int nlaunch = 0;
-    const char *sv = getenv("TGP_SYRK_VARIANT");
-    const int syrk_variant = sv ? atoi(sv) : 2;
-    const char *pv = getenv("TGP_SYRK_PERSIST");
-    const int persist = pv ? atoi(pv) : 0;          // workgroups of the persistent grid (0 = one per tile)
-    for (int k = 0; k < nP; ++k) {
-        double *Pk = d_A + panel_off(k, Np);
-        const int64_t mk = Np - (int64_t)TGP_PW * k;
-        double *W0 = d_W + (int64_t)(2 * k) * TGP_TB * TGP_TB;
-        double *W1 = W0 + TGP_TB * TGP_TB;
-        double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
-        const int r1 = (int)((mk - TGP_TB) / TGP_TB);
-        run_potrf128(st, Pk, TGP_PW, W0, ctx->d_info, (int)(k * TGP_PW));
-        gemm_col_kernel<0, TGP_TB><<<r1, 256, 0, st>>>(R1, W0, R1);
-        gemm_col_kernel<1, TGP_PW><<<r1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
-        run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, ctx->d_info, (int)(k * TGP_PW + TGP_TB));
-        const int r2 = (int)((mk - TGP_PW) / TGP_TB);
-        if (r2 > 0) {
-            double *R2 = Pk + (int64_t)TGP_PW * TGP_PW + TGP_TB;    // row 256, column 128
-            gemm_col_kernel<0, TGP_TB><<<r2, 256, 0, st>>>(R2, W1, R2);
-            if (prof) TGP_HIP(hipEventRecord(ctx->prof_events[2 * nlaunch], st));
-            const int64_t nvirt = tilemap_grid(r2);
-            unsigned gs = (unsigned)nvirt;
-            if (persist > 0 && nvirt > persist) gs = (unsigned)persist;
-            switch (syrk_variant) {
-                case 0: syrk_trailing_kernel<TileCfg<18, false>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
-                case 1: syrk_trailing_kernel<TileCfg<17, false>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
-                case 2: syrk_trailing_kernel<TileCfg<17, true>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
-                case 3: syrk_trailing_kernel<TileCfg<17, true>, 8><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
-                case 4: syrk_trailing_kernel<TileCfg<17, true>, 4><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
-                case 5: syrk_trailing_kernel<TileCfg<18, true>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
-                case 18: syrk_trailing_kernel<TileCfg<17, true, 8>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
-                case 19: syrk_trailing_kernel<TileCfg<17, true, 16>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
-                case 20: syrk_trailing_kernel<TileCfg<17, true, 24>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
-                case 11: syrk_trailing_kernel<TileCfg<17, true, 1>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
-                case 12: syrk_trailing_kernel<TileCfg<17, true, 2>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
-                case 16: syrk_trailing_kernel<TileCfg<17, true, 6>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
-                case 17: syrk_trailing_kernel<TileCfg<17, true, 7>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
-                case 30: {       // development: in-kernel stamps of the first (largest) launch
-                    static unsigned long long *d_st = nullptr;
-                    if (k == 0) {
-                        if (!d_st) (void)hipMalloc((void **)&d_st, (size_t)nvirt * 32);
-                        (void)hipMemsetAsync(d_st, 0, (size_t)nvirt * 32, st);
-                        syrk_trailing_kernel<TileCfg<17, true>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt, d_st);
-                        std::vector<unsigned long long> h((size_t)nvirt * 4);
-                        (void)hipMemcpyAsync(h.data(), d_st, (size_t)nvirt * 32, hipMemcpyDeviceToHost, st);
-                        (void)hipStreamSynchronize(st);
-                        double a = 0, b = 0, e = 0, rt = 0; long cnt = 0;
-                        for (int64_t i = 0; i < nvirt; ++i) if (h[4 * i + 1]) { a += h[4 * i]; b += h[4 * i + 1]; e += h[4 * i + 2]; rt += h[4 * i + 3]; ++cnt; }
-                        fprintf(stderr, "[stamps] tiles %ld  prologue %.0f  loop %.0f  epilogue %.0f cycles (mean); loop clock %.3f GHz\n",
-                                cnt, a / cnt, b / cnt, e / cnt, b / rt * 0.1);
-                    } else {
-                        syrk_trailing_kernel<TileCfg<17, true>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt);
-                    }
-                } break;
-                default: syrk_trailing_kernel<TileCfg<17, true>, 0><<<gs, 256, 0, st>>>(d_A, Np, k, r2, nvirt); break;
+    auto timed = [&](auto &&fn, double fl) -> int {
+        if (prof) TGP_HIP(hipEventRecord(ctx->prof_events[2 * nlaunch], st));
+        fn();
+        if (prof) TGP_HIP(hipEventRecord(ctx->prof_events[2 * nlaunch + 1], st));
+        flops += fl;
+        ++nlaunch;
+        return 0;
+    };
+    auto Wk = [&](int k) { return d_W + (int64_t)(2 * k) * TGP_TB * TGP_TB; };
+    auto panel = [&](int k) { return d_A + panel_off(k, Np); };
+    if (mode == 0) {
+        for (int k = 0; k < nP; ++k) {
+            const int64_t mk = Np - (int64_t)TGP_PW * k;
+            factor_panel(st, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW);
+            const int T = (int)((mk - TGP_PW) / TGP_TB);
+            if (T > 0) {
+                const double m = (double)T * TGP_TB;
+                int rc = timed([&] { launch_syrk<1>(st, d_A, Np, k + 1, T, 0, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr); },
+                               (double)TGP_PW * m * (m + 1.0));
+                if (rc) return rc;
             }
-            if (prof) TGP_HIP(hipEventRecord(ctx->prof_events[2 * nlaunch + 1], st));
-            { const double m = (double)r2 * TGP_TB; flops += (double)TGP_PW * m * (m + 1.0); }   // algorithmic: lower triangle only
-            ++nlaunch;
+        }
+    } else if (mode == 2) {
+        // look-ahead: the update after pair (k, k+1) is split into the 4 tile columns the NEXT pair lives
+        // in (U2a) and the rest (U2b); the next pair is factored on a high-priority side stream while
+        // U2b keeps the chip busy.
+        hipStream_t sd = ctx->side_stream;
+        auto factor_pair = [&](hipStream_t s, int k) {       // F(k), U1(k), F(k+1)
+            const int64_t mk = Np - (int64_t)TGP_PW * k;
+            factor_panel(s, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW);
+            if (k + 1 >= nP) return;
+            const int T1 = (int)((mk - TGP_PW) / TGP_TB);
+            launch_syrk<1>(s, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
+            factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW);
+        };
+        factor_pair(st, 0);
+        for (int k = 0; k + 2 < nP; k += 2) {
+            const int T2 = (int)((Np - (int64_t)TGP_PW * (k + 2)) / TGP_TB);       // tiles from block k+2
+            const double *P0 = panel(k) + (int64_t)2 * TGP_PW * TGP_PW;
+            const double *P1 = panel(k + 1) + (int64_t)TGP_PW * TGP_PW;
+            {   // U2a: tile columns 0..3 (panels k+2, k+3)
+                const double rows = (double)T2 * TGP_TB, w = (T2 < 4 ? T2 : 4) * (double)TGP_TB;
+                const double elems = w * (rows - w) + w * (w + 1.0) / 2.0;
+                int rc = timed([&] { launch_syrk<2>(st, d_A, Np, k + 2, T2, 4, P0, P1); }, 2.0 * 2.0 * TGP_PW * elems);
+                if (rc) return rc;
+            }
+            TGP_HIP(hipEventRecord(ctx->ev[4], st));
+            TGP_HIP(hipStreamWaitEvent(sd, ctx->ev[4], 0));
+            factor_pair(sd, k + 2);
+            TGP_HIP(hipEventRecord(ctx->ev[5], sd));
+            const int T3 = T2 - 4;
+            if (T3 > 0) {   // U2b: everything from block k+4 on
+                const double m = (double)T3 * TGP_TB;
+                const int64_t skip = (int64_t)4 * TGP_TB * TGP_PW;
+                int rc = timed([&] { launch_syrk<2>(st, d_A, Np, k + 4, T3, 0, P0 + skip, P1 + skip); },
+                               2.0 * TGP_PW * m * (m + 1.0));
+                if (rc) return rc;
+            }
+            TGP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));
+        }
+    } else {
+        for (int k = 0; k < nP; k += 2) {
+            const int64_t mk = Np - (int64_t)TGP_PW * k;
+            factor_panel(st, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW);
+            if (k + 1 >= nP) break;
+            const int T1 = (int)((mk - TGP_PW) / TGP_TB);
+            // U1: only the two tile columns of panel k+1, depth 256 (short; not part of the timed set)
+            launch_syrk<1>(st, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
+            factor_panel(st, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW);
+            const int T2 = T1 - 2;
+            if (T2 > 0) {
+                const double m = (double)T2 * TGP_TB;
+                unsigned long long *d_st = nullptr;
+                if (want_stamps && k == 0) (void)hipMalloc((void **)&d_st, (size_t)tilemap_grid(T2) * 32);
+                if (d_st) (void)hipMemsetAsync(d_st, 0, (size_t)tilemap_grid(T2) * 32, st);
+                int rc = timed([&] { launch_syrk<2>(st, d_A, Np, k + 2, T2, 0, panel(k) + (int64_t)2 * TGP_PW * TGP_PW,
+                                                     panel(k + 1) + (int64_t)TGP_PW * TGP_PW, d_st); },
+                               2.0 * TGP_PW * m * (m + 1.0));
+                if (rc) return rc;
+                if (d_st) {
+                    const int64_t nv = tilemap_grid(T2);
+                    std::vector<unsigned long long> h((size_t)nv * 4);
+                    (void)hipMemcpyAsync(h.data(), d_st, (size_t)nv * 32, hipMemcpyDeviceToHost, st);
+                    (void)hipStreamSynchronize(st);
+                    double a = 0, b = 0, e = 0, rt = 0; long cnt = 0;
+                    for (int64_t i = 0; i < nv; ++i) if (h[4 * i + 1]) { a += h[4 * i]; b += h[4 * i + 1]; e += h[4 * i + 2]; rt += h[4 * i + 3]; ++cnt; }
+                    fprintf(stderr, "[stamps] tiles %ld  prologue %.0f  loop %.0f  epilogue %.0f cycles (mean); loop clock %.3f GHz\n",
+                            cnt, a / cnt, b / cnt, e / cnt, b / rt * 0.1);
+                    (void)hipFree(d_st);
+                }
+            }
         }
     }
     TGP_HIP(hipGetLastError());
@@ -226,7 +294,6 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
     }
     return *ctx->h_info;
 }
-
 
 // 256x256 diagonal block (ld 256): L in place, inverses of its two 128-blocks to W0 / W1
 int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base) {

@@ -58,9 +58,12 @@ __device__ __forceinline__ void lds_put2(double *p, const double2 &v) {
 
 // MODE 0: C = A B^T     MODE 1: C -= A B^T      (A: 128 x KDEPTH, B: 128 x KDEPTH, row-major)
 // A and C always live in 256-wide panels (ld 256); B is a panel (LDB 256) or a W block (LDB 128).
-template <int MODE, int LDB, int KDEPTH, typename CFG = TileDefault>
+// NSEG = 2: the contraction runs over two operand pairs back to back, C -= A0 B0^T + A1 B1^T (the
+// depth-512 trailing update after two factored panels), one chunk pipeline across both.
+template <int MODE, int LDB, int KDEPTH, typename CFG = TileDefault, int NSEG = 1>
 __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double *b_ptr, double *c_ptr,
-                                              unsigned long long *stamps = nullptr) {
+                                              unsigned long long *stamps = nullptr, const double *a1_ptr = nullptr,
+                                              const double *b1_ptr = nullptr) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tr1 = 0, tr2 = 0;
     if (stamps) ts0 = __builtin_amdgcn_s_memtime();
     constexpr int LDA = TGP_PW, LDC = TGP_PW;
@@ -79,6 +82,8 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
     const int kp = (tid & 7) * 2;
     const __amdgpu_buffer_rsrc_t ra_src = tile_rsrc(a_ptr, 128 * LDA * 8);
     const __amdgpu_buffer_rsrc_t rb_src = tile_rsrc(b_ptr, 128 * LDB * 8);
+    const __amdgpu_buffer_rsrc_t ra1_src = tile_rsrc(NSEG > 1 ? a1_ptr : a_ptr, 128 * LDA * 8);
+    const __amdgpu_buffer_rsrc_t rb1_src = tile_rsrc(NSEG > 1 ? b1_ptr : b_ptr, 128 * LDB * 8);
     const __amdgpu_buffer_rsrc_t rc_dst = tile_rsrc(c_ptr, 128 * LDC * 8);
     const int va = (srow * LDA + kp) * 8, vb = (srow * LDB + kp) * 8;       // per-lane byte offsets
 
@@ -120,18 +125,23 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
     }
 
     if (stamps) { ts1 = __builtin_amdgcn_s_memtime(); tr1 = __builtin_amdgcn_s_memrealtime(); }
-    constexpr int nchunk = KDEPTH / KB;
+    constexpr int cps = KDEPTH / KB;               // chunks per segment
+    constexpr int nchunk = NSEG * cps;
     const int fa = (wr * 64 + l15) * LS + l4;      // fragment read offsets
     const int fb = (wc * 64 + l15) * LS + l4;
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         const bool more = (c + 1 < nchunk);
         if (more && !(CFG::DBG & 2)) {
-            const int k0 = (c + 1) * KB;
+            const int cn = c + 1;
+            const int k0 = (NSEG > 1 ? (cn % cps) : cn) * KB;
+            const bool second = NSEG > 1 && cn >= cps;           // wave-uniform
+            const __amdgpu_buffer_rsrc_t sa = second ? ra1_src : ra_src;
+            const __amdgpu_buffer_rsrc_t sb = second ? rb1_src : rb_src;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                ra[s] = buf_ld2(ra_src, va, (s * 32 * LDA + k0) * 8);
-                rb[s] = buf_ld2(rb_src, vb, (s * 32 * LDB + k0) * 8);
+                ra[s] = buf_ld2(sa, va, (s * 32 * LDA + k0) * 8);
+                rb[s] = buf_ld2(sb, vb, (s * 32 * LDB + k0) * 8);
             }
         }
         const double *As = lds[buf][0];

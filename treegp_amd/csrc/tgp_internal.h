@@ -16,6 +16,7 @@ struct tgp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // the stream every kernel is launched on
     hipStream_t own_stream = nullptr;  // created by tgp_init
+    hipStream_t side_stream = nullptr; // high-priority stream for the Cholesky look-ahead
     bool ext_stream = false;           // stream was set by tgp_set_stream
     std::string err;
     double timings[TGP_NTIMINGS] = {0};
