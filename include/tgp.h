@@ -106,6 +106,12 @@ int tgp_kk_twod_bootstrap(tgp_ctx *ctx, const double *x, const double *y, const 
                           const double *yerr, int64_t n, const int64_t *idx, int64_t n_boot,
                           double min_sep, double max_sep, int nbins, double *xi_out);
 
+/* ---- mean function: uniform mean of the k nearest neighbours of each X in the table (X0, y0) -----
+ * replaces KNeighborsRegressor(n_neighbors=k).fit(X0, y0).predict(X) at treegp/gp_interp.py:236-238.
+ * k in 1..8 or 16.                                                                            */
+int tgp_knn_mean(tgp_ctx *ctx, const double *X0, const double *y0, int64_t n0, const double *X, int64_t m,
+                 int k, double *out);
+
 /* ---- device-resident tier (bench / multi-GPU): same maths, d_ pointers, ctx stream --------*/
 int tgp_dev_alloc(tgp_ctx *ctx, int64_t bytes, void **d_out);
 int tgp_dev_free(tgp_ctx *ctx, void *d_ptr);

@@ -335,3 +335,39 @@ def test_kk_bootstrap_vs_oracle_loop():
     sel = got[:, O.twod_mask(nb)]
     d = sel - sel.mean(axis=0)
     np.testing.assert_allclose(cov, d.T @ d / 4.0, rtol=1e-9, atol=1e-14)
+
+
+def test_knn_mean_vs_oracle(golden):
+    from oracle import gp_oracle as O
+    from treegp_amd import ops
+    g = golden("g6_meanify.npz")
+    rng = np.random.default_rng(2)
+    Xq = rng.uniform(0, 2048, (5000, 2))
+    for k in (1, 2, 4, 7, 8, 16):
+        np.testing.assert_allclose(ops.knn_mean(g["X0"], g["y0"], Xq, k), O.knn_mean(g["X0"], g["y0"], Xq, k), rtol=1e-13)
+    np.testing.assert_allclose(ops.knn_mean(g["X0"], g["y0"], g["X"], 4), g["spatial_average"], rtol=1e-13)
+
+
+def test_kk_edge_cases_vs_oracle():
+    """regular grids put many pairs exactly on pixel edges; duplicates give r == 0; tiny catalogues"""
+    from oracle import gp_oracle as O
+    from treegp_amd import ops
+    gx, gy = np.meshgrid(np.linspace(0, 1, 33), np.linspace(0, 1, 29))
+    x, y = gx.ravel(), gy.ravel()
+    x = np.concatenate([x, x[:40]]); y = np.concatenate([y, y[:40]])          # coincident points
+    rng = np.random.default_rng(9)
+    k = rng.standard_normal(len(x))
+    for nb, mn, mx in ((8, 0.0, 0.25), (21, 0.03125, 0.15625), (5, 0.0, 2.0)):
+        xi, wt, npairs = ops.kk_twod(x, y, k, None, mn, mx, nb)
+        xo, wo, no = O.kk_twod(x, y, k, None, mn, mx, nb)
+        assert np.array_equal(npairs, no)
+        np.testing.assert_allclose(xi, xo, rtol=1e-10, atol=1e-12 * np.abs(xo).max())
+    xi, wt, mr, mlr, npairs = ops.kk_log(x, y, k, None, 1 / 32, 0.5, 12)
+    xo, wo, ro, lo, no = O.kk_log(x, y, k, None, 1 / 32, 0.5, 12)
+    assert np.array_equal(npairs, no)
+    for n in (2, 3, 17):
+        xs, ys, ks = rng.uniform(0, 1, n), rng.uniform(0, 1, n), rng.standard_normal(n)
+        xi, wt, npairs = ops.kk_twod(xs, ys, ks, None, 0.0, 0.7, 5)
+        xo, wo, no = O.kk_twod(xs, ys, ks, None, 0.0, 0.7, 5)
+        assert np.array_equal(npairs, no)
+        np.testing.assert_allclose(xi, xo, rtol=1e-10, atol=1e-14)

@@ -42,6 +42,7 @@ SIGNATURES = {
     "tgp_kk_twod": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp]),
     "tgp_kk_log": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "tgp_kk_twod_bootstrap": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, C.c_double, C.c_double, C.c_int, _vp]),
+    "tgp_knn_mean": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, C.c_int, _vp]),
     "tgp_dev_alloc": (C.c_int, [_vp, _i64, C.POINTER(_vp)]),
     "tgp_dev_free": (C.c_int, [_vp, _vp]),
     "tgp_h2d": (C.c_int, [_vp, _vp, _vp, _i64]),

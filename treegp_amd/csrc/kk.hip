@@ -20,10 +20,11 @@ constexpr int MAXBL = 256;        // max log bins
 
 struct KKArgs {
     const double *x, *y, *v, *w;  // v: value before mean subtraction
-    const int64_t *idx;           // (n_boot, n) resample indices or nullptr
+    const int64_t *idx;           // (n_boot, n) point order: spatially sorted (resample) indices
     const double *mean;           // (n_boot) mean to subtract from v (nullptr: 0)
+    const double *bbox;           // (n_boot, ntile, 4) xmin, xmax, ymin, ymax of every 256-point tile
     int64_t n;
-    double min_sep, max_sep, bs, minsq, maxsq, lmin;
+    double min_sep, max_sep, bs, inv_bs, minsq, maxsq, lmin;
     int nbins, jchunks;
 };
 
@@ -32,6 +33,40 @@ __device__ __forceinline__ void lds_add(double *p, double v) {
 }
 __device__ __forceinline__ void glb_add(double *p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// int(x / bs) for x >= 0 exactly as the IEEE division + truncation gives it, without dividing unless
+// x sits within 1e-9 bin widths of a bin edge: q = x * (1/bs) can be off by an ulp or two, which only
+// matters at an edge; r = x - i*bs (one rounding, fma) tells how far from the edges x is.
+__device__ __forceinline__ int bin_of(double x, double bs, double inv_bs) {
+    int i = (int)(x * inv_bs);
+    const double r = fma(-(double)i, bs, x);
+    const double eps = 1e-9 * bs;
+    if (!(r > eps && r < bs - eps)) i = (int)(x / bs);
+    return i;
+}
+
+// x_i, y_i bounding boxes of the tiles (one workgroup per tile and resample)
+__global__ __launch_bounds__(256) void kk_bbox_kernel(KKArgs a, double *__restrict__ bbox) {
+    __shared__ double r[4][256];
+    const int tid = threadIdx.x;
+    const int64_t boot = blockIdx.y, tile = blockIdx.x;
+    const int64_t ntile = (a.n + KT - 1) / KT;
+    const int64_t i = tile * KT + tid;
+    double xv = 0, yv = 0;
+    const bool ok = i < a.n;
+    if (ok) { const int64_t s = a.idx[boot * a.n + i]; xv = a.x[s]; yv = a.y[s]; }
+    const double big = __builtin_huge_val();
+    r[0][tid] = ok ? xv : big; r[1][tid] = ok ? xv : -big; r[2][tid] = ok ? yv : big; r[3][tid] = ok ? yv : -big;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            r[0][tid] = fmin(r[0][tid], r[0][tid + o]); r[1][tid] = fmax(r[1][tid], r[1][tid + o]);
+            r[2][tid] = fmin(r[2][tid], r[2][tid + o]); r[3][tid] = fmax(r[3][tid], r[3][tid + o]);
+        }
+        __syncthreads();
+    }
+    if (tid < 4) bbox[(boot * ntile + tile) * 4 + tid] = r[tid][0];
 }
 
 // out layout: [boot][NACC][nb]   NACC = 3 (TwoD: wkk, w, n) or 5 (Log: wkk, w, wr, wlogr, n)
@@ -47,51 +82,59 @@ __global__ __launch_bounds__(256) void kk_pairs_kernel(KKArgs a, double *__restr
     for (int t = tid; t < 4 * NACC * nb; t += 256) hist[t] = 0.0;
 
     const int64_t boot = blockIdx.z;
-    const int64_t *idx = a.idx ? a.idx + boot * a.n : nullptr;
+    const int64_t *idx = a.idx + boot * a.n;
     const double mean = a.mean ? a.mean[boot] : 0.0;
     const int64_t ti = blockIdx.x;
     const int64_t ntile = (a.n + KT - 1) / KT;
+    const double *bb = a.bbox + boot * ntile * 4;
+    const double bxl = bb[ti * 4], bxh = bb[ti * 4 + 1], byl = bb[ti * 4 + 2], byh = bb[ti * 4 + 3];
     const int64_t i = ti * KT + tid;
     double xi = 0, yi = 0, ki = 0, wi = 0;
     const bool ivalid = i < a.n;
     if (ivalid) {
-        const int64_t s = idx ? idx[i] : i;
+        const int64_t s = idx[i];
         xi = a.x[s]; yi = a.y[s]; ki = a.v[s] - mean; wi = a.w ? a.w[s] : 1.0;
     }
-    // j tiles tj >= ti, dealt round-robin over gridDim.y chunks
+    // j tiles tj >= ti, dealt round-robin over gridDim.y chunks; tiles out of reach are skipped whole
     for (int64_t tj = ti + blockIdx.y; tj < ntile; tj += gridDim.y) {
+        {
+            const double gx = fmax(0.0, fmax(bb[tj * 4] - bxh, bxl - bb[tj * 4 + 1]));
+            const double gy = fmax(0.0, fmax(bb[tj * 4 + 2] - byh, byl - bb[tj * 4 + 3]));
+            if (TWOD ? (gx >= a.max_sep || gy >= a.max_sep) : (gx * gx + gy * gy >= a.maxsq)) continue;   // uniform
+        }
         __syncthreads();
         const int64_t j = tj * KT + tid;
         if (j < a.n) {
-            const int64_t s = idx ? idx[j] : j;
+            const int64_t s = idx[j];
             sx[tid] = a.x[s]; sy[tid] = a.y[s]; sk[tid] = a.v[s] - mean; sw[tid] = a.w ? a.w[s] : 1.0;
         }
         __syncthreads();
         const int cnt = (int)((a.n - tj * KT < KT) ? (a.n - tj * KT) : KT);
         const int t0 = (tj == ti) ? tid + 1 : 0;          // unordered pairs: j > i
         if (!ivalid) continue;
-        for (int t = (tj == ti ? 0 : 0); t < cnt; ++t) {
-            if (t < t0) continue;
+        for (int t = 0; t < cnt; ++t) {
             const double dx = sx[t] - xi, dy = sy[t] - yi;
             const double rsq = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
             if constexpr (TWOD) {
                 const double ad = fmax(fabs(dx), fabs(dy));
-                if (rsq != 0.0 && rsq >= a.minsq && ad < a.max_sep) {
+                if (t >= t0 && rsq != 0.0 && rsq >= a.minsq && ad < a.max_sep) {
                     const double ww = wi * sw[t];
                     const double wkk = ww * (ki * sk[t]);
-                    const int ix = (int)(__dadd_rn(dx, a.max_sep) / a.bs), iy = (int)(__dadd_rn(dy, a.max_sep) / a.bs);
+                    const int ix = bin_of(__dadd_rn(dx, a.max_sep), a.bs, a.inv_bs);
+                    const int iy = bin_of(__dadd_rn(dy, a.max_sep), a.bs, a.inv_bs);
                     if (ix >= 0 && ix < a.nbins && iy >= 0 && iy < a.nbins) {
                         const int b = iy * a.nbins + ix;
                         lds_add(myh + b, wkk); lds_add(myh + nb + b, ww); lds_add(myh + 2 * nb + b, 1.0);
                     }
-                    const int jx = (int)(__dadd_rn(-dx, a.max_sep) / a.bs), jy = (int)(__dadd_rn(-dy, a.max_sep) / a.bs);
+                    const int jx = bin_of(__dadd_rn(-dx, a.max_sep), a.bs, a.inv_bs);
+                    const int jy = bin_of(__dadd_rn(-dy, a.max_sep), a.bs, a.inv_bs);
                     if (jx >= 0 && jx < a.nbins && jy >= 0 && jy < a.nbins) {
                         const int b = jy * a.nbins + jx;
                         lds_add(myh + b, wkk); lds_add(myh + nb + b, ww); lds_add(myh + 2 * nb + b, 1.0);
                     }
                 }
             } else {
-                if (rsq >= a.minsq && rsq < a.maxsq) {
+                if (t >= t0 && rsq >= a.minsq && rsq < a.maxsq) {
                     const double lr = 0.5 * log(rsq);
                     const int b = (int)((lr - a.lmin) / a.bs);
                     if (b >= 0 && b < a.nbins) {
@@ -153,6 +196,38 @@ struct IoBuf {
 };
 }  // namespace
 
+// Z-order (Morton) key of every point on a 2^b x 2^b grid with ~32 points per cell, and the counting-sort
+// permutation of `src` (indices into the points) by that key.  Spatially compact 256-point tiles let
+// the pair kernel skip tile pairs that are farther apart than max_sep.
+static void morton_keys(const double *x, const double *y, int64_t n, std::vector<uint32_t> &key, int &nbuckets) {
+    double xl = x[0], xh = x[0], yl = y[0], yh = y[0];
+    for (int64_t i = 1; i < n; ++i) {
+        xl = x[i] < xl ? x[i] : xl; xh = x[i] > xh ? x[i] : xh;
+        yl = y[i] < yl ? y[i] : yl; yh = y[i] > yh ? y[i] : yh;
+    }
+    int b = 0;
+    while (b < 8 && ((int64_t)1 << (2 * (b + 1))) * 32 <= n) ++b;
+    const int nc = 1 << b;
+    nbuckets = nc * nc;
+    const double sxc = (xh > xl) ? nc / (xh - xl) : 0.0, syc = (yh > yl) ? nc / (yh - yl) : 0.0;
+    key.resize(n);
+    for (int64_t i = 0; i < n; ++i) {
+        int cx = (int)((x[i] - xl) * sxc), cy = (int)((y[i] - yl) * syc);
+        cx = cx < 0 ? 0 : (cx >= nc ? nc - 1 : cx);
+        cy = cy < 0 ? 0 : (cy >= nc ? nc - 1 : cy);
+        uint32_t k = 0;
+        for (int t = 0; t < b; ++t) k |= (uint32_t)((cx >> t) & 1) << (2 * t) | (uint32_t)((cy >> t) & 1) << (2 * t + 1);
+        key[i] = k;
+    }
+}
+static void counting_sort_row(const int64_t *src, int64_t n, const std::vector<uint32_t> &key, int nbuckets,
+                              std::vector<int64_t> &count, int64_t *dst) {
+    count.assign(nbuckets + 1, 0);
+    for (int64_t t = 0; t < n; ++t) ++count[key[src ? src[t] : t] + 1];
+    for (int k = 0; k < nbuckets; ++k) count[k + 1] += count[k];
+    for (int64_t t = 0; t < n; ++t) { const int64_t s = src ? src[t] : t; dst[count[key[s]]++] = s; }
+}
+
 static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, const double *v, const double *w_host,
                   const double *yerr_host, int64_t n, const int64_t *idx, int64_t n_boot, double min_sep,
                   double max_sep, int nbins, std::vector<double> &acc_host) {
@@ -165,7 +240,9 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
     const int nb = twod ? nbins * nbins : nbins;
     const size_t accb = (size_t)n_boot * nacc * nb * sizeof(double);
     auto rup = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t need = 4 * rup(n * 8) + rup(idx ? (size_t)n_boot * n * 8 : 8) + rup(n_boot * 8) + rup(accb);
+    const int64_t ntile0 = (n + KT - 1) / KT;
+    const size_t need = 4 * rup(n * 8) + rup((size_t)n_boot * n * 8) + rup(n_boot * 8) + rup(accb) +
+                        rup((size_t)n_boot * ntile0 * 4 * 8);
     int rc = tgp_ensure_scratch(ctx, need);
     if (rc) return rc;
     char *base = (char *)ctx->scratch;
@@ -173,9 +250,25 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
     auto take = [&](size_t b) { char *p = base + off; off += rup(b); return p; };
     double *d_x = (double *)take(n * 8), *d_y = (double *)take(n * 8), *d_v = (double *)take(n * 8),
            *d_w = (double *)take(n * 8);
-    int64_t *d_idx = (int64_t *)take(idx ? (size_t)n_boot * n * 8 : 8);
+    int64_t *d_idx = (int64_t *)take((size_t)n_boot * n * 8);
     double *d_mean = (double *)take(n_boot * 8);
     double *d_acc = (double *)take(accb);
+    double *d_bbox = (double *)take((size_t)n_boot * ntile0 * 4 * 8);
+    // spatial order of every catalogue (the base points, or each bootstrap resample)
+    std::vector<int64_t> sorted((size_t)n_boot * n);
+    if (twod) {
+        std::vector<uint32_t> key;
+        int nbuckets = 1;
+        morton_keys(x, y, n, key, nbuckets);
+        std::vector<int64_t> count;
+        for (int64_t b = 0; b < n_boot; ++b)
+            counting_sort_row(idx ? idx + b * n : nullptr, n, key, nbuckets, count, sorted.data() + b * n);
+    } else {
+        // log bins reach across most of the field: nothing to cull, and neighbouring i-points of a wave
+        // would hit the same bin for the same j (LDS-atomic serialisation), so keep the caller's order
+        for (int64_t b = 0; b < n_boot; ++b)
+            for (int64_t t = 0; t < n; ++t) sorted[b * n + t] = idx ? idx[b * n + t] : t;
+    }
 
     TGP_HIP(hipEventRecord(ctx->ev[0], st));
     TGP_HIP(hipMemcpyAsync(d_x, x, n * 8, hipMemcpyHostToDevice, st));
@@ -194,26 +287,27 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
             have_w = true;
         }
     }
-    if (idx) {
-        TGP_HIP(hipMemcpyAsync(d_idx, idx, (size_t)n_boot * n * 8, hipMemcpyHostToDevice, st));
-        boot_mean_kernel<<<(unsigned)n_boot, 256, 0, st>>>(d_v, d_idx, n, d_mean);
-    }
+    TGP_HIP(hipMemcpyAsync(d_idx, sorted.data(), (size_t)n_boot * n * 8, hipMemcpyHostToDevice, st));
+    if (idx) boot_mean_kernel<<<(unsigned)n_boot, 256, 0, st>>>(d_v, d_idx, n, d_mean);
     TGP_HIP(hipMemsetAsync(d_acc, 0, accb, st));
 
     KKArgs a;
     a.x = d_x; a.y = d_y; a.v = d_v; a.w = have_w ? d_w : nullptr;
-    a.idx = idx ? d_idx : nullptr;
+    a.idx = d_idx;
     a.mean = idx ? d_mean : nullptr;
+    a.bbox = d_bbox;
     a.n = n;
     a.min_sep = min_sep; a.max_sep = max_sep;
     a.minsq = min_sep * min_sep; a.maxsq = max_sep * max_sep;
     a.nbins = nbins;
     if (twod) { a.bs = 2.0 * max_sep / nbins; a.lmin = 0.0; }
     else { a.bs = log(max_sep / min_sep) / nbins; a.lmin = log(min_sep); }
+    a.inv_bs = 1.0 / a.bs;
     const int64_t ntile = (n + KT - 1) / KT;
-    // enough workgroups to fill the chip: split the j-tile loop when there are few i-tiles
-    int jch = (int)((4096 + ntile * n_boot - 1) / (ntile * n_boot));
-    if (jch < 1) jch = 1;
+    kk_bbox_kernel<<<dim3((unsigned)ntile, (unsigned)n_boot), 256, 0, st>>>(a, d_bbox);
+    // enough workgroups to fill the chip and to even out the triangular j range of the i-tiles
+    int jch = (int)((8192 + ntile * n_boot - 1) / (ntile * n_boot));
+    if (jch < 4) jch = 4;
     if (jch > ntile) jch = (int)ntile;
     a.jchunks = jch;
     const size_t shm = (size_t)(4 * KT + 4 * nacc * nb) * sizeof(double);

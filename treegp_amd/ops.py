@@ -147,6 +147,18 @@ def kk_twod_bootstrap(x, y, yv, y_err, idx, min_sep, max_sep, nbins, ctx=None):
     return out
 
 
+def knn_mean(X0, y0, X, k=4, ctx=None):
+    """Uniform mean of the k nearest table rows for every row of X (gp_interp.py:236-238)."""
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    X02, X2 = as_xy(X0), as_xy(X)
+    y0 = f64(y0)
+    out = np.empty(X2.shape[0])
+    rc = lib.tgp_knn_mean(ctx, ptr(X02), ptr(y0), X02.shape[0], ptr(X2), X2.shape[0], int(k), ptr(out))
+    check(ctx, rc, "tgp_knn_mean")
+    return out
+
+
 # ---- device-resident tier ---------------------------------------------------------------------
 class DeviceBuffer(object):
     def __init__(self, ctx, nbytes):
