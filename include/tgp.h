@@ -166,9 +166,11 @@ int tgp_dd_factor_diag(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int6
 /* every rank, after the broadcast of d_bcast: solve the local rows of panel kpanel */
 int tgp_dd_trsm(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int64_t Np, int kpanel, int G, int g,
                 double *d_W, const double *d_bcast);
-/* every rank, after the all-gather of the panel ([rank][cmax][256][256]): update the local block rows */
+/* every rank, after the all-gather of the panel ([rank][cmax][256][256]): update the local block rows,
+ * trailing 128-tile columns [col_lo, col_hi) only (col_hi < 0: to the end) -- the first two columns are
+ * the next panel, updated first so that its factorisation overlaps the rest (look-ahead)          */
 int tgp_dd_update(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
-                  const double *d_gathered, int cmax);
+                  const double *d_gathered, int cmax, int col_lo, int col_hi);
 /* block-row-cyclic triangular solves (scipy cho_solve, gp_interp.py:182) */
 int tgp_dd_fwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_yk);
 int tgp_dd_fwd_update(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int64_t Np, int kb, int G, int g,

@@ -48,6 +48,14 @@ class ThreadComm(object):
         self.sh.barrier.wait()
         t.copy_(tot)
 
+    def all_gather_start(self, out, inp):
+        self.all_gather(out, inp)
+
+        class _D(object):
+            def wait(self_inner):
+                pass
+        return _D()
+
     def all_gather(self, out, inp):
         vals = self._exchange(inp)
         n = inp.numel()
@@ -107,9 +115,12 @@ class NumpyLocalOps(object):
             out[i * BLK * BLK:(i + 1) * BLK * BLK] = torch.from_numpy(self.rows[b][:, k * BLK:(k + 1) * BLK].ravel())
         return out
 
-    def update(self, k, gathered, cmax):
+    def update(self, k, gathered, cmax, col_lo=0, col_hi=-1):
         G = self.G
         P = gathered.numpy()
+        ncol = 2 * (self.nB - k - 1)
+        if col_hi < 0 or col_hi > ncol:
+            col_hi = ncol
 
         def blk(b):
             r = b % G
@@ -121,7 +132,11 @@ class NumpyLocalOps(object):
                 continue
             Pi = blk(bi)
             for bj in range(k + 1, bi + 1):
-                self.rows[bi][:, bj * BLK:(bj + 1) * BLK] -= Pi @ blk(bj).T
+                for half in (0, 1):                       # 128-tile columns of block bj
+                    tcol = 2 * (bj - k - 1) + half
+                    if col_lo <= tcol < col_hi:
+                        c0 = bj * BLK + half * 128
+                        self.rows[bi][:, c0:c0 + 128] -= Pi @ blk(bj)[half * 128:(half + 1) * 128, :].T
 
     def info(self):
         i, self._info = self._info, 0

@@ -110,9 +110,9 @@ __global__ __launch_bounds__(256) void potrf128_lds_kernel(double *A, int lda, d
 // laid out [rank][cmax blocks][256][256]; blockIdx.y = local tile row among blocks > k,
 // blockIdx.x = trailing tile column (tiles right of the diagonal exit).
 __global__ __launch_bounds__(256, 2) void syrk_dist_kernel(double *Aloc, const int64_t *__restrict__ loff, int kpanel,
-                                                           int G, int g, int cmax, const double *P) {
+                                                           int G, int g, int cmax, const double *P, int col_lo) {
     const int lt = blockIdx.y;
-    const int64_t gtj = blockIdx.x;
+    const int64_t gtj = (int64_t)blockIdx.x + col_lo;
     const int64_t s0 = kpanel + 1;
     const int64_t bi = dist_first_ge(s0, g, G) + (int64_t)(lt >> 1) * G;
     const int64_t gti = 2 * (bi - s0) + (lt & 1);
@@ -319,13 +319,16 @@ int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, 
 }
 
 int launch_syrk_dist(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
-                     const double *d_P, int cmax) {
+                     const double *d_P, int cmax, int col_lo, int col_hi) {
     const int64_t nB = Np / TGP_PW;
     const int64_t nloc = dist_panel_blocks(kpanel + 1, nB, g, G);     // local blocks > k
-    const int64_t ncol = 2 * (nB - kpanel - 1);
+    const int64_t ncol_all = 2 * (nB - kpanel - 1);
+    if (col_hi < 0 || col_hi > ncol_all) col_hi = (int)ncol_all;
+    if (col_lo < 0) col_lo = 0;
+    const int64_t ncol = (int64_t)col_hi - col_lo;
     if (nloc <= 0 || ncol <= 0) return 0;
     dim3 grid((unsigned)ncol, (unsigned)(2 * nloc));
-    syrk_dist_kernel<<<grid, 256, 0, ctx->stream>>>(d_Aloc, d_loff, kpanel, G, g, cmax, d_P);
+    syrk_dist_kernel<<<grid, 256, 0, ctx->stream>>>(d_Aloc, d_loff, kpanel, G, g, cmax, d_P, col_lo);
     TGP_HIP(hipGetLastError());
     return 0;
 }

@@ -72,9 +72,9 @@ int tgp_dd_trsm(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int64_t Np,
 }
 
 int tgp_dd_update(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
-                  const double *d_gathered, int cmax) {
+                  const double *d_gathered, int cmax, int col_lo, int col_hi) {
     TGP_ARG(d_Aloc && d_loff && d_gathered && cmax >= 0);
-    return launch_syrk_dist(ctx, d_Aloc, d_loff, Np, kpanel, G, g, d_gathered, cmax);
+    return launch_syrk_dist(ctx, d_Aloc, d_loff, Np, kpanel, G, g, d_gathered, cmax, col_lo, col_hi);
 }
 
 // forward sweep, block kb (owner): y_k (256) <- L_kk^-1 y_k

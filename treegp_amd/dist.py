@@ -60,6 +60,14 @@ class TorchComm(object):
     def all_reduce_max(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
 
+    def all_gather_start(self, out, inp):
+        """Non-blocking all-gather where the backend has one (RCCL runs it on its own stream, so it
+        overlaps the kernels queued behind it); returns an object with .wait()."""
+        if self.native_gather:
+            return self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
+        self.all_gather(out, inp)
+        return _Done()
+
     def all_gather(self, out, inp):
         """out (size * len(inp)) <- concatenation of every rank's inp"""
         if self.native_gather:
@@ -73,9 +81,18 @@ class TorchComm(object):
                 self.dist.broadcast(chunk, src=r, group=self.group)
 
 
+class _Done(object):
+    def wait(self):
+        pass
+
+
 class SelfComm(object):
     """World of one (lets the distributed code path run on a single GPU)."""
     rank, size = 0, 1
+
+    def all_gather_start(self, out, inp):
+        self.all_gather(out, inp)
+        return _Done()
 
     def broadcast(self, t, src):
         pass
@@ -147,9 +164,9 @@ class HipLocalOps(object):
         o = int(self.loff[k]) + skip * BLK
         return self.A[o:o + cmax * BLK * BLK]
 
-    def update(self, k, gathered, cmax):
+    def update(self, k, gathered, cmax, col_lo=0, col_hi=-1):
         self._chk(self.lib.tgp_dd_update(self.ctx, self._p(self.A), self._p(self.d_loff), self.Np, k, self.G, self.g,
-                                         self._p(gathered), cmax), "tgp_dd_update")
+                                         self._p(gathered), cmax, col_lo, col_hi), "tgp_dd_update")
 
     def info(self):
         return int(self.lib.tgp_dd_info(self.ctx, 1))
@@ -187,6 +204,7 @@ class DistributedCholesky(object):
         assert (ops.G, ops.g) == (self.G, self.g)
         self.nB, self.Np = ops.nB, ops.Np
         self.gathered = ops.empty(max(self.G * ops.cmax0, 1) * BLK * BLK)
+        self.gathered2 = ops.empty(max(self.G * ops.cmax0, 1) * BLK * BLK)    # look-ahead double buffer
         self.timer = timer            # optional callable(): returns an event-like with .record()/.elapsed_time()
         self.update_ms = 0.0          # local trailing-update kernel time of the last factorize()
         self.update_flops = 0.0       # algorithmic flops of this rank's share
@@ -202,10 +220,16 @@ class DistributedCholesky(object):
         return 2.0 * BLK * elems
 
     def factorize(self):
+        """Right-looking factorisation with look-ahead: the two tile columns of panel k+1 are updated
+        first, panel k+1 is factored / solved and its all-gather is started, and only then is the rest
+        of update k launched, so the collective (RCCL, own stream) runs under the large update."""
         ops, comm, G, g, nB = self.ops, self.comm, self.G, self.g, self.nB
         events = []
         self.update_flops, self.update_launches = 0.0, 0
-        for k in range(nB):
+        bufs = [self.gathered, self.gathered2]
+
+        def factor_and_gather(k, buf):
+            """panel k: diagonal block on its owner, broadcast, local solves, start the all-gather"""
             owner = k % G
             if g == owner:
                 ops.factor_diag(k)
@@ -213,22 +237,33 @@ class DistributedCholesky(object):
             ops.trsm(k)
             rem = nB - k - 1
             if rem == 0:
-                break
+                return None, 0
             cmax = -(-rem // G)                                  # most blocks > k any rank holds
             send = ops.panel_send_view(k, cmax)
-            comm.all_gather(self.gathered[:G * cmax * BLK * BLK], send)
+            return comm.all_gather_start(buf[:G * cmax * BLK * BLK], send), cmax
+
+        def timed_update(k, buf, cmax, lo, hi):
             if self.timer is not None:
                 e0, e1 = self.timer(), self.timer()
                 e0.record()
-                ops.update(k, self.gathered, cmax)
+                ops.update(k, buf, cmax, lo, hi)
                 e1.record()
                 events.append((e0, e1))
             else:
-                ops.update(k, self.gathered, cmax)
+                ops.update(k, buf, cmax, lo, hi)
+
+        work, cmax = factor_and_gather(0, bufs[0])
+        for k in range(nB - 1):
+            cur = bufs[k & 1]
+            work.wait()                                          # panel k is on every rank
+            ops.update(k, cur, cmax, 0, 2)                       # columns of panel k+1 first
+            nwork, ncmax = factor_and_gather(k + 1, bufs[(k + 1) & 1])
+            timed_update(k, cur, cmax, 2, -1)                    # the bulk, overlapping the gather of k+1
             fl = self._local_update_flops(k)
             if fl > 0:
                 self.update_flops += fl
                 self.update_launches += 1
+            work, cmax = nwork, ncmax
         # any rank's failure is everybody's failure; report the smallest failing index
         big = 1e18
         mine = ops.info()                                        # synchronises the stream
