@@ -68,3 +68,36 @@ def test_config3_size_vonkarman_residual():
     yp = ops.gp_predict(spec, X, alpha, Xs)
     ref = O.gp_predict(O.kernel_matrix("vk", Xs, X, amp=1.0, ell=0.1), alpha)
     np.testing.assert_allclose(yp, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+
+
+def test_config5_size_meanify_yerr():
+    """configs[4] shape on one GPU: N=131 072 with a mean-function table (KNN-4) and a y_err diagonal,
+    through the treegp-compatible API; residual on the device + 2048 predictions against the oracle."""
+    from oracle import gp_oracle as O
+    import treegp_amd as treegp
+    from treegp_amd import ops
+    from treegp_amd.synthetic import star_field, headline_invlam
+    n, m = 131072, 2048
+    X, y, y_err, Xs = star_field(n, m)
+    # SURVEY 8(d): X0 = 50x50 grid of bin centres on the unit square, y0 = 0.02 + 0.2((u-.5)^2+(v-.5)^2)
+    g = (np.arange(50) + 0.5) / 50
+    U, V = np.meshgrid(g, g)
+    X0 = np.array([U.ravel(), V.ravel()]).T
+    y0 = 0.02 + 0.2 * ((X0[:, 0] - 0.5) ** 2 + (X0[:, 1] - 0.5) ** 2)
+    y = y + O.knn_mean(X0, y0, X, 4)
+    iL = headline_invlam()
+    gp = treegp.GPInterpolation(kernel="1.0**2 * AnisotropicRBF(invLam={0!r})".format(iL), optimizer="none",
+                                normalize=True, n_neighbors=4)
+    gp._X0, gp._y0 = X0, y0                      # what average_fits= would have loaded
+    gp.initialize(X, y, y_err=y_err)
+    np.testing.assert_allclose(gp._spatial_average, O.knn_mean(X0, y0, X, 4), rtol=1e-13)
+    yp = gp.predict(Xs)
+    spec = treegp.kernel_to_spec(gp.kernel)
+    alpha = gp._alpha
+    rhs = y - gp._mean - gp._spatial_average
+    Ka = ops.gp_predict(spec, X, alpha, X)
+    rel = np.linalg.norm(Ka + y_err ** 2 * alpha - rhs) / np.linalg.norm(rhs)
+    assert rel < 1e-10, rel
+    kw = dict(amp=spec.amp, a=spec.a, b=spec.b, c=spec.c)
+    ref = O.gp_predict(O.kernel_matrix("gauss", Xs, X, **kw), alpha) + gp._mean + O.knn_mean(X0, y0, Xs, 4)
+    np.testing.assert_allclose(yp, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
