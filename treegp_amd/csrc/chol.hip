@@ -1,18 +1,16 @@
 // Blocked right-looking fp64 Cholesky on the packed lower panels (seam S2 of include/tgp.h;
 // replaces scipy.linalg.cholesky at treegp/gp_interp.py:181 and log_likelihood.py:30).
 //
-// Per 256-wide panel k (two 128-column halves):
-//   potrf128  diag block 0     one workgroup, in-LDS Gauss-Jordan: L11 in place + W11 = L11^-1
+// F(k), factor one 256-wide panel (two 128-column halves):
+//   potrf128  diag block 0     one workgroup: L11 in place + W11 = L11^-1          (potrf128.h)
 //   gemm<0>   rows below       X = A W11^T            (triangular solve as a GEMM, in place)
 //   gemm<1>   column half 1    A[:,128:256] -= X X_d^T (depth 128)
 //   potrf128  diag block 1     L22, W22
 //   gemm<0>   rows below       X = A W22^T
-//   syrk      trailing matrix  C -= P P^T, depth 256, on v_mfma_f64_16x16x4_f64   <- N^3/3 flops
-// All GEMMs are the same NT tile: 128x128 per workgroup of 4 waves (2x2, 64x64 per wave =
-// 4x4 MFMA tiles, 128 accumulator VGPRs), operands staged through LDS in 16-deep k-chunks
-// (row stride 18 doubles -> conflict-free ds_read_b64 fragment reads), double-buffered with
-// the next chunk's global loads in flight during the MFMAs; two workgroups per CU so one
-// workgroup's C prologue/epilogue hides behind the other's MFMAs.
+// Schedule (launch_potrf): panels in pairs, F(k) -> U1 (panel k+1 only, depth 256) -> F(k+1) ->
+// U2 (everything to the right, depth 512, <- N^3/3 flops), with U2 split so that the next pair is
+// factored on a priority side stream underneath it.
+// All GEMMs are the NT tile of gemm_tile.h on v_mfma_f64_16x16x4_f64; two workgroups per CU.
 #include "tgp_internal.h"
 
 #include "gemm_tile.h"

@@ -20,12 +20,11 @@ constexpr int KB = 16;         // k-chunk depth
 //         aligned rows, so staging stores are ds_write_b64 pairs.
 //   PRE   MODE 1 only: load C into the accumulators (negated) in the prologue, together with the
 //         first operand chunk (one memory latency), instead of a 4-round read-modify-write epilogue.
-template <int LSV, bool PRE, int DBGV = 0>
+template <int LSV, bool PRE>
 struct TileCfg {
     static constexpr int LS = LSV;
     static constexpr bool PRELOAD = PRE;
-    static constexpr int DBG = DBGV;     // timing experiments only (wrong results): 1 no loop barrier,
-};                                       // 2 no loop global loads, 4 no loop LDS stores, 8 no C stores, 16 no C loads
+};
 using TileDefault = TileCfg<17, true>;
 
 // buffer addressing (one wave-uniform 128-bit descriptor per operand, one 32-bit lane offset, the
@@ -97,7 +96,7 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
     // C fragment map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 r
     const int vc = ((wr * 64 + l4) * LDC + wc * 64 + l15) * 8;
     d4 acc[4][4];
-    if constexpr (PRELOAD && !(CFG::DBG & 16)) {
+    if constexpr (PRELOAD) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -132,7 +131,7 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         const bool more = (c + 1 < nchunk);
-        if (more && !(CFG::DBG & 2)) {
+        if (more) {
             const int cn = c + 1;
             const int k0 = (NSEG > 1 ? (cn % cps) : cn) * KB;
             const bool second = NSEG > 1 && cn >= cps;           // wave-uniform
@@ -163,26 +162,17 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
         // chunk's MFMAs: hipcc otherwise hoists them above two thirds of the MFMAs and every chunk
         // stalls on memory latency
         __builtin_amdgcn_sched_barrier(0);
-        if (more && !(CFG::DBG & 4)) {
+        if (more) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 lds_put2<LS>(&lds[buf ^ 1][0][(srow + 32 * s) * LS + kp], ra[s]);
                 lds_put2<LS>(&lds[buf ^ 1][1][(srow + 32 * s) * LS + kp], rb[s]);
             }
         }
-        if constexpr (!(CFG::DBG & 1)) __syncthreads();
+        __syncthreads();
     }
 
     if (stamps) { ts2 = __builtin_amdgcn_s_memtime(); tr2 = __builtin_amdgcn_s_memrealtime(); }
-    if constexpr (CFG::DBG & 8) {
-        double s = 0.0;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
-        if (s == 1.2345e-300) buf_st1(s, rc_dst, vc, 0);
-        return;
-    }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         if constexpr (MODE == 1 && !PRELOAD) {
