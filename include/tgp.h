@@ -177,7 +177,8 @@ int tgp_dd_fwd_update(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff,
                       const double *d_zk, double *d_yloc);
 int tgp_dd_bwd_partial(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int64_t Np, int kb, int G, int g,
                        const double *d_aloc, double *d_s);
-int tgp_dd_bwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_ak);
+int tgp_dd_bwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_ak,
+                    const double *d_s /* subtracted from a_k first; may be NULL */);
 int tgp_dd_logdet_local(tgp_ctx *ctx, const double *d_Aloc, const int64_t *d_loff, int64_t Np, int64_t n, int G, int g,
                         double *d_out);
 int tgp_dd_info(tgp_ctx *ctx, int reset);                /* first non-PD pivot since the last reset */

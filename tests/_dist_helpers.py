@@ -159,9 +159,10 @@ class NumpyLocalOps(object):
                 acc += self.rows[b][:, k * BLK:(k + 1) * BLK].T @ aloc[lb * BLK:(lb + 1) * BLK].numpy()
         s.copy_(torch.from_numpy(acc))
 
-    def bwd_diag(self, k, ak):
+    def bwd_diag(self, k, ak, s=None):
         L = np.tril(self.rows[k][:, k * BLK:(k + 1) * BLK])
-        ak.copy_(torch.from_numpy(np.linalg.solve(L.T, ak.numpy())))
+        rhs = ak.numpy() - (0 if s is None else s.numpy())
+        ak.copy_(torch.from_numpy(np.linalg.solve(L.T, rhs)))
 
     def logdet_local(self, out):
         s = 0.0

@@ -72,7 +72,7 @@ SIGNATURES = {
     "tgp_dd_fwd_diag": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "tgp_dd_fwd_update": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "tgp_dd_bwd_partial": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
-    "tgp_dd_bwd_diag": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "tgp_dd_bwd_diag": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "tgp_dd_logdet_local": (C.c_int, [_vp, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp]),
     "tgp_dd_info": (C.c_int, [_vp, C.c_int]),
 }

@@ -101,10 +101,11 @@ int tgp_dd_bwd_partial(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff
     const int64_t lb0 = (below > 0) ? (dist_first_ge(kb + 1, g, G) - g) / G : 0;
     return launch_gemv_t_rows(ctx, d_Aloc + h_loff[kb] + skip * TGP_PW, below * TGP_PW, d_aloc + lb0 * TGP_PW, d_s);
 }
-// backward sweep, block kb (owner): a_k (256) <- L_kk^-T a_k
-int tgp_dd_bwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_ak) {
+// backward sweep, block kb (owner): a_k (256) <- L_kk^-T (a_k - s)   (d_s may be NULL)
+int tgp_dd_bwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_ak,
+                    const double *d_s) {
     const double *W0 = d_W + (int64_t)(2 * kb) * TGP_TB * TGP_TB;
-    return launch_diag256_bwd(ctx, d_Aloc + h_loff[kb], W0, W0 + TGP_TB * TGP_TB, d_ak);
+    return launch_diag256_bwd(ctx, d_Aloc + h_loff[kb], W0, W0 + TGP_TB * TGP_TB, d_ak, d_s);
 }
 
 int tgp_dd_logdet_local(tgp_ctx *ctx, const double *d_Aloc, const int64_t *d_loff, int64_t Np, int64_t n, int G, int g,

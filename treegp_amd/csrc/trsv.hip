@@ -353,8 +353,8 @@ int launch_diag256_fwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const 
     return 0;
 }
 // y (256) <- L_kk^-T y
-int launch_diag256_bwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y) {
-    diag256_bwd_kernel<<<1, 256, 0, ctx->stream>>>(Lkk, W0, W1, y, nullptr, 0);
+int launch_diag256_bwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y, const double *s) {
+    diag256_bwd_kernel<<<1, 256, 0, ctx->stream>>>(Lkk, W0, W1, y, s, s ? 1 : 0);
     TGP_HIP(hipGetLastError());
     return 0;
 }

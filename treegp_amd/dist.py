@@ -183,8 +183,9 @@ class HipLocalOps(object):
         self._chk(self.lib.tgp_dd_bwd_partial(self.ctx, self._p(self.A), self._hl(), self.Np, k, self.G, self.g,
                                               self._p(aloc), self._p(s)), "bwd_partial")
 
-    def bwd_diag(self, k, ak):
-        self._chk(self.lib.tgp_dd_bwd_diag(self.ctx, self._p(self.A), self._hl(), k, self._p(self.W), self._p(ak)), "bwd_diag")
+    def bwd_diag(self, k, ak, s=None):
+        self._chk(self.lib.tgp_dd_bwd_diag(self.ctx, self._p(self.A), self._hl(), k, self._p(self.W), self._p(ak),
+                                           None if s is None else self._p(s)), "bwd_diag")
 
     def logdet_local(self, out):
         self._chk(self.lib.tgp_dd_logdet_local(self.ctx, self._p(self.A), self._p(self.d_loff), self.Np, self.n, self.G,
@@ -275,40 +276,40 @@ class DistributedCholesky(object):
         return 0 if first >= big else int(first)
 
     def solve(self, y_full):
-        """alpha (Np, replicated) = (L L^T)^-1 y; y_full is the replicated right-hand side (Np)."""
+        """alpha (Np, replicated) = (L L^T)^-1 y; y_full is the replicated right-hand side (Np).
+        Forward: the owner of block k solves its diagonal block in place in z and broadcasts the 2 KB
+        result; every rank then updates its own rows.  Backward: every rank contributes the partial
+        sum of its rows, one 2 KB all-reduce, the owner finishes the block."""
         ops, comm, G, g, nB = self.ops, self.comm, self.G, self.g, self.nB
         nloc = ops.nloc
         yloc = ops.zeros(max(nloc, 1) * BLK)
+        yv = [yloc[lb * BLK:(lb + 1) * BLK] for lb in range(nloc)]
         for lb in range(nloc):
             b = g + lb * G
-            yloc[lb * BLK:(lb + 1) * BLK].copy_(y_full[b * BLK:(b + 1) * BLK])
+            yv[lb].copy_(y_full[b * BLK:(b + 1) * BLK])
         z = ops.zeros(self.Np)
-        zk = ops.zeros(BLK)
+        zv = [z[k * BLK:(k + 1) * BLK] for k in range(nB)]
         for k in range(nB):                                      # L z = y
             owner = k % G
             if g == owner:
-                lb = (k - g) // G
-                blk = yloc[lb * BLK:(lb + 1) * BLK]
-                ops.fwd_diag(k, blk)
-                zk.copy_(blk)
-            comm.broadcast(zk, owner)
-            z[k * BLK:(k + 1) * BLK].copy_(zk)
-            ops.fwd_update(k, zk, yloc)
+                zv[k].copy_(yv[(k - g) // G])
+                ops.fwd_diag(k, zv[k])
+            comm.broadcast(zv[k], owner)
+            ops.fwd_update(k, zv[k], yloc)
         aloc = ops.zeros(max(nloc, 1) * BLK)
+        av = [aloc[lb * BLK:(lb + 1) * BLK] for lb in range(nloc)]
         s = ops.zeros(BLK)
         for k in range(nB - 1, -1, -1):                          # L^T a = z
-            owner = k % G
             ops.bwd_partial(k, aloc, s)
             comm.all_reduce_sum(s)
-            if g == owner:
-                lb = (k - g) // G
-                ak = aloc[lb * BLK:(lb + 1) * BLK]
-                ak.copy_(z[k * BLK:(k + 1) * BLK] - s)
-                ops.bwd_diag(k, ak)
+            if g == k % G:
+                ak = av[(k - g) // G]
+                ak.copy_(zv[k])
+                ops.bwd_diag(k, ak, s)                           # a_k = L_kk^-T (z_k - s)
         alpha = ops.zeros(self.Np)
         for lb in range(nloc):
             b = g + lb * G
-            alpha[b * BLK:(b + 1) * BLK].copy_(aloc[lb * BLK:(lb + 1) * BLK])
+            alpha[b * BLK:(b + 1) * BLK].copy_(av[lb])
         comm.all_reduce_sum(alpha)
         return alpha
 
