@@ -14,7 +14,8 @@ R = os.environ["GRAFT_REPO_ROOT"]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
 for fn in glob.glob(R + "/gpurun_out/pmcb_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
-        k = "syrk_trailing_kernel" if "syrk_trailing" in r["Kernel_Name"] else ("kbuild_lower_kernel" if "kbuild_lower" in r["Kernel_Name"] else None)
+        nm = r["Kernel_Name"]
+        k = "syrk_trailing_kernel<.., NSEG=2>" if ("syrk_trailing" in nm and ", 2>(" in nm) else ("kbuild_lower_kernel" if "kbuild_lower" in nm else None)
         if k is None: continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 out = {}

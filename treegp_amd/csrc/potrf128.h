@@ -10,15 +10,23 @@
 //   phase 2: blocked in-place inversion of the 4x4 block-lower matrix (W_ii = D_i,
 //            W_ij = -D_i sum_k L_ik W_kj), again 16x16x4 MFMA tiles from LDS.
 //
-// LDS image T: 128 rows x stride 130 doubles (MFMA fragment reads: lane (r, kq) -> slot
-// 130 r + kq, conflict-free per 32-lane group).  Explicit inverses only of well-conditioned
-// diagonal blocks: cond(L_block) <= sqrt(cond(K)).
+// Explicit inverses only of well-conditioned diagonal blocks: cond(L_block) <= sqrt(cond(K)).
 #pragma once
 #include "tgp_internal.h"
 
 namespace potrf_v2 {
 typedef double d4v __attribute__((ext_vector_type(4)));
-constexpr int TS = 130;
+// LDS image: only the 10 lower 32x32 blocks of the 4x4 block matrix, each with row stride 34 doubles
+// (fragment reads: lane (r, kq) -> slot 34 r + kq, conflict-free per 32-lane group).  87 KB, so the
+// kernel fits beside one 70 KB GEMM workgroup on a CU -- that is what lets the look-ahead side stream
+// get a CU while the trailing update saturates the chip.
+constexpr int BS = 34;                    // row stride inside a block
+constexpr int BLK_ELEMS = 32 * BS;
+constexpr int T_ELEMS = 10 * BLK_ELEMS;
+__device__ __forceinline__ int taddr(int r, int c) {           // (r, c) with block(r) >= block(c)
+    const int bi = r >> 5, bj = c >> 5;
+    return (bi * (bi + 1) / 2 + bj) * BLK_ELEMS + (r & 31) * BS + (c & 31);
+}
 
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
@@ -59,8 +67,8 @@ __device__ __forceinline__ void gauss_jordan32(double (&t)[32], double (&ls)[32]
 __device__ __forceinline__ d4v mma_nt32(const double *T, int ra, int ca, int rb, int cb, d4v acc, int l15, int l4) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        const double a = T[(ra + l15) * TS + ca + 4 * ks + l4];
-        const double b = T[(rb + l15) * TS + cb + 4 * ks + l4];
+        const double a = T[taddr(ra + l15, ca + 4 * ks + l4)];
+        const double b = T[taddr(rb + l15, cb + 4 * ks + l4)];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
     return acc;
@@ -69,15 +77,15 @@ __device__ __forceinline__ d4v mma_nt32(const double *T, int ra, int ca, int rb,
 __device__ __forceinline__ d4v mma_nn32(const double *T, int ra, int ca, int rb, int cb, d4v acc, int l15, int l4) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        const double a = T[(ra + l15) * TS + ca + 4 * ks + l4];
-        const double b = T[(rb + 4 * ks + l4) * TS + cb + l15];
+        const double a = T[taddr(ra + l15, ca + 4 * ks + l4)];
+        const double b = T[taddr(rb + 4 * ks + l4, cb + l15)];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
     return acc;
 }
 
 __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, double *W, int *info, int base) {
-    __shared__ double T[128 * TS];
+    __shared__ double T[T_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const d4v zero4 = {0.0, 0.0, 0.0, 0.0};
@@ -85,8 +93,10 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
     for (int idx = tid; idx < 128 * 64; idx += 256) {          // two columns per thread, coalesced rows
         const int i = idx >> 6, c = (idx & 63) * 2;
         const double2 v = *reinterpret_cast<const double2 *>(A + (int64_t)i * lda + c);
-        T[i * TS + c] = (c <= i) ? v.x : 0.0;
-        T[i * TS + c + 1] = (c + 1 <= i) ? v.y : 0.0;
+        if ((c >> 5) <= (i >> 5)) {                              // lower blocks only
+            T[taddr(i, c)] = (c <= i) ? v.x : 0.0;
+            T[taddr(i, c + 1)] = (c + 1 <= i) ? v.y : 0.0;
+        }
     }
     __syncthreads();
 
@@ -98,13 +108,13 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
             const int i = lane;
             double t[32], ls[32];
 #pragma clang loop unroll(full)
-            for (int c = 0; c < 32; ++c) t[c] = T[(r0 + i) * TS + r0 + c];
+            for (int c = 0; c < 32; ++c) t[c] = T[taddr(r0 + i, r0 + c)];
             int fail = -1;
             gauss_jordan32(t, ls, i, fail);
             if (fail >= 0 && i == 0) atomicCAS(info, 0, base + r0 + fail + 1);
 #pragma clang loop unroll(full)
             for (int c = 0; c < 32; ++c) {
-                T[(r0 + i) * TS + r0 + c] = (c <= i) ? t[c] : 0.0;                 // D_j replaces the block
+                T[taddr(r0 + i, r0 + c)] = (c <= i) ? t[c] : 0.0;                  // D_j replaces the block
                 if (c <= i) A[(int64_t)(r0 + i) * lda + r0 + c] = ls[c];           // L_jj is final
             }
         }
@@ -117,16 +127,16 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
             d4v x0 = zero4, x1 = zero4;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const double a = T[(rb + l15) * TS + r0 + 4 * ks + l4];
-                const double b0 = T[(r0 + l15) * TS + r0 + 4 * ks + l4];
-                const double b1 = T[(r0 + 16 + l15) * TS + r0 + 4 * ks + l4];
+                const double a = T[taddr(rb + l15, r0 + 4 * ks + l4)];
+                const double b0 = T[taddr(r0 + l15, r0 + 4 * ks + l4)];
+                const double b1 = T[taddr(r0 + 16 + l15, r0 + 4 * ks + l4)];
                 x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, x0, 0, 0, 0);
                 x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, x1, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                T[(rb + l4 + 4 * r) * TS + r0 + l15] = x0[r];
-                T[(rb + l4 + 4 * r) * TS + r0 + 16 + l15] = x1[r];
+                T[taddr(rb + l4 + 4 * r, r0 + l15)] = x0[r];
+                T[taddr(rb + l4 + 4 * r, r0 + 16 + l15)] = x1[r];
             }
         }
         __syncthreads();
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
             const int tj = tt - ti * (ti + 1) / 2;
             const d4v p = mma_nt32(T, r1 + 16 * ti, r0, r1 + 16 * tj, r0, zero4, l15, l4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) T[(r1 + 16 * ti + l4 + 4 * r) * TS + r1 + 16 * tj + l15] -= p[r];
+            for (int r = 0; r < 4; ++r) T[taddr(r1 + 16 * ti + l4 + 4 * r, r1 + 16 * tj + l15)] -= p[r];
         }
         __syncthreads();
     }
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
     // off-diagonal blocks of L are final: write them out (diagonal blocks went out from registers)
     for (int idx = tid; idx < 128 * 128; idx += 256) {
         const int i = idx >> 7, c = idx & 127;
-        if ((c >> 5) < (i >> 5)) A[(int64_t)i * lda + c] = T[i * TS + c];
+        if ((c >> 5) < (i >> 5)) A[(int64_t)i * lda + c] = T[taddr(i, c)];
     }
     __syncthreads();
 
@@ -161,20 +171,20 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
                 s = mma_nn32(T, 32 * ib + 16 * rt, 32 * kb, 32 * kb, 32 * cb + 16 * ct, s, l15, l4);
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) T[(32 * ib + 16 * rt + l4 + 4 * r) * TS + 32 * cb + 16 * ct + l15] = s[r];
+            for (int r = 0; r < 4; ++r) T[taddr(32 * ib + 16 * rt + l4 + 4 * r, 32 * cb + 16 * ct + l15)] = s[r];
             __syncthreads();
             const d4v w = mma_nn32(T, 32 * ib + 16 * rt, 32 * ib, 32 * ib, 32 * cb + 16 * ct, zero4, l15, l4);   // D_i S
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) T[(32 * ib + 16 * rt + l4 + 4 * r) * TS + 32 * cb + 16 * ct + l15] = -w[r];
+            for (int r = 0; r < 4; ++r) T[taddr(32 * ib + 16 * rt + l4 + 4 * r, 32 * cb + 16 * ct + l15)] = -w[r];
             __syncthreads();
         }
     }
     for (int idx = tid; idx < 128 * 64; idx += 256) {
         const int i = idx >> 6, c = (idx & 63) * 2;
         double2 v;
-        v.x = (c <= i) ? T[i * TS + c] : 0.0;
-        v.y = (c + 1 <= i) ? T[i * TS + c + 1] : 0.0;
+        v.x = (c <= i) ? T[taddr(i, c)] : 0.0;
+        v.y = (c + 1 <= i) ? T[taddr(i, c + 1)] : 0.0;
         *reinterpret_cast<double2 *>(W + i * 128 + c) = v;
     }
 }
