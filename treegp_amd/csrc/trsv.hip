@@ -12,18 +12,37 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// y <- W y   (W lower-triangular 128x128, ld 128), one workgroup
+// y <- W y   (W lower-triangular 128x128, ld 128), one workgroup.  Rows of W are the dot-product
+// direction, so a thread-per-row read of global memory would be uncoalesced: the block is staged
+// through LDS with every load in flight at once (the kernel is pure latency), then each thread
+// pair takes one row from LDS.
 __global__ __launch_bounds__(256) void diag_gemv_n_kernel(const double *__restrict__ W, double *y) {
-    __shared__ double ys[128];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid < 128) ys[tid] = y[tid];
-    __syncthreads();
-    const double y0 = ys[2 * lane], y1 = ys[2 * lane + 1];
-    for (int r = w; r < 128; r += 4) {
-        const double2 a = *reinterpret_cast<const double2 *>(W + r * 128 + 2 * lane);
-        const double s = wave_sum(a.x * y0 + a.y * y1);
-        if (lane == 0) y[r] = s;
+    __shared__ double M[128 * 129];
+    __shared__ double ys[128], part[256];
+    const int tid = threadIdx.x;
+    {
+        const int c = (tid & 63) * 2, r0 = tid >> 6;
+        double2 v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = *reinterpret_cast<const double2 *>(W + (r0 + 4 * k) * 128 + c);
+        if (tid < 128) ys[tid] = y[tid];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            M[(r0 + 4 * k) * 129 + c] = v[k].x;
+            M[(r0 + 4 * k) * 129 + c + 1] = v[k].y;
+        }
     }
+    __syncthreads();
+    const int r = tid & 127, h = tid >> 7;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+    for (int c = h * 64; c < h * 64 + 64; c += 2) {
+        s0 += M[r * 129 + c] * ys[c];
+        s1 += M[r * 129 + c + 1] * ys[c + 1];
+    }
+    part[tid] = s0 + s1;
+    __syncthreads();
+    if (tid < 128) y[tid] = part[tid] + part[tid + 128];
 }
 
 // y <- W^T y
