@@ -59,10 +59,13 @@ __device__ __forceinline__ void lds_put2(double *p, const double2 &v) {
 // A and C always live in 256-wide panels (ld 256); B is a panel (LDB 256) or a W block (LDB 128).
 // NSEG = 2: the contraction runs over two operand pairs back to back, C -= A0 B0^T + A1 B1^T (the
 // depth-512 trailing update after two factored panels), one chunk pipeline across both.
+// NSEG = 0: run-time number of segments `nseg_rt`, segment s at a_ptr + s * seg_stride_a (and likewise
+// for B) -- the posterior-covariance product over all panels of the factor.
 template <int MODE, int LDB, int KDEPTH, typename CFG = TileDefault, int NSEG = 1>
 __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double *b_ptr, double *c_ptr,
                                               unsigned long long *stamps = nullptr, const double *a1_ptr = nullptr,
-                                              const double *b1_ptr = nullptr) {
+                                              const double *b1_ptr = nullptr, int nseg_rt = 1,
+                                              int64_t seg_stride_a = 0, int64_t seg_stride_b = 0) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tr1 = 0, tr2 = 0;
     if (stamps) ts0 = __builtin_amdgcn_s_memtime();
     constexpr int LDA = TGP_PW, LDC = TGP_PW;
@@ -125,7 +128,7 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
 
     if (stamps) { ts1 = __builtin_amdgcn_s_memtime(); tr1 = __builtin_amdgcn_s_memrealtime(); }
     constexpr int cps = KDEPTH / KB;               // chunks per segment
-    constexpr int nchunk = NSEG * cps;
+    const int nchunk = (NSEG > 0 ? NSEG : nseg_rt) * cps;
     const int fa = (wr * 64 + l15) * LS + l4;      // fragment read offsets
     const int fb = (wc * 64 + l15) * LS + l4;
     for (int c = 0; c < nchunk; ++c) {
@@ -133,10 +136,15 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
         const bool more = (c + 1 < nchunk);
         if (more) {
             const int cn = c + 1;
-            const int k0 = (NSEG > 1 ? (cn % cps) : cn) * KB;
+            const int k0 = (NSEG != 1 ? (cn % cps) : cn) * KB;
             const bool second = NSEG > 1 && cn >= cps;           // wave-uniform
-            const __amdgpu_buffer_rsrc_t sa = second ? ra1_src : ra_src;
-            const __amdgpu_buffer_rsrc_t sb = second ? rb1_src : rb_src;
+            __amdgpu_buffer_rsrc_t sa = second ? ra1_src : ra_src;
+            __amdgpu_buffer_rsrc_t sb = second ? rb1_src : rb_src;
+            if constexpr (NSEG == 0) {
+                const int seg = cn / cps;
+                sa = tile_rsrc(a_ptr + seg * seg_stride_a, 128 * LDA * 8);
+                sb = tile_rsrc(b_ptr + seg * seg_stride_b, 128 * LDB * 8);
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 ra[s] = buf_ld2(sa, va, (s * 32 * LDA + k0) * 8);
