@@ -21,23 +21,30 @@ class ThreadComm(object):
         self.sh, self.rank, self.size = shared, rank, shared.size
 
     def _exchange(self, t):
+        if t.is_cuda:
+            torch.cuda.synchronize()          # virtual ranks use several streams of one device
         self.sh.slots[self.rank] = t
         self.sh.barrier.wait()
         vals = list(self.sh.slots)
         return vals
 
+    def _done(self, t):
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        self.sh.barrier.wait()
+
     def broadcast(self, t, src):
         vals = self._exchange(t)
         if self.rank != src:
             t.copy_(vals[src])
-        self.sh.barrier.wait()
+        self._done(t)
 
     def all_reduce_sum(self, t):
         vals = self._exchange(t.clone())
         tot = vals[0].clone()
         for v in vals[1:]:
             tot += v
-        self.sh.barrier.wait()
+        self._done(t)
         t.copy_(tot)
 
     def all_reduce_max(self, t):
@@ -45,23 +52,20 @@ class ThreadComm(object):
         tot = vals[0].clone()
         for v in vals[1:]:
             tot = torch.maximum(tot, v)
-        self.sh.barrier.wait()
+        self._done(t)
         t.copy_(tot)
 
     def all_gather_start(self, out, inp):
+        from treegp_amd.dist import _Done
         self.all_gather(out, inp)
-
-        class _D(object):
-            def wait(self_inner):
-                pass
-        return _D()
+        return _Done(out)
 
     def all_gather(self, out, inp):
         vals = self._exchange(inp)
         n = inp.numel()
         for r in range(self.size):
             out[r * n:(r + 1) * n].copy_(vals[r])
-        self.sh.barrier.wait()
+        self._done(out)
 
 
 class NumpyLocalOps(object):
@@ -88,6 +92,17 @@ class NumpyLocalOps(object):
         return torch.zeros(n, dtype=torch.float64)
 
     def kbuild(self, *a):
+        pass
+
+    # no streams on the CPU: the choreography hooks are no-ops
+    def on_side(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def side_wait_main(self):
+        pass
+
+    def main_wait_side(self):
         pass
 
     def factor_diag(self, k):

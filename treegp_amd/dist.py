@@ -66,7 +66,7 @@ class TorchComm(object):
         if self.native_gather:
             return self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
         self.all_gather(out, inp)
-        return _Done()
+        return _Done(out)
 
     def all_gather(self, out, inp):
         """out (size * len(inp)) <- concatenation of every rank's inp"""
@@ -82,8 +82,21 @@ class TorchComm(object):
 
 
 class _Done(object):
+    """Handle of a gather that was issued synchronously on the then-current stream: wait() orders the
+    now-current stream behind it (no-op for CPU tensors)."""
+
+    def __init__(self, tensor=None):
+        self.ev = None
+        if tensor is not None and getattr(tensor, "is_cuda", False):
+            import torch
+            self.ev = torch.cuda.Event()
+            self.ev.record(torch.cuda.current_stream(tensor.device))
+            self.dev = tensor.device
+
     def wait(self):
-        pass
+        if self.ev is not None:
+            import torch
+            torch.cuda.current_stream(self.dev).wait_event(self.ev)
 
 
 class SelfComm(object):
@@ -92,7 +105,7 @@ class SelfComm(object):
 
     def all_gather_start(self, out, inp):
         self.all_gather(out, inp)
-        return _Done()
+        return _Done(out)
 
     def broadcast(self, t, src):
         pass
@@ -126,10 +139,30 @@ class HipLocalOps(object):
         self.bcast = torch.empty(BCAST_ELEMS, dtype=torch.float64, device=device)
         self.d_loff = torch.from_numpy(self.loff).to(device)
         self.kc = spec.to_c()
-        self.lib.tgp_set_stream(ctx, C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+        self.main_stream = torch.cuda.current_stream(device)
+        self.lib.tgp_set_stream(ctx, C.c_void_p(self.main_stream.cuda_stream))
+        # panel chain (diagonal block, broadcast, local solves, all-gather) runs on a second stream
+        # with its own context, concurrently with the bulk trailing update on the main stream
+        self.side_stream = torch.cuda.Stream(device=device, priority=-1)
+        self.ctx_side = _lib.new_ctx(device.index if device.index is not None else 0)
+        self.lib.tgp_set_stream(self.ctx_side, C.c_void_p(self.side_stream.cuda_stream))
 
-    def _chk(self, rc, what):
-        self._lib.check(self.ctx, rc, what)
+    def _chk(self, rc, what, ctx=None):
+        self._lib.check(ctx or self.ctx, rc, what)
+
+    # -- stream choreography -------------------------------------------------------------------------
+    def on_side(self):
+        return self.torch.cuda.stream(self.side_stream)
+
+    def side_wait_main(self):
+        ev = self.torch.cuda.Event()
+        ev.record(self.main_stream)
+        self.side_stream.wait_event(ev)
+
+    def main_wait_side(self):
+        ev = self.torch.cuda.Event()
+        ev.record(self.side_stream)
+        self.main_stream.wait_event(ev)
 
     def _p(self, t, off=0):
         return C.c_void_p(t.data_ptr() + 8 * int(off))
@@ -151,13 +184,13 @@ class HipLocalOps(object):
         self._chk(self.lib.tgp_dd_kbuild(self.ctx, C.byref(self.kc), self._p(dX), self.n, self._p(dyerr), self._p(self.A),
                                          self._p(self.d_loff), self.G, self.g), "tgp_dd_kbuild")
 
-    def factor_diag(self, k):
-        self._chk(self.lib.tgp_dd_factor_diag(self.ctx, self._p(self.A), self._hl(), self.Np, k, self.G, self.g,
-                                              self._p(self.W), self._p(self.bcast)), "tgp_dd_factor_diag")
+    def factor_diag(self, k):              # side stream
+        self._chk(self.lib.tgp_dd_factor_diag(self.ctx_side, self._p(self.A), self._hl(), self.Np, k, self.G, self.g,
+                                              self._p(self.W), self._p(self.bcast)), "tgp_dd_factor_diag", self.ctx_side)
 
-    def trsm(self, k):
-        self._chk(self.lib.tgp_dd_trsm(self.ctx, self._p(self.A), self._hl(), self.Np, k, self.G, self.g, self._p(self.W),
-                                       self._p(self.bcast)), "tgp_dd_trsm")
+    def trsm(self, k):                     # side stream
+        self._chk(self.lib.tgp_dd_trsm(self.ctx_side, self._p(self.A), self._hl(), self.Np, k, self.G, self.g,
+                                       self._p(self.W), self._p(self.bcast)), "tgp_dd_trsm", self.ctx_side)
 
     def panel_send_view(self, k, cmax):
         skip = BLK if k % self.G == self.g else 0
@@ -169,7 +202,10 @@ class HipLocalOps(object):
                                          self._p(gathered), cmax, col_lo, col_hi), "tgp_dd_update")
 
     def info(self):
-        return int(self.lib.tgp_dd_info(self.ctx, 1))
+        a = int(self.lib.tgp_dd_info(self.ctx, 1))
+        b = int(self.lib.tgp_dd_info(self.ctx_side, 1))
+        bad = [v for v in (a, b) if v > 0]
+        return min(bad) if bad else 0
 
     # -- triangular solves -----------------------------------------------------------------------
     def fwd_diag(self, k, yk):
@@ -221,16 +257,17 @@ class DistributedCholesky(object):
         return 2.0 * BLK * elems
 
     def factorize(self):
-        """Right-looking factorisation with look-ahead: the two tile columns of panel k+1 are updated
-        first, panel k+1 is factored / solved and its all-gather is started, and only then is the rest
-        of update k launched, so the collective (RCCL, own stream) runs under the large update."""
+        """Right-looking factorisation with look-ahead on two streams.  Main stream: the two tile
+        columns of panel k+1 first (strip), then the bulk of update k.  Side stream, started as soon
+        as the strip is done: diagonal block of panel k+1 on its owner, broadcast, local solves, and
+        the (asynchronous) all-gather of panel k+1 -- all of it underneath the bulk update."""
         ops, comm, G, g, nB = self.ops, self.comm, self.G, self.g, self.nB
         events = []
         self.update_flops, self.update_launches = 0.0, 0
         bufs = [self.gathered, self.gathered2]
 
         def factor_and_gather(k, buf):
-            """panel k: diagonal block on its owner, broadcast, local solves, start the all-gather"""
+            """panel k on the side stream: diagonal block on its owner, broadcast, local solves, all-gather"""
             owner = k % G
             if g == owner:
                 ops.factor_diag(k)
@@ -253,18 +290,23 @@ class DistributedCholesky(object):
             else:
                 ops.update(k, buf, cmax, lo, hi)
 
-        work, cmax = factor_and_gather(0, bufs[0])
+        ops.side_wait_main()                                     # K build (main) precedes panel 0
+        with ops.on_side():
+            work, cmax = factor_and_gather(0, bufs[0])
         for k in range(nB - 1):
             cur = bufs[k & 1]
-            work.wait()                                          # panel k is on every rank
+            work.wait()                                          # main stream: panel k is on every rank
             ops.update(k, cur, cmax, 0, 2)                       # columns of panel k+1 first
-            nwork, ncmax = factor_and_gather(k + 1, bufs[(k + 1) & 1])
-            timed_update(k, cur, cmax, 2, -1)                    # the bulk, overlapping the gather of k+1
+            ops.side_wait_main()
+            with ops.on_side():
+                nwork, ncmax = factor_and_gather(k + 1, bufs[(k + 1) & 1])
+            timed_update(k, cur, cmax, 2, -1)                    # the bulk, concurrent with the side chain
             fl = self._local_update_flops(k)
             if fl > 0:
                 self.update_flops += fl
                 self.update_launches += 1
             work, cmax = nwork, ncmax
+        ops.main_wait_side()                                     # last panel's chain has no gather to wait on
         # any rank's failure is everybody's failure; report the smallest failing index
         big = 1e18
         mine = ops.info()                                        # synchronises the stream
