@@ -99,6 +99,14 @@ int tgp_kk_twod(tgp_ctx *ctx, const double *x, const double *y, const double *k,
 int tgp_kk_log(tgp_ctx *ctx, const double *x, const double *y, const double *k,
                const double *w, int64_t n, double min_sep, double max_sep, int nbins,
                double *xi, double *weight, double *meanr, double *meanlogr, double *npairs);
+/* One shard of the same pair loop (multi-GPU, SURVEY 8e "pair histogram"): bin_type 0 = TwoD,
+ * 1 = Log; the 256-point i-tiles are dealt round-robin to `nparts` callers and `part` bins
+ * only its own.  acc_out holds the raw sums, 3 x nbins^2 (sum w w k k, sum w w, pairs) for
+ * TwoD and 5 x nbins (sum wwkk, sum ww, sum ww r, sum ww ln r, pairs) for Log; adding the
+ * shards (one all-reduce) and dividing by the weights gives tgp_kk_twod / tgp_kk_log.      */
+int tgp_kk_partial(tgp_ctx *ctx, int bin_type, const double *x, const double *y, const double *k,
+                   const double *w, int64_t n, double min_sep, double max_sep, int nbins,
+                   int part, int nparts, double *acc_out);
 /* bootstrap (two_pcf.py:269-281, 342-362): idx is (n_boot, n) int64; resample b uses points
  * idx[b,:], k = yv[idx] - mean(yv[idx]), w = 1/yerr[idx]^2 (unit weights if yerr == NULL or
  * sum(yerr[idx]) == 0).  xi_out is (n_boot, nbins^2).                                       */
@@ -111,6 +119,21 @@ int tgp_kk_twod_bootstrap(tgp_ctx *ctx, const double *x, const double *y, const 
  * k in 1..8 or 16.                                                                            */
 int tgp_knn_mean(tgp_ctx *ctx, const double *X0, const double *y0, int64_t n0, const double *X, int64_t m,
                  int k, double *out);
+
+/* ---- building the mean function ("meanify"): binned 2-D statistic of scattered values ------------
+ * replaces scipy.stats.binned_statistic_2d(u, v, ., bins=[u_edges, v_edges], statistic=.) at
+ * treegp/meanify.py:76-107, with scipy's bin numbering (np.digitize, last edge inclusive).
+ * stat MEAN: sum/count; MEDIAN: scipy's median of the bin; WEIGHTED: w = 1/err^2,
+ * average = sum(w p)/sum(w), wrms = sqrt((sum(w p p) - 2 avg sum(w p) + avg^2 sum(w))/sum(w)).
+ * Outputs are (nu_edges-1, nv_edges-1) row-major (u index first, as scipy returns them; the
+ * reference transposes afterwards); empty bins are NaN.  wrms (0 unless WEIGHTED) and count
+ * (points per bin; sum of weights for WEIGHTED) may be NULL.                                  */
+#define TGP_STAT_MEAN 0
+#define TGP_STAT_MEDIAN 1
+#define TGP_STAT_WEIGHTED 2
+int tgp_binned_stat_2d(tgp_ctx *ctx, const double *u, const double *v, const double *val, const double *err,
+                       int64_t n, const double *u_edges, int nu_edges, const double *v_edges, int nv_edges,
+                       int stat, double *average, double *wrms, double *count);
 
 /* ---- device-resident tier (bench / multi-GPU): same maths, d_ pointers, ctx stream --------*/
 int tgp_dev_alloc(tgp_ctx *ctx, int64_t bytes, void **d_out);

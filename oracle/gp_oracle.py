@@ -271,3 +271,46 @@ def correlation_length_matrix(size, e1, e2):
     rot = np.array([[np.cos(phi), np.sin(phi)], [-np.sin(phi), np.cos(phi)]])
     ell = np.array([[size ** 2, 0], [0, (size * q) ** 2]])
     return np.dot(rot.T, ell.dot(rot))
+
+
+def meanify_grid(coords, params, params_err=None, bin_spacing=120.0, statistics="mean",
+                 lu_min=None, lu_max=None, lv_min=None, lv_max=None):
+    """meanify.py:49-137 restated with the same SciPy call the reference makes
+    (scipy.stats.binned_statistic_2d): bin edges np.linspace(min, max, int((max-min)/bin_spacing)),
+    statistic "mean" / "median", or the three "sum" passes of the weighted branch (:76-101, on the
+    same edges; the reference itself stops with a NameError there, :108).  Returns a dict with
+    average / wrms (already transposed, :105-106), xedge, yedge, u0, v0 (bin-centre meshgrid,
+    :121-124), and the filtered coords0, params0, wrms0 (:131-137)."""
+    from scipy.stats import binned_statistic_2d
+    coords = np.asarray(coords, float); params = np.asarray(params, float)
+    lu_min = np.min(coords[:, 0]) if lu_min is None else lu_min
+    lu_max = np.max(coords[:, 0]) if lu_max is None else lu_max
+    lv_min = np.min(coords[:, 1]) if lv_min is None else lv_min
+    lv_max = np.max(coords[:, 1]) if lv_max is None else lv_max
+    nbin_u = int((lu_max - lu_min) / bin_spacing)
+    nbin_v = int((lv_max - lv_min) / bin_spacing)
+    binning = [np.linspace(lu_min, lu_max, nbin_u), np.linspace(lv_min, lv_max, nbin_v)]
+    if statistics == "weighted":
+        weights = 1.0 / np.asarray(params_err, float) ** 2
+        sum_wpp, xedge, yedge, _ = binned_statistic_2d(coords[:, 0], coords[:, 1], weights * params * params,
+                                                       bins=binning, statistic="sum")
+        sum_wp = binned_statistic_2d(coords[:, 0], coords[:, 1], weights * params, bins=binning, statistic="sum")[0]
+        sum_w = binned_statistic_2d(coords[:, 0], coords[:, 1], weights, bins=binning, statistic="sum")[0]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            average = sum_wp / sum_w
+            wvar = (1.0 / sum_w) * (sum_wpp - 2.0 * average * sum_wp + average * average * sum_w)
+            wrms = np.sqrt(wvar)
+    else:
+        average, xedge, yedge, _ = binned_statistic_2d(coords[:, 0], coords[:, 1], params, bins=binning,
+                                                       statistic=statistics)
+        wrms = np.zeros_like(average)
+    average = average.T
+    wrms = wrms.T
+    flat_a, flat_w = average.reshape(-1), wrms.reshape(-1)
+    keep = np.isfinite(flat_a) & np.isfinite(flat_w)
+    u0 = xedge[:-1] + (xedge[1] - xedge[0]) / 2.0
+    v0 = yedge[:-1] + (yedge[1] - yedge[0]) / 2.0
+    u0, v0 = np.meshgrid(u0, v0)
+    coords0 = np.array([u0.reshape(-1), v0.reshape(-1)]).T
+    return dict(average=average, wrms=wrms, xedge=xedge, yedge=yedge, u0=u0, v0=v0,
+                coords0=coords0[keep], params0=flat_a[keep], wrms0=flat_w[keep])

@@ -187,3 +187,45 @@ class NumpyLocalOps(object):
                 if b * BLK + r < self.n:
                     s += 2.0 * np.log(d[r])
         out[0] = s
+
+
+def numpy_kk_partial(bin_type, x, y, k, w, min_sep, max_sep, nbins, part, nparts, ctx=None):
+    """CPU stand-in for ops.kk_partial (tgp_kk_partial): the pairs (i, j > i) whose 256-point i-tile is
+    dealt to `part`, binned by the oracle's rules; raw sums (3, nbins^2) TwoD / (5, nbins) Log."""
+    x = np.asarray(x, float); y = np.asarray(y, float); k = np.asarray(k, float)
+    n = len(x)
+    w = np.ones(n) if w is None else np.asarray(w, float)
+    acc = np.zeros((3, nbins * nbins) if bin_type == 0 else (5, nbins))
+    for s in range(part * 256, n, nparts * 256):
+        e = min(n, s + 256)
+        dx = x[None, :] - x[s:e, None]
+        dy = y[None, :] - y[s:e, None]
+        rsq = dx * dx + dy * dy
+        later = np.arange(n)[None, :] > np.arange(s, e)[:, None]
+        ww = w[s:e, None] * w[None, :]
+        kk = k[s:e, None] * k[None, :]
+        if bin_type == 0:
+            bs = 2.0 * max_sep / nbins
+            ok = later & (rsq != 0.0) & (rsq >= min_sep * min_sep) & (np.maximum(np.abs(dx), np.abs(dy)) < max_sep)
+            for sgn in (1.0, -1.0):
+                ix = ((sgn * dx[ok] + max_sep) / bs).astype(np.int64)
+                iy = ((sgn * dy[ok] + max_sep) / bs).astype(np.int64)
+                good = (ix >= 0) & (ix < nbins) & (iy >= 0) & (iy < nbins)
+                b = iy[good] * nbins + ix[good]
+                acc[0] += np.bincount(b, weights=(ww * kk)[ok][good], minlength=nbins * nbins)
+                acc[1] += np.bincount(b, weights=ww[ok][good], minlength=nbins * nbins)
+                acc[2] += np.bincount(b, minlength=nbins * nbins)
+        else:
+            bs = np.log(max_sep / min_sep) / nbins
+            ok = later & (rsq >= min_sep * min_sep) & (rsq < max_sep * max_sep)
+            lr = 0.5 * np.log(rsq[ok])
+            b = ((lr - np.log(min_sep)) / bs).astype(np.int64)
+            good = (b >= 0) & (b < nbins)
+            b = b[good]
+            wg = ww[ok][good]
+            acc[0] += np.bincount(b, weights=wg * kk[ok][good], minlength=nbins)
+            acc[1] += np.bincount(b, weights=wg, minlength=nbins)
+            acc[2] += np.bincount(b, weights=wg * np.sqrt(rsq[ok][good]), minlength=nbins)
+            acc[3] += np.bincount(b, weights=wg * lr[good], minlength=nbins)
+            acc[4] += np.bincount(b, minlength=nbins)
+    return acc

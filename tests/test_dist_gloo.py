@@ -57,3 +57,60 @@ def _worker(rank, world, port, n, out_dir):
 def test_distributed_cholesky_gloo(tmp_path, world, n):
     mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
+
+
+def _pair_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from _dist_helpers import numpy_kk_partial
+        from treegp_amd import ops
+        from treegp_amd.dist import TorchComm
+        from oracle import gp_oracle as O
+        rng = np.random.default_rng(5)
+        n, nbins = 1500, 11
+        x, y = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+        k = rng.standard_normal(n)
+        w = rng.uniform(0.5, 2.0, n)
+        # the per-rank kernels are replaced by NumPy; what is under test is the sharding + reduction
+        ops.kk_partial = numpy_kk_partial
+
+        def boot_local(ctx, lib, x, y, yv, e, idx, min_sep, max_sep, nbins):
+            rows = []
+            for r in idx:
+                kr = yv[r] - np.mean(yv[r])
+                wr = None if (e is None or np.sum(e[r]) == 0) else 1.0 / e[r] ** 2
+                rows.append(O.kk_twod(x[r], y[r], kr, wr, min_sep, max_sep, nbins)[0])
+            return np.array(rows)
+        ops._kk_twod_bootstrap_local = boot_local
+        ops._lib.get_ctx = lambda device=None: None
+        ops._lib.load_library = lambda: None
+        ops.set_pair_comm(TorchComm())
+        xi, wt, npairs = ops.kk_twod(x, y, k, w, 0.0, 0.2, nbins)
+        rxi, rwt, rn = O.kk_twod(x, y, k, w, 0.0, 0.2, nbins)
+        np.testing.assert_array_equal(npairs, rn)
+        np.testing.assert_allclose(wt, rwt, rtol=1e-13)
+        np.testing.assert_allclose(xi, rxi, rtol=0, atol=1e-13 * np.abs(rxi).max())
+        out = ops.kk_log(x, y, k, None, 0.01, 0.5, 9)
+        ref = O.kk_log(x, y, k, None, 0.01, 0.5, 9)
+        np.testing.assert_array_equal(out[4], ref[4])
+        for a, b in zip(out[:4], ref[:4]):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-13 * np.abs(b).max())
+        idx = O.bootstrap_indices(300, 5)
+        e = rng.uniform(0.1, 0.2, 300)
+        xb = ops.kk_twod_bootstrap(x[:300], y[:300], k[:300], e, idx, 0.0, 0.3, 7)
+        ref = boot_local(None, None, x[:300], y[:300], k[:300], e, idx, 0.0, 0.3, 7)
+        np.testing.assert_array_equal(xb, ref)
+        ops.set_pair_comm(None)
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_pair_binning_gloo(tmp_path):
+    world = 2
+    mp.spawn(_pair_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))

@@ -85,3 +85,56 @@ def test_virtual_ranks(G, n):
     a_o, _ = O.gp_solve(O.kernel_matrix("gauss", X, **kw), y, y_err)
     yp_o = O.gp_predict(O.kernel_matrix("gauss", Xs, X, **kw), a_o)
     np.testing.assert_allclose(results[0][2], yp_o, rtol=0, atol=1e-10 * np.abs(yp_o).max())
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_sharded_pair_binning_virtual_ranks(G):
+    """SURVEY 8e pair histogram: i-tiles (kk_twod / kk_log) and whole resamples (bootstrap) dealt to the
+    ranks, one sum-reduction; equal to the single-GPU call and to the oracle."""
+    from treegp_amd import _lib, ops
+    from _dist_helpers import ThreadComm
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(G)
+    n, nbins = 3000, 15
+    x, y = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    k = rng.standard_normal(n)
+    w = rng.uniform(0.5, 2.0, n)
+    e = rng.uniform(0.1, 0.2, n)
+    idx = O.bootstrap_indices(n, 7)
+    one = (ops.kk_twod(x, y, k, w, 0.0, 0.2, nbins), ops.kk_log(x, y, k, None, 0.01, 0.5, 12),
+           ops.kk_twod_bootstrap(x, y, k, e, idx, 0.0, 0.2, nbins))
+    ora = O.kk_twod(x, y, k, w, 0.0, 0.2, nbins)
+    shared = ThreadComm.Shared(G)
+    results, errors = [None] * G, []
+
+    def run(rank):
+        try:
+            ctx = _lib.new_ctx(0)
+            ops.set_pair_comm(ThreadComm(shared, rank))
+            results[rank] = (ops.kk_twod(x, y, k, w, 0.0, 0.2, nbins, ctx=ctx),
+                             ops.kk_log(x, y, k, None, 0.01, 0.5, 12, ctx=ctx),
+                             ops.kk_twod_bootstrap(x, y, k, e, idx, 0.0, 0.2, nbins, ctx=ctx))
+            ops.set_pair_comm(None)
+        except BaseException as ex:           # noqa: BLE001
+            errors.append(ex)
+            try:
+                shared.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for r in range(G):
+        twod, lg, boot = results[r]
+        np.testing.assert_array_equal(twod[2], one[0][2])                 # pair counts: exact
+        np.testing.assert_array_equal(twod[2], ora[2])
+        np.testing.assert_allclose(twod[0], ora[0], rtol=0, atol=1e-12 * np.abs(ora[0]).max())
+        np.testing.assert_allclose(twod[1], one[0][1], rtol=1e-12)
+        np.testing.assert_array_equal(lg[4], one[1][4])
+        for a, b in zip(lg[:4], one[1][:4]):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-12 * np.abs(b).max())
+        np.testing.assert_allclose(boot, one[2], rtol=0, atol=1e-12 * np.abs(one[2]).max())

@@ -119,3 +119,36 @@ def test_kk_twod_vs_naive_loop():
     np.testing.assert_allclose(xi[s_w > 0], (s_wkk / np.where(s_w > 0, s_w, 1))[s_w > 0], rtol=1e-12, atol=1e-15)
     # point symmetry the reference relies on (two_pcf.py:306-310)
     np.testing.assert_allclose(xi.reshape(nb, nb), xi.reshape(nb, nb)[::-1, ::-1], rtol=1e-12, atol=1e-15)
+
+
+def meanify_fixture_coords(nfields=300, ndata=500):
+    """The star positions behind the reference's tests/inputs/mean_gp_stat_mean.fits: legacy
+    np.random.seed(42) stream of its tests/test_meanify.py:43-55 -- per field 500 uniform x, 500 uniform
+    y, then the 500 normals that np.random.multivariate_normal draws (values not needed here)."""
+    np.random.seed(42)
+    coords = []
+    for _ in range(nfields):
+        x = np.random.uniform(0, 2048, size=ndata)
+        y = np.random.uniform(0, 2048, size=ndata)
+        np.random.standard_normal(ndata)
+        coords.append(np.array([x, y]).T)
+    return coords
+
+
+def test_meanify_grid_geometry_against_reference_fixture(golden):
+    """COORDS0 of the reference's own meanify output (bin_spacing=40, 50 x 50 bins, all populated) pins the
+    edges, the bin-centre formula and the flattening order of oracle.meanify_grid."""
+    g = golden("g6_meanify.npz")
+    coords = np.concatenate(meanify_fixture_coords(), axis=0)
+    # the reference's smooth mean function (test_meanify.py:27) stands in for the GRF draws
+    params = 0.02 + 5e-8 * (coords[:, 0] - 1024) ** 2 + 5e-8 * (coords[:, 1] - 1024) ** 2
+    for stat in ("mean", "median"):
+        m = O.meanify_grid(coords, params, bin_spacing=40.0, statistics=stat)
+        np.testing.assert_array_equal(m["coords0"], g["X0"])
+        assert m["average"].shape == (50, 50)
+        # the fixture's PARAMS0 are GRF realisations around that function (reference tolerance 2e-1, :67)
+        np.testing.assert_allclose(m["params0"], g["y0"], atol=2e-1)
+    err = 0.01 + 0.02 * np.random.default_rng(0).uniform(size=len(params))
+    w = O.meanify_grid(coords, params, params_err=err, bin_spacing=40.0, statistics="weighted")
+    np.testing.assert_array_equal(w["coords0"], g["X0"])
+    assert np.all(w["wrms0"] >= 0) and np.all(np.isfinite(w["params0"]))

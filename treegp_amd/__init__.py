@@ -12,6 +12,7 @@ from .gp_interp import GPInterpolation
 from .kernels import AnisotropicRBF, VonKarman, AnisotropicVonKarman, eval_kernel, kernel_to_spec
 from .two_pcf import two_pcf  # noqa: F401  (class shadows the module, as in the reference)
 from .log_likelihood import log_likelihood  # noqa: F401
+from .meanify import meanify  # noqa: F401
 
 __all__ = ["__version__", "__version_info__", "GPInterpolation", "two_pcf", "log_likelihood", "AnisotropicRBF",
-           "VonKarman", "AnisotropicVonKarman", "eval_kernel", "kernel_to_spec"]
+           "VonKarman", "AnisotropicVonKarman", "eval_kernel", "kernel_to_spec", "meanify"]

@@ -26,6 +26,7 @@ struct KKArgs {
     int64_t n;
     double min_sep, max_sep, bs, inv_bs, minsq, maxsq, lmin;
     int nbins, jchunks;
+    int part, nparts;             // this launch owns the i-tiles ti = part, part + nparts, ...  (multi-GPU sharding)
 };
 
 __device__ __forceinline__ void lds_add(double *p, double v) {
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void kk_pairs_kernel(KKArgs a, double *__restr
     const int64_t boot = blockIdx.z;
     const int64_t *idx = a.idx + boot * a.n;
     const double mean = a.mean ? a.mean[boot] : 0.0;
-    const int64_t ti = blockIdx.x;
+    const int64_t ti = (int64_t)blockIdx.x * a.nparts + a.part;
     const int64_t ntile = (a.n + KT - 1) / KT;
     const double *bb = a.bbox + boot * ntile * 4;
     const double bxl = bb[ti * 4], bxh = bb[ti * 4 + 1], byl = bb[ti * 4 + 2], byh = bb[ti * 4 + 3];
@@ -230,8 +231,9 @@ static void counting_sort_row(const int64_t *src, int64_t n, const std::vector<u
 
 static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, const double *v, const double *w_host,
                   const double *yerr_host, int64_t n, const int64_t *idx, int64_t n_boot, double min_sep,
-                  double max_sep, int nbins, std::vector<double> &acc_host) {
+                  double max_sep, int nbins, std::vector<double> &acc_host, int part = 0, int nparts = 1) {
     TGP_ARG(x && y && v && n > 1 && nbins > 0 && n_boot >= 1);
+    TGP_ARG(nparts >= 1 && part >= 0 && part < nparts);
     TGP_ARG(twod ? (nbins * nbins <= MAXB2) : (nbins <= MAXBL));
     TGP_ARG(max_sep > 0.0 && (twod || min_sep > 0.0));
     TGP_HIP(hipSetDevice(ctx->device));
@@ -300,6 +302,7 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
     a.min_sep = min_sep; a.max_sep = max_sep;
     a.minsq = min_sep * min_sep; a.maxsq = max_sep * max_sep;
     a.nbins = nbins;
+    a.part = part; a.nparts = nparts;
     if (twod) { a.bs = 2.0 * max_sep / nbins; a.lmin = 0.0; }
     else { a.bs = log(max_sep / min_sep) / nbins; a.lmin = log(min_sep); }
     a.inv_bs = 1.0 / a.bs;
@@ -311,8 +314,10 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
     if (jch > ntile) jch = (int)ntile;
     a.jchunks = jch;
     const size_t shm = (size_t)(4 * KT + 4 * nacc * nb) * sizeof(double);
-    dim3 grid((unsigned)ntile, (unsigned)jch, (unsigned)n_boot), block(256);
-    if (twod) {
+    const int64_t my_tiles = (ntile - part + nparts - 1) / nparts;      // ti = part, part + nparts, ... < ntile
+    dim3 grid((unsigned)my_tiles, (unsigned)jch, (unsigned)n_boot), block(256);
+    if (my_tiles <= 0) {
+    } else if (twod) {
         TGP_HIP(hipFuncSetAttribute((const void *)kk_pairs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         kk_pairs_kernel<true><<<grid, block, shm, st>>>(a, d_acc);
     } else {
@@ -363,6 +368,18 @@ int tgp_kk_log(tgp_ctx *ctx, const double *x, const double *y, const double *k, 
         if (meanlogr) meanlogr[b] = nz ? acc[3 * nb + b] / ww : 0.0;
         if (npairs) npairs[b] = acc[4 * nb + b];
     }
+    return 0;
+}
+
+// raw accumulators of the i-tiles dealt to `part` of `nparts`: the sum over parts is the whole catalogue
+// (multi-GPU: one part per rank, all-reduce, then xi = acc[0] / acc[1] on the host)
+int tgp_kk_partial(tgp_ctx *ctx, int bin_type, const double *x, const double *y, const double *k, const double *w,
+                   int64_t n, double min_sep, double max_sep, int nbins, int part, int nparts, double *acc_out) {
+    TGP_ARG(acc_out && (bin_type == 0 || bin_type == 1));
+    std::vector<double> acc;
+    int rc = kk_run(ctx, bin_type == 0, x, y, k, w, nullptr, n, nullptr, 1, min_sep, max_sep, nbins, acc, part, nparts);
+    if (rc) return rc;
+    memcpy(acc_out, acc.data(), acc.size() * sizeof(double));
     return 0;
 }
 

@@ -50,6 +50,10 @@ class TorchComm(object):
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self.native_gather = dist.get_backend(group) == "nccl"
+        self.device = None                   # where host-side reductions have to be staged (RCCL: on the GPU)
+        if self.native_gather:
+            import torch
+            self.device = torch.device("cuda", torch.cuda.current_device())
 
     def broadcast(self, t, src):
         self.dist.broadcast(t, src=src, group=self.group)

@@ -6,6 +6,8 @@ A kernel is described by ``KernelSpec`` -- the plain numbers the device needs --
 """
 import ctypes as C
 
+import threading
+
 import numpy as np
 
 from . import _lib
@@ -107,7 +109,55 @@ def gp_predict_cov(spec, factor, X, Xs, ctx=None):
     return cov
 
 
+# ---- pair binning across ranks: i-tiles / bootstrap resamples dealt to the ranks ------
+_pair = threading.local()                  # per thread: the tests run virtual ranks as threads
+
+
+def _pair_comm():
+    return getattr(_pair, "comm", None)
+
+
+def set_pair_comm(comm):
+    """Shard every following kk_twod / kk_log / kk_twod_bootstrap call over the ranks of ``comm``
+    (an object with rank, size, all_reduce_sum(tensor), e.g. treegp_amd.dist.TorchComm); None
+    switches back to single-GPU.  Every rank must make the same calls with the same data."""
+    _pair.comm = comm if (comm is not None and comm.size > 1) else None
+
+
+def kk_partial(bin_type, x, y, k, w, min_sep, max_sep, nbins, part, nparts, ctx=None):
+    """Raw accumulators (3, nbins^2) [TwoD, bin_type 0] or (5, nbins) [Log, 1] of one shard."""
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    x, y, k = f64(x), f64(y), f64(k)
+    w = None if w is None else f64(w)
+    acc = np.zeros((3, nbins * nbins) if bin_type == 0 else (5, nbins))
+    rc = lib.tgp_kk_partial(ctx, int(bin_type), ptr(x), ptr(y), ptr(k), ptr(w), len(x), float(min_sep),
+                            float(max_sep), int(nbins), int(part), int(nparts), ptr(acc))
+    check(ctx, rc, "tgp_kk_partial")
+    return acc
+
+
+def _kk_sharded(bin_type, x, y, k, w, min_sep, max_sep, nbins, ctx, comm):
+    import torch
+    acc = kk_partial(bin_type, x, y, k, w, min_sep, max_sep, nbins, comm.rank, comm.size, ctx)
+    t = torch.from_numpy(acc)
+    dev = getattr(comm, "device", None)
+    if dev is not None:
+        t = t.to(dev)
+    comm.all_reduce_sum(t)                               # <= 5 nbins^2 doubles
+    acc = t.cpu().numpy()
+    ww = acc[1]
+    nz = ww != 0.0
+    safe = np.where(nz, ww, 1.0)
+    xi = np.where(nz, acc[0] / safe, 0.0)
+    if bin_type == 0:
+        return xi, ww, acc[2]
+    return xi, ww, np.where(nz, acc[2] / safe, 0.0), np.where(nz, acc[3] / safe, 0.0), acc[4]
+
+
 def kk_twod(x, y, k, w, min_sep, max_sep, nbins, ctx=None):
+    if _pair_comm() is not None:
+        return _kk_sharded(0, x, y, k, w, min_sep, max_sep, nbins, ctx, _pair_comm())
     ctx = ctx or _lib.get_ctx()
     lib = _lib.load_library()
     x, y, k = f64(x), f64(y), f64(k)
@@ -121,6 +171,8 @@ def kk_twod(x, y, k, w, min_sep, max_sep, nbins, ctx=None):
 
 
 def kk_log(x, y, k, w, min_sep, max_sep, nbins, ctx=None):
+    if _pair_comm() is not None:
+        return _kk_sharded(1, x, y, k, w, min_sep, max_sep, nbins, ctx, _pair_comm())
     ctx = ctx or _lib.get_ctx()
     lib = _lib.load_library()
     x, y, k = f64(x), f64(y), f64(k)
@@ -140,6 +192,26 @@ def kk_twod_bootstrap(x, y, yv, y_err, idx, min_sep, max_sep, nbins, ctx=None):
     idx = np.ascontiguousarray(idx, dtype=np.int64)
     n_boot, n = idx.shape
     assert n == len(x)
+    comm = _pair_comm()
+    if comm is not None:
+        # whole resamples per rank (rows rank, rank + size, ...), then one sum puts the rows together
+        import torch
+        mine = idx[comm.rank::comm.size]
+        full = np.zeros((n_boot, nbins * nbins))
+        if len(mine):
+            full[comm.rank::comm.size] = _kk_twod_bootstrap_local(ctx, lib, x, y, yv, e, mine, min_sep, max_sep, nbins)
+        t = torch.from_numpy(full)
+        dev = getattr(comm, "device", None)
+        if dev is not None:
+            t = t.to(dev)
+        comm.all_reduce_sum(t)
+        return t.cpu().numpy()
+    return _kk_twod_bootstrap_local(ctx, lib, x, y, yv, e, idx, min_sep, max_sep, nbins)
+
+
+def _kk_twod_bootstrap_local(ctx, lib, x, y, yv, e, idx, min_sep, max_sep, nbins):
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    n_boot, n = idx.shape
     out = np.empty((n_boot, nbins * nbins))
     rc = lib.tgp_kk_twod_bootstrap(ctx, ptr(x), ptr(y), ptr(yv), ptr(e), n, ptr(idx), n_boot, float(min_sep),
                                    float(max_sep), int(nbins), ptr(out))
@@ -157,6 +229,29 @@ def knn_mean(X0, y0, X, k=4, ctx=None):
     rc = lib.tgp_knn_mean(ctx, ptr(X02), ptr(y0), X02.shape[0], ptr(X2), X2.shape[0], int(k), ptr(out))
     check(ctx, rc, "tgp_knn_mean")
     return out
+
+
+_STATS = {"mean": 0, "median": 1, "weighted": 2}
+
+
+def binned_stat_2d(u, v, values, u_edges, v_edges, statistic="mean", err=None, ctx=None):
+    """scipy.stats.binned_statistic_2d(u, v, values, bins=[u_edges, v_edges], statistic) on the GPU
+    (meanify.py:76-107).  Returns average, wrms, count, each (len(u_edges)-1, len(v_edges)-1)."""
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    u, v, values = f64(u), f64(v), f64(values)
+    ue, ve = f64(u_edges), f64(v_edges)
+    e = None if err is None else f64(err)
+    if statistic not in _STATS:
+        raise ValueError("statistic must be one of %s" % sorted(_STATS))
+    if statistic == "weighted" and e is None:
+        raise ValueError("the weighted statistic needs errors")
+    shape = (len(ue) - 1, len(ve) - 1)
+    avg, wrms, cnt = np.empty(shape), np.empty(shape), np.empty(shape)
+    rc = lib.tgp_binned_stat_2d(ctx, ptr(u), ptr(v), ptr(values), ptr(e), len(u), ptr(ue), len(ue), ptr(ve), len(ve),
+                                _STATS[statistic], ptr(avg), ptr(wrms), ptr(cnt))
+    check(ctx, rc, "tgp_binned_stat_2d")
+    return avg, wrms, cnt
 
 
 # ---- device-resident tier ---------------------------------------------------------------------
