@@ -114,6 +114,14 @@ int tgp_kk_twod_bootstrap(tgp_ctx *ctx, const double *x, const double *y, const 
                           const double *yerr, int64_t n, const int64_t *idx, int64_t n_boot,
                           double min_sep, double max_sep, int nbins, double *xi_out);
 
+/* ---- vector 2-point correlation (E/B diagnostics): the pair accumulation of treegp/utils.py:5-74 ----
+ * All pairs i < j; log|p_j - p_i| binned on `edges` (nbins + 1 increasing values = the uniform
+ * edges np.histogram builds for (bins, range); last edge inclusive).  acc_out is (7, nbins):
+ * pairs, sum log r, sum (dx_i dx_j + dy_i dy_j), Re and Im of sum v_i v_j (v = dx + i dy), Re and
+ * Im of sum v_i v_j conj(d)^2/|d|^2.  xi_+ = acc[2]/acc[0], xi_- = acc[5]/acc[0], ...        */
+int tgp_vcorr(tgp_ctx *ctx, const double *x, const double *y, const double *dx, const double *dy,
+              int64_t n, const double *edges, int nbins, double *acc_out);
+
 /* ---- mean function: uniform mean of the k nearest neighbours of each X in the table (X0, y0) -----
  * replaces KNeighborsRegressor(n_neighbors=k).fit(X0, y0).predict(X) at treegp/gp_interp.py:236-238.
  * k in 1..8 or 16.                                                                            */

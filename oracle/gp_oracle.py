@@ -314,3 +314,40 @@ def meanify_grid(coords, params, params_err=None, bin_spacing=120.0, statistics=
     coords0 = np.array([u0.reshape(-1), v0.reshape(-1)]).T
     return dict(average=average, wrms=wrms, xedge=xedge, yedge=yedge, u0=u0, v0=v0,
                 coords0=coords0[keep], params0=flat_a[keep], wrms0=flat_w[keep])
+
+
+def vcorr(x, y, dx, dy, rmin=5.0 / 3600.0, rmax=1.5, dlogr=0.05, chunk=512):
+    """utils.py:36-74 restated without the index arrays: every pair i < j, complex separation
+    d = (x_j - x_i) + i (y_j - y_i), log|d| histogrammed with np.histogram on (bins, range)
+    exactly as there, weights 1, log|d|, dx_i dx_j + dy_i dy_j, v_i v_j and v_i v_j conj(d)^2/|d|^2
+    (v = dx + i dy).  Parity unpinned: no reference test checks a value (tests/test_hyp_search.py:133-139
+    only runs it) and treegp/utils.py imports treecorr at module level, so it cannot be imported here.
+    Returns logr, xiplus, ximinus, xicross, xiz2 and the pair counts."""
+    x = np.asarray(x, float); y = np.asarray(y, float)
+    v = np.asarray(dx, float) + 1j * np.asarray(dy, float)
+    n = len(x)
+    logrmin = np.log(rmin)
+    bins = int(np.ceil(np.log(rmax / rmin) / dlogr))
+    hrange = (logrmin, logrmin + bins * dlogr)
+    counts = np.zeros(bins); s_logr = np.zeros(bins); s_plus = np.zeros(bins)
+    s_z2 = np.zeros(bins, complex); s_minus = np.zeros(bins, complex)
+    z = x + 1j * y
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        i1, i2 = np.nonzero(np.arange(n)[None, :] > np.arange(s, e)[:, None])
+        i1 = i1 + s
+        dr = 1j * (y[i2] - y[i1])
+        dr += x[i2] - x[i1]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            logdr = np.log(np.absolute(dr))
+            h = lambda w=None: np.histogram(logdr, bins=bins, range=hrange, weights=w)[0]   # noqa: E731
+            counts += h()
+            s_logr += h(np.where(np.isfinite(logdr), logdr, 0.0))
+            s_plus += h(v[i1].real * v[i2].real + v[i1].imag * v[i2].imag)
+            vv = v[i1] * v[i2]
+            s_z2 += h(vv)
+            vv = vv * np.conj(dr) * np.conj(dr) / (dr.real * dr.real + dr.imag * dr.imag)
+            s_minus += h(np.where(np.isfinite(vv), vv, 0.0))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (s_logr / counts, s_plus / counts, (s_minus / counts).real, (s_minus / counts).imag,
+                s_z2 / counts, counts)

@@ -13,6 +13,7 @@ from .kernels import AnisotropicRBF, VonKarman, AnisotropicVonKarman, eval_kerne
 from .two_pcf import two_pcf  # noqa: F401  (class shadows the module, as in the reference)
 from .log_likelihood import log_likelihood  # noqa: F401
 from .meanify import meanify  # noqa: F401
+from .utils import comp_eb, comp_eb_treecorr
 
 __all__ = ["__version__", "__version_info__", "GPInterpolation", "two_pcf", "log_likelihood", "AnisotropicRBF",
-           "VonKarman", "AnisotropicVonKarman", "eval_kernel", "kernel_to_spec", "meanify"]
+           "VonKarman", "AnisotropicVonKarman", "eval_kernel", "kernel_to_spec", "meanify", "comp_eb", "comp_eb_treecorr"]

@@ -43,6 +43,7 @@ SIGNATURES = {
     "tgp_kk_log": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "tgp_kk_partial": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, _vp]),
     "tgp_kk_twod_bootstrap": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, C.c_double, C.c_double, C.c_int, _vp]),
+    "tgp_vcorr": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, C.c_int, _vp]),
     "tgp_knn_mean": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, C.c_int, _vp]),
     "tgp_binned_stat_2d": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "tgp_dev_alloc": (C.c_int, [_vp, _i64, C.POINTER(_vp)]),

@@ -219,6 +219,18 @@ def _kk_twod_bootstrap_local(ctx, lib, x, y, yv, e, idx, min_sep, max_sep, nbins
     return out
 
 
+def vcorr_sums(x, y, dx, dy, edges, ctx=None):
+    """Raw per-bin sums (7, nbins) of the vector pair correlation over all pairs (utils.py:36-72)."""
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    x, y, dx, dy, edges = f64(x), f64(y), f64(dx), f64(dy), f64(edges)
+    nbins = len(edges) - 1
+    acc = np.zeros((7, nbins))
+    rc = lib.tgp_vcorr(ctx, ptr(x), ptr(y), ptr(dx), ptr(dy), len(x), ptr(edges), nbins, ptr(acc))
+    check(ctx, rc, "tgp_vcorr")
+    return acc
+
+
 def knn_mean(X0, y0, X, k=4, ctx=None):
     """Uniform mean of the k nearest table rows for every row of X (gp_interp.py:236-238)."""
     ctx = ctx or _lib.get_ctx()
