@@ -214,6 +214,10 @@ int tgp_dd_logdet_local(tgp_ctx *ctx, const double *d_Aloc, const int64_t *d_lof
                         double *d_out);
 int tgp_dd_info(tgp_ctx *ctx, int reset);                /* first non-PD pivot since the last reset */
 
+/* measurement hook: `reps` launches of the depth-512 trailing update over a whole packed Np x Np
+ * matrix (contents arbitrary), timed with HIP events on the context's stream */
+int tgp_debug_syrk_loop(tgp_ctx *ctx, double *d_A, int64_t Np, int reps, double *ms_per_launch,
+                        double *flops_per_launch);
 /* test hook: tile enumeration of the trailing update over T x T 128-tiles; fills (ti, tj)
  * for every block id (-1 = empty slot) and returns the grid size, or -1 if cap is too small */
 int tgp_debug_tilemap(int64_t T, int32_t *ti, int32_t *tj, int64_t cap);

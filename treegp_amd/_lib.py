@@ -61,6 +61,7 @@ SIGNATURES = {
     "tgp_d_potrf": (C.c_int, [_vp, _vp, _i64, _vp]),
     "tgp_d_potrs": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "tgp_d_unpack_lower": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    "tgp_debug_syrk_loop": (C.c_int, [_vp, _vp, _i64, C.c_int, _dp, _dp]),
     "tgp_debug_tilemap": (C.c_int, [_i64, _vp, _vp, _i64]),
     # multi-GPU tier
     "tgp_set_stream": (C.c_int, [_vp, _vp]),

@@ -126,9 +126,10 @@ __global__ __launch_bounds__(256, 2) void syrk_dist_kernel(double *Aloc, const i
 }
 
 inline void run_potrf128(hipStream_t st, double *A, int lda, double *W, int *info, int base) {
-    static const int variant = [] { const char *e = getenv("TGP_POTRF_VARIANT"); return e ? atoi(e) : 1; }();
+    static const int variant = [] { const char *e = getenv("TGP_POTRF_VARIANT"); return e ? atoi(e) : 2; }();
     if (variant == 0) potrf128_lds_kernel<<<1, 256, 0, st>>>(A, lda, W, info, base);
-    else potrf_v2::potrf128_kernel<<<1, 256, 0, st>>>(A, lda, W, info, base);
+    else if (variant == 1) potrf_v2::potrf128_kernel<false><<<1, 256, 0, st>>>(A, lda, W, info, base);
+    else potrf_v2::potrf128_kernel<true><<<1, 256, 0, st>>>(A, lda, W, info, base);
 }
 }  // namespace
 
@@ -328,6 +329,28 @@ int launch_syrk_dist(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_
     dim3 grid((unsigned)ncol, (unsigned)(2 * nloc));
     syrk_dist_kernel<<<grid, 256, 0, ctx->stream>>>(d_Aloc, d_loff, kpanel, G, g, cmax, d_P, col_lo);
     TGP_HIP(hipGetLastError());
+    return 0;
+}
+
+// measurement hook: the depth-512 trailing update of a whole Np x Np packed matrix (as after the first
+// panel pair), `reps` launches back to back on whatever d_A holds; average launch time by HIP events
+int tgp_debug_syrk_loop(tgp_ctx *ctx, double *d_A, int64_t Np, int reps, double *ms_per_launch, double *flops_per_launch) {
+    TGP_ARG(d_A && Np >= 4 * TGP_PW && Np % TGP_PW == 0 && reps > 0 && ms_per_launch && flops_per_launch);
+    TGP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int T2 = (int)((Np - (int64_t)TGP_PW * 2) / TGP_TB);
+    const double *P0 = d_A + panel_off(0, Np) + (int64_t)2 * TGP_PW * TGP_PW;
+    const double *P1 = d_A + panel_off(1, Np) + (int64_t)TGP_PW * TGP_PW;
+    launch_syrk<2>(st, d_A, Np, 2, T2, 0, P0, P1);
+    TGP_HIP(hipEventRecord(ctx->ev[0], st));
+    for (int r = 0; r < reps; ++r) launch_syrk<2>(st, d_A, Np, 2, T2, 0, P0, P1);
+    TGP_HIP(hipEventRecord(ctx->ev[1], st));
+    TGP_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    const double m = (double)T2 * TGP_TB;
+    *ms_per_launch = ms / reps;
+    *flops_per_launch = 2.0 * TGP_PW * m * (m + 1.0);
     return 0;
 }
 

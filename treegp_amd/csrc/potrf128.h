@@ -3,8 +3,12 @@
 // every panel (and, in the multi-GPU solve, of every rank), so it is built for latency:
 //
 //   phase 1, per 32-column block jb:
-//     wave 0   32x32 diagonal block in REGISTERS (lane i = row i): Gauss-Jordan elimination gives
-//              L_jj and D_j = L_jj^-1 in 32 steps with v_readlane broadcasts, no LDS, no barrier
+//     wave 0   32x32 diagonal block -> L_jj and D_j = L_jj^-1, no workgroup barrier:
+//              DIAG16 (default): two 16x16 halves, each by Gauss-Jordan in REGISTERS of one 16-lane DPP
+//              row (lane i = row i; every broadcast is a `row_newbcast` DPP move, no SGPR round trip,
+//              pivots through v_rsq_f64 + two Newton steps), glued by five 16x16x16 MFMA products
+//              through LDS inside the wave (L21 = A21 D11^T, A22 -= L21 L21^T, D21 = -D22 L21 D11);
+//              !DIAG16: the whole 32x32 block in registers with v_readlane broadcasts (3x slower)
 //     4 waves  rows below:   X = A D_j^T           (v_mfma_f64_16x16x4_f64, operands from LDS)
 //     4 waves  Schur update: T[r1:, r1:] -= X X^T  (lower 16x16 tiles)
 //   phase 2: blocked in-place inversion of the 4x4 block-lower matrix (W_ii = D_i,
@@ -12,6 +16,7 @@
 //
 // Explicit inverses only of well-conditioned diagonal blocks: cond(L_block) <= sqrt(cond(K)).
 #pragma once
+#include <utility>
 #include "tgp_internal.h"
 
 namespace potrf_v2 {
@@ -63,6 +68,55 @@ __device__ __forceinline__ void gauss_jordan32(double (&t)[32], double (&ls)[32]
     }
 }
 
+// ---- 16x16 Gauss-Jordan inside one DPP row -------------------------------------------------------------
+// lane N of every 16-lane row to all lanes of that row (gfx90a+ DPP control row_newbcast:N)
+template <int N>
+__device__ __forceinline__ double bcast16(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x150 + N, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x150 + N, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// 1/sqrt(p) to ~1 ulp: hardware estimate + two Newton steps (the pivot chain is the critical path)
+__device__ __forceinline__ double rsqrt_nr(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    const double hp = 0.5 * p;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = __builtin_fma(-hp * y, y, 0.5);
+        y = __builtin_fma(y, e, y);
+    }
+    return y;
+}
+template <int J, int C>
+__device__ __forceinline__ void gj16_elem(double (&t)[16], const double li, const double lm) {
+    if constexpr (C > J) t[C] = __builtin_fma(-lm, bcast16<C>(li), t[C]);            // L[C][J] lives in lane C
+    else if constexpr (C < J) t[C] = __builtin_fma(-lm, bcast16<J>(t[C]), t[C]);     // (L^-1)[J][C]: pivot row, lane J
+}
+template <int J, int... Cs>
+__device__ __forceinline__ void gj16_column(double (&t)[16], double (&ls)[16], const int i, int &fail,
+                                            std::integer_sequence<int, Cs...>) {
+    const double pj = bcast16<J>(t[J]);
+    if (!(pj > 0.0) && fail < 0) fail = J;
+    const double inv = rsqrt_nr(pj);
+    const double d = pj * inv;
+    const double li = t[J] * inv;                         // L[i][J] for the rows below the pivot
+    const double scale = (i == J) ? inv : 1.0;            // row J of L^-1: scale the pivot row
+    ((t[Cs] = (Cs < J) ? t[Cs] * scale : t[Cs]), ...);
+    const double lm = (i > J) ? li : 0.0;                 // rows <= J are finished: multiplier 0
+    (gj16_elem<J, Cs>(t, li, lm), ...);
+    t[J] = (i > J) ? -li * inv : ((i == J) ? inv : t[J]);
+    ls[J] = (i > J) ? li : ((i == J) ? d : 0.0);
+}
+template <int... Js>
+__device__ __forceinline__ void gj16_all(double (&t)[16], double (&ls)[16], const int i, int &fail,
+                                         std::integer_sequence<int, Js...> seq) {
+    (gj16_column<Js>(t, ls, i, fail, seq), ...);
+}
+// lanes 0..15 of a wave (lane i = row i): on exit t[c] = (L^-1)[i][c], ls[c] = L[i][c] for c <= i
+__device__ __forceinline__ void gauss_jordan16(double (&t)[16], double (&ls)[16], const int i, int &fail) {
+    gj16_all(t, ls, i, fail, std::make_integer_sequence<int, 16>{});
+}
+
 // acc += A[ra.., ca..ca+31] (16 x 32) * B[rb.., cb..cb+31]^T (16 x 32), both row-major in T
 __device__ __forceinline__ d4v mma_nt32(const double *T, int ra, int ca, int rb, int cb, d4v acc, int l15, int l4) {
 #pragma unroll
@@ -84,6 +138,44 @@ __device__ __forceinline__ d4v mma_nn32(const double *T, int ra, int ca, int rb,
     return acc;
 }
 
+// 16-deep products on the block-packed image (operands inside one 32x32 block)
+__device__ __forceinline__ d4v mma_nt16(const double *T, int ra, int ca, int rb, int cb, int l15, int l4) {
+    d4v acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T[taddr(ra + l15, ca + 4 * ks + l4)], T[taddr(rb + l15, cb + 4 * ks + l4)], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ d4v mma_nn16(const double *T, int ra, int ca, int rb, int cb, int l15, int l4) {
+    d4v acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T[taddr(ra + l15, ca + 4 * ks + l4)], T[taddr(rb + 4 * ks + l4, cb + l15)], acc, 0, 0, 0);
+    return acc;
+}
+
+// one 16x16 diagonal half at (q, q): lanes 0..15 factor it in registers; D replaces it in T, L goes to A
+__device__ __forceinline__ void diag16(double *T, double *A, int lda, int q, int lane, int *info, int base) {
+    if (lane < 16) {
+        const int i = lane;
+        double t[16], ls[16];
+#pragma clang loop unroll(full)
+        for (int c = 0; c < 16; ++c) {
+            const double v = T[taddr(q + i, q + c)];
+            t[c] = (c <= i) ? v : 0.0;
+        }
+        int fail = -1;
+        gauss_jordan16(t, ls, i, fail);
+        if (fail >= 0 && i == 0) atomicCAS(info, 0, base + q + fail + 1);
+#pragma clang loop unroll(full)
+        for (int c = 0; c < 16; ++c) {
+            T[taddr(q + i, q + c)] = (c <= i) ? t[c] : 0.0;
+            if (c <= i) A[(int64_t)(q + i) * lda + q + c] = ls[c];
+        }
+    }
+}
+
+template <bool DIAG16>
 __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, double *W, int *info, int base) {
     __shared__ double T[T_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,7 +196,27 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
 #pragma unroll 1
     for (int jb = 0; jb < 4; ++jb) {
         const int r0 = 32 * jb;
-        if (wave == 0 && lane < 32) {
+        if (DIAG16 && wave == 0) {
+            // whole wave, no workgroup barrier: LDS operations of one wave execute in program order
+            diag16(T, A, lda, r0, lane, info, base);
+            const d4v x = mma_nt16(T, r0 + 16, r0, r0, r0, l15, l4);                   // L21 = A21 D11^T
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                T[taddr(r0 + 16 + l4 + 4 * r, r0 + l15)] = x[r];
+                A[(int64_t)(r0 + 16 + l4 + 4 * r) * lda + r0 + l15] = x[r];
+            }
+            const d4v p = mma_nt16(T, r0 + 16, r0, r0 + 16, r0, l15, l4);              // A22 -= L21 L21^T
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[taddr(r0 + 16 + l4 + 4 * r, r0 + 16 + l15)] -= p[r];
+            diag16(T, A, lda, r0 + 16, lane, info, base);
+            const d4v s = mma_nn16(T, r0 + 16, r0, r0, r0, l15, l4);                   // S = L21 D11
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[taddr(r0 + 16 + l4 + 4 * r, r0 + l15)] = s[r];
+            const d4v w = mma_nn16(T, r0 + 16, r0 + 16, r0 + 16, r0, l15, l4);         // D21 = -D22 S
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[taddr(r0 + 16 + l4 + 4 * r, r0 + l15)] = -w[r];
+        }
+        if (!DIAG16 && wave == 0 && lane < 32) {
             const int i = lane;
             double t[32], ls[32];
 #pragma clang loop unroll(full)
