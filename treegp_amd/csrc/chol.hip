@@ -51,6 +51,45 @@ __global__ __launch_bounds__(256, 2) void syrk_trailing_kernel(double *Abase, in
                                                 NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
 }
 
+// Same update on the DTV tile (gemm_tile.h): NW = 4 -> 128 x 128 per workgroup (2 per CU), NW = 8 -> 256 x 128
+// (1 per CU, rows in 256-blocks: (bi, tj) with tj <= 2 bi + 1; the upper 128 x 128 block of a diagonal
+// 256-block is updated too -- storage nobody reads -- which wastes 1/T of the flops).
+template <int NW, int NSEG>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void syrk_dtv_kernel(double *Abase, int64_t Np, int ob, int T, int strip,
+                                                                           const double *P0, const double *P1) {
+    int ti, tj;          // ti in units of 32 NW rows
+    if constexpr (NW == 4) {
+        if (strip == 0) {
+            tilemap(blockIdx.x, T, ti, tj);
+            if (ti < 0) return;
+        } else {
+            tj = (int)(blockIdx.x % strip);
+            ti = (int)(blockIdx.x / strip);
+            if (ti < tj || ti >= T) return;
+        }
+    } else {
+        const int T2 = T >> 1;
+        if (strip == 0) {
+            const int64_t b = blockIdx.x;
+            const int half = (int)((b >> 3) & 1);
+            int J;
+            tilemap(((b >> 4) << 3) | (b & 7), T2, ti, J);       // low 3 bits (XCD) stay in place
+            if (ti < 0) return;
+            tj = 2 * J + half;
+        } else {
+            tj = (int)(blockIdx.x % strip);
+            ti = (int)(blockIdx.x / strip);
+            if (ti >= T2 || tj > 2 * ti + 1) return;
+        }
+    }
+    constexpr int RM = 32 * NW;
+    const int64_t pj = ob + (tj >> 1);
+    const int64_t I = (int64_t)TGP_PW * ob + (int64_t)RM * ti;
+    double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
+    const int64_t oa = (int64_t)ti * RM * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
+    gemm_tile_dtv<NW, TGP_PW, NSEG>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
+}
+
 // First-generation 128x128 diagonal-block kernel (kept for A/B runs, TGP_POTRF_VARIANT=0; the
 // default is potrf_v2::potrf128_kernel in potrf128.h).  In-LDS Gauss-Jordan: after step j, columns <= j of T hold L^-1 rows, columns > j the Schur
 // complement; column j of L goes to global memory as soon as it is final.
@@ -154,7 +193,18 @@ template <int NSEG>
 void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int strip, const double *P0, const double *P1,
                  unsigned long long *stamps = nullptr) {
     if (T <= 0) return;
+    // TGP_SYRK_TILE: 0 = 2x2-wave tile, operands through LDS | 4 / 8 = DTV tile with 4 / 8 waves (default 4: 69.3 TF on the bare depth-512 update, against 63.0 for tile 0 and 62.7 for tile 8)
+    static const int tile = [] { const char *e = getenv("TGP_SYRK_TILE"); return e ? atoi(e) : 4; }();
+    if (tile == 8 && (T & 1) == 0 && !stamps) {
+        const unsigned gs = strip == 0 ? (unsigned)(2 * tilemap_grid(T / 2)) : (unsigned)((int64_t)(T / 2) * strip);
+        syrk_dtv_kernel<8, NSEG><<<gs, 512, 0, st>>>(d_A, Np, ob, T, strip, P0, P1);
+        return;
+    }
     const unsigned gs = strip == 0 ? (unsigned)tilemap_grid(T) : (unsigned)((int64_t)T * strip);
+    if (tile == 4 && !stamps) {
+        syrk_dtv_kernel<4, NSEG><<<gs, 256, 0, st>>>(d_A, Np, ob, T, strip, P0, P1);
+        return;
+    }
     syrk_trailing_kernel<TileDefault, NSEG><<<gs, 256, 0, st>>>(d_A, Np, ob, T, strip, P0, P1, stamps);
 }
 }  // namespace

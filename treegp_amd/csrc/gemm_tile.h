@@ -372,3 +372,120 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
         stamps[3] = tr2 - tr1;
     }
 }
+
+
+// ---- trailing-update tile, second generation ("DTV"): A straight into VGPRs, only B through LDS ----------
+// C (32 NW x 128) -= sum over NSEG operand pairs of A (32 NW x KDEPTH) B (128 x KDEPTH)^T, everything in
+// 256-wide panels (ld 256).  NW waves stacked along M: wave w owns rows 32w .. 32w+31 and all 128 columns
+// (2 x 8 MFMA tiles, 128 accumulator VGPRs).  Its A rows are private, so A fragments are loaded from global
+// memory directly in MFMA layout (double-buffered in registers) and never touch LDS; B (shared by all waves)
+// is staged through LDS once per workgroup.  Measured motive: on the 2x2-wave tile above the VGPR->LDS
+// staging stores alone cost 7 % (63.0 -> 67.7 TF with them removed); here they are 1/2 (NW = 4) or 1/4
+// (NW = 8, 256 x 128 per workgroup) of that per flop.
+// k assignment: lane (r, kq) handles k = 8h + 2kq + {0, 1} in MFMA steps 2h, 2h+1, so both the direct A
+// loads and the B fragment reads are 16-byte accesses (B rows padded to 18 doubles: conflict-free b128).
+template <int NW, int KDEPTH, int NSEG>
+__device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double *b_ptr, double *c_ptr,
+                                              const double *a1_ptr, const double *b1_ptr) {
+    constexpr int LD = TGP_PW;
+    constexpr int LSB = 18;
+    constexpr int BPT = 16 / NW;                    // B staging pieces (16 B) per thread and chunk
+    constexpr int BROWS = 8 * NW;                   // rows covered by one staging pass
+    __shared__ __attribute__((aligned(16))) double ldsB[2][128 * LSB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    const __amdgpu_buffer_rsrc_t ra0 = tile_rsrc(a_ptr, 32 * NW * LD * 8);
+    const __amdgpu_buffer_rsrc_t rb0 = tile_rsrc(b_ptr, 128 * LD * 8);
+    const __amdgpu_buffer_rsrc_t ra1 = tile_rsrc(NSEG > 1 ? a1_ptr : a_ptr, 32 * NW * LD * 8);
+    const __amdgpu_buffer_rsrc_t rb1 = tile_rsrc(NSEG > 1 ? b1_ptr : b_ptr, 128 * LD * 8);
+    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(c_ptr, 32 * NW * LD * 8);
+    const int va = ((32 * w + l15) * LD + 2 * l4) * 8;          // A: row of m-tile 0, k-pair kq
+    const int srow = tid >> 3, kp = (tid & 7) * 2;
+    const int vb = (srow * LD + kp) * 8;                        // B staging piece
+    const int vc = ((32 * w + l4) * LD + l15) * 8;              // C fragment: col = lane & 15, row = (lane >> 4) + 4r
+    const int fb = l15 * LSB + 2 * l4;                          // B fragment read
+
+    double2 areg[2][2][2];                                      // [set][m][h]
+    double2 rbst[BPT];
+    auto load_a = [&](double2 (&dst)[2][2], __amdgpu_buffer_rsrc_t src, int k0) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) dst[m][h] = buf_ld2(src, va, (m * 16 * LD + k0 + 8 * h) * 8);
+    };
+    auto load_b = [&](__amdgpu_buffer_rsrc_t src, int k0) {
+#pragma unroll
+        for (int s = 0; s < BPT; ++s) rbst[s] = buf_ld2(src, vb, (s * BROWS * LD + k0) * 8);
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < BPT; ++s) *reinterpret_cast<double2 *>(&ldsB[buf][(srow + BROWS * s) * LSB + kp]) = rbst[s];
+    };
+    load_a(areg[0], ra0, 0);
+    load_b(rb0, 0);
+
+    d4 acc[2][8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][n][r] = buf_ld1(rc, vc, ((m * 16 + 4 * r) * LD + n * 16) * 8);
+    store_b(0);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[m][n] = -acc[m][n];
+
+    constexpr int cps = KDEPTH / KB;
+    constexpr int nchunk = NSEG * cps;
+    static_assert(nchunk % 2 == 0, "chunks are processed in register-set pairs");
+    auto step = [&](const int c, double2 (&cur)[2][2], double2 (&nxt)[2][2]) {
+        const int buf = c & 1;
+        const bool more = (c + 1 < nchunk);
+        if (more) {
+            const int cn = c + 1;
+            const int k0 = (cn % cps) * KB;
+            const bool second = NSEG > 1 && cn >= cps;           // wave-uniform
+            load_a(nxt, second ? ra1 : ra0, k0);
+            load_b(second ? rb1 : rb0, k0);
+        }
+        const double *Bs = ldsB[buf];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double2 bf[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) bf[n] = *reinterpret_cast<const double2 *>(&Bs[fb + n * 16 * LSB + 8 * h]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m][h].x, bf[n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m][h].y, bf[n].y, acc[m][n], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // staging stores (they wait for the loads) behind the MFMAs
+        if (more) store_b(buf ^ 1);
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int c = 0; c < nchunk; c += 2) {
+        step(c, areg[0], areg[1]);
+        step(c + 1, areg[1], areg[0]);
+    }
+
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf_st1(-acc[m][n][r], rc, vc, ((m * 16 + 4 * r) * LD + n * 16) * 8);
+}
