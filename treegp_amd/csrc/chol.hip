@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void syrk_dist_kernel(double *Aloc, const i
     const double *b = P + (((int64_t)rj * cmax + idxj) * TGP_PW + (gtj & 1) * TGP_TB) * TGP_PW;
     double *c = Aloc + loff[bj] + (((bi - dist_first_ge(bj, g, G)) / G) * TGP_PW + (lt & 1) * TGP_TB) * TGP_PW +
                 (gtj & 1) * TGP_TB;
-    gemm_tile_128<1, TGP_PW, TGP_PW>(a, b, c);
+    gemm_tile_dtv<4, TGP_PW, 1>(a, b, c, nullptr, nullptr);
 }
 
 inline void run_potrf128(hipStream_t st, double *A, int lda, double *W, int *info, int base) {

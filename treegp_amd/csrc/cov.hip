@@ -59,15 +59,15 @@ __global__ __launch_bounds__(256, 2) void cov_update_kernel(double *Bt, int64_t 
     const double *a = Bt + p * Mp * TGP_PW + ti * TGP_TB * TGP_PW + (kb & 1) * TGP_TB;
     const double *b = A + panel_off(p, Np) + (c * TGP_TB - p * TGP_PW) * TGP_PW + (kb & 1) * TGP_TB;
     double *cc = Bt + (c >> 1) * Mp * TGP_PW + ti * TGP_TB * TGP_PW + (c & 1) * TGP_TB;
-    gemm_tile_128<1, TGP_PW, TGP_TB>(a, b, cc);
+    gemm_tile_dtv<4, TGP_TB, 1>(a, b, cc, nullptr, nullptr);
 }
 
 // C(ti, tj) -= sum over all panels of Bt[ti] Bt[tj]^T        (C in the same panel layout, Mp rows)
 __global__ __launch_bounds__(256, 2) void cov_syrk_kernel(double *Cpm, const double *Bt, int64_t Mp, int nP) {
     const int64_t ti = blockIdx.x, tj = blockIdx.y;
     double *c = Cpm + (tj >> 1) * Mp * TGP_PW + ti * TGP_TB * TGP_PW + (tj & 1) * TGP_TB;
-    gemm_tile_128<1, TGP_PW, TGP_PW, TileDefault, 0>(Bt + ti * TGP_TB * TGP_PW, Bt + tj * TGP_TB * TGP_PW, c, nullptr, nullptr,
-                                                     nullptr, nP, Mp * TGP_PW, Mp * TGP_PW);
+    gemm_tile_dtv<4, TGP_PW, 0>(Bt + ti * TGP_TB * TGP_PW, Bt + tj * TGP_TB * TGP_PW, c, nullptr, nullptr, nP, Mp * TGP_PW,
+                                Mp * TGP_PW);
 }
 }  // namespace
 

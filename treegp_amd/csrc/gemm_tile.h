@@ -384,9 +384,11 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
 // (NW = 8, 256 x 128 per workgroup) of that per flop.
 // k assignment: lane (r, kq) handles k = 8h + 2kq + {0, 1} in MFMA steps 2h, 2h+1, so both the direct A
 // loads and the B fragment reads are 16-byte accesses (B rows padded to 18 doubles: conflict-free b128).
+// NSEG = 0: run-time number of operand pairs, pair s at a_ptr + s * seg_stride_a / b_ptr + s * seg_stride_b.
 template <int NW, int KDEPTH, int NSEG>
 __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double *b_ptr, double *c_ptr,
-                                              const double *a1_ptr, const double *b1_ptr) {
+                                              const double *a1_ptr, const double *b1_ptr, int nseg_rt = 1,
+                                              int64_t seg_stride_a = 0, int64_t seg_stride_b = 0) {
     constexpr int LD = TGP_PW;
     constexpr int LSB = 18;
     constexpr int BPT = 16 / NW;                    // B staging pieces (16 B) per thread and chunk
@@ -443,8 +445,8 @@ __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double 
         for (int n = 0; n < 8; ++n) acc[m][n] = -acc[m][n];
 
     constexpr int cps = KDEPTH / KB;
-    constexpr int nchunk = NSEG * cps;
-    static_assert(nchunk % 2 == 0, "chunks are processed in register-set pairs");
+    static_assert(cps % 2 == 0, "chunks are processed in register-set pairs");
+    const int nchunk = (NSEG > 0 ? NSEG : nseg_rt) * cps;
     auto step = [&](const int c, double2 (&cur)[2][2], double2 (&nxt)[2][2]) {
         const int buf = c & 1;
         const bool more = (c + 1 < nchunk);
@@ -452,8 +454,14 @@ __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double 
             const int cn = c + 1;
             const int k0 = (cn % cps) * KB;
             const bool second = NSEG > 1 && cn >= cps;           // wave-uniform
-            load_a(nxt, second ? ra1 : ra0, k0);
-            load_b(second ? rb1 : rb0, k0);
+            __amdgpu_buffer_rsrc_t sa = second ? ra1 : ra0, sb = second ? rb1 : rb0;
+            if constexpr (NSEG == 0) {
+                const int seg = cn / cps;
+                sa = tile_rsrc(a_ptr + seg * seg_stride_a, 32 * NW * LD * 8);
+                sb = tile_rsrc(b_ptr + seg * seg_stride_b, 128 * LD * 8);
+            }
+            load_a(nxt, sa, k0);
+            load_b(sb, k0);
         }
         const double *Bs = ldsB[buf];
 #pragma unroll
