@@ -24,6 +24,26 @@ __global__ __launch_bounds__(256, 2) void gemm_col_kernel(const double *A, const
     gemm_tile_128<MODE, LDB, TGP_TB>(A + t * 128 * TGP_PW, B, C + t * 128 * TGP_PW);
 }
 
+// The same two jobs on the latency tile (nt_small_tile): 16-row slices, for steps with only a few tiles.
+template <int MODE, int LDB>
+__global__ __launch_bounds__(256) void gemm_col_small_kernel(const double *A, const double *B, double *C) {
+    const int64_t o = (int64_t)blockIdx.x * 16 * TGP_PW;
+    nt_small_tile<MODE, TGP_TB, 1>(A + o, TGP_PW, B, LDB, C + o, TGP_PW, nullptr, nullptr);
+}
+template <int NSEG>
+__global__ __launch_bounds__(256) void syrk_small_kernel(double *Abase, int64_t Np, int ob, int T, const double *P0,
+                                                         const double *P1) {
+    const int ri = blockIdx.x;                   // 16-row slice of the trailing matrix
+    const int tj = blockIdx.y;                   // 128-column tile
+    if (tj > (ri >> 3) || (ri >> 3) >= T) return;
+    const int64_t pj = ob + (tj >> 1);
+    const int64_t I = (int64_t)TGP_PW * ob + 16 * (int64_t)ri;
+    double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
+    const int64_t oa = (int64_t)ri * 16 * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
+    nt_small_tile<1, TGP_PW, NSEG>(P0 + oa, TGP_PW, P0 + obb, TGP_PW, C, TGP_PW, NSEG > 1 ? P1 + oa : nullptr,
+                                   NSEG > 1 ? P1 + obb : nullptr);
+}
+
 // Trailing update C(ti, tj) -= sum over NSEG panels of P[ti] P[tj]^T on the lower-triangular tile set
 // of the trailing matrix that starts at block `ob` (256-row blocks).  P0 / P1 point at the row of
 // the factored panel(s) that corresponds to the first trailing row.
@@ -178,14 +198,22 @@ void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_inf
     double *W1 = W0 + TGP_TB * TGP_TB;
     double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
     const int r1 = (int)((mk - TGP_TB) / TGP_TB);
+    // few row blocks: 16-row slices spread a block over 8 workgroups (latency); many: 128-row tiles (throughput)
+    static const int small_rows = [] { const char *e = getenv("TGP_SMALL_ROWS"); return e ? atoi(e) : 24; }();
     run_potrf128(st, Pk, TGP_PW, W0, d_info, base);
-    gemm_col_kernel<0, TGP_TB><<<r1, 256, 0, st>>>(R1, W0, R1);
-    gemm_col_kernel<1, TGP_PW><<<r1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
+    if (r1 <= small_rows) {
+        gemm_col_small_kernel<0, TGP_TB><<<r1 * 8, 256, 0, st>>>(R1, W0, R1);
+        gemm_col_small_kernel<1, TGP_PW><<<r1 * 8, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
+    } else {
+        gemm_col_kernel<0, TGP_TB><<<r1, 256, 0, st>>>(R1, W0, R1);
+        gemm_col_kernel<1, TGP_PW><<<r1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
+    }
     run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, d_info, base + TGP_TB);
     const int r2 = (int)((mk - TGP_PW) / TGP_TB);
     if (r2 > 0) {
         double *R2 = Pk + (int64_t)TGP_PW * TGP_PW + TGP_TB;    // row 256, column 128
-        gemm_col_kernel<0, TGP_TB><<<r2, 256, 0, st>>>(R2, W1, R2);
+        if (r2 <= small_rows) gemm_col_small_kernel<0, TGP_TB><<<r2 * 8, 256, 0, st>>>(R2, W1, R2);
+        else gemm_col_kernel<0, TGP_TB><<<r2, 256, 0, st>>>(R2, W1, R2);
     }
 }
 
@@ -193,6 +221,12 @@ template <int NSEG>
 void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int strip, const double *P0, const double *P1,
                  unsigned long long *stamps = nullptr) {
     if (T <= 0) return;
+    static const int small_t = [] { const char *e = getenv("TGP_SMALL_T"); return e ? atoi(e) : 8; }();
+    if (T <= small_t && !stamps) {
+        const int cols = strip == 0 ? T : (strip < T ? strip : T);
+        syrk_small_kernel<NSEG><<<dim3((unsigned)(T * 8), (unsigned)cols), 256, 0, st>>>(d_A, Np, ob, T, P0, P1);
+        return;
+    }
     // TGP_SYRK_TILE: 0 = 2x2-wave tile, operands through LDS | 4 / 8 = DTV tile with 4 / 8 waves (default 4: 69.3 TF on the bare depth-512 update, against 63.0 for tile 0 and 62.7 for tile 8)
     static const int tile = [] { const char *e = getenv("TGP_SYRK_TILE"); return e ? atoi(e) : 4; }();
     if (tile == 8 && (T & 1) == 0 && !stamps) {

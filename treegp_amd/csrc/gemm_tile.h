@@ -497,3 +497,57 @@ __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double 
 #pragma unroll
             for (int r = 0; r < 4; ++r) buf_st1(-acc[m][n][r], rc, vc, ((m * 16 + 4 * r) * LD + n * 16) * 8);
 }
+
+
+// ---- latency tile for small problems ----------------------------------------------------------------------
+// One workgroup = 16 rows x 128 columns of C, wave w the columns 32w .. 32w+31 (1 x 2 MFMA tiles, two
+// independent accumulator chains).  No LDS: A (16 x K) and B (128 x K) fragments come straight from global
+// memory / L2 in MFMA layout with the k-permuted 16-byte loads of the DTV tile.  8x the L2 traffic per flop
+// of the 128 x 128 tiles, but a 128 x 128 x K product becomes 32 waves' worth of parallel work instead of
+// one workgroup: what a factorisation with only a few tiles per step needs (N below a few thousand).
+// The barrier before the epilogue makes in-place use (C aliasing A) safe, as in the panel solve.
+template <int MODE, int KDEPTH, int NSEG>
+__device__ __forceinline__ void nt_small_tile(const double *a, int lda, const double *b, int ldb, double *c, int ldc,
+                                              const double *a1, const double *b1) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    constexpr int CH = KDEPTH / KB;
+    constexpr int UN = CH < 4 ? CH : 4;                 // chunks whose loads are issued together
+#pragma unroll
+    for (int seg = 0; seg < NSEG; ++seg) {
+        const double *ap = (seg ? a1 : a) + (int64_t)l15 * lda + 2 * l4;
+        const double *bp = (seg ? b1 : b) + (int64_t)(32 * w + l15) * ldb + 2 * l4;
+#pragma unroll 1
+        for (int c0 = 0; c0 < CH; c0 += UN) {
+            double2 af[UN][2], bf[UN][2][2];
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = (c0 + u) * KB + 8 * h;
+                    af[u][h] = *reinterpret_cast<const double2 *>(ap + k);
+                    bf[u][0][h] = *reinterpret_cast<const double2 *>(bp + k);
+                    bf[u][1][h] = *reinterpret_cast<const double2 *>(bp + (int64_t)16 * ldb + k);
+                }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u][h].x, bf[u][0][h].x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u][h].x, bf[u][1][h].x, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u][h].y, bf[u][0][h].y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u][h].y, bf[u][1][h].y, acc[1], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double *p = c + (int64_t)(l4 + 4 * r) * ldc + 32 * w + 16 * n + l15;
+            if constexpr (MODE == 1) *p = *p - acc[n][r];
+            else *p = acc[n][r];
+        }
+}
