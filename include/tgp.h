@@ -202,6 +202,12 @@ int tgp_dd_trsm(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int64_t Np,
  * the next panel, updated first so that its factorisation overlaps the rest (look-ahead)          */
 int tgp_dd_update(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
                   const double *d_gathered, int cmax, int col_lo, int col_hi);
+/* the same after the PAIR of panels (kpanel, kpanel+1) in one pass of depth 512: gathered0 / gathered1 are
+ * the all-gathered panels kpanel (blocks > kpanel, cmax0 per rank) and kpanel+1 (blocks > kpanel+1, cmax1);
+ * tile columns col_lo..col_hi count from block kpanel+2.                                              */
+int tgp_dd_update2(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
+                   const double *d_gathered0, int cmax0, const double *d_gathered1, int cmax1, int col_lo,
+                   int col_hi);
 /* block-row-cyclic triangular solves (scipy cho_solve, gp_interp.py:182) */
 int tgp_dd_fwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_yk);
 int tgp_dd_fwd_update(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int64_t Np, int kb, int G, int g,

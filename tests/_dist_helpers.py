@@ -130,7 +130,33 @@ class NumpyLocalOps(object):
             out[i * BLK * BLK:(i + 1) * BLK * BLK] = torch.from_numpy(self.rows[b][:, k * BLK:(k + 1) * BLK].ravel())
         return out
 
-    def update(self, k, gathered, cmax, col_lo=0, col_hi=-1):
+    def update2(self, k, gathered0, cmax0, gathered1, cmax1, col_lo=0, col_hi=-1):
+        """pair (k, k+1): the blocks > k+1 get both panels' contributions; columns count from block k+2"""
+        G = self.G
+        P0, P1 = gathered0.numpy(), gathered1.numpy()
+        ncol = 2 * (self.nB - k - 2)
+        if col_hi < 0 or col_hi > ncol:
+            col_hi = ncol
+
+        def blk(P, cmax, first, b):
+            r = b % G
+            idx = (b - first_ge(first, r, G)) // G
+            o = (r * cmax + idx) * BLK * BLK
+            return P[o:o + BLK * BLK].reshape(BLK, BLK)
+        for bi in self.blocks:
+            if bi <= k + 1:
+                continue
+            A0, A1 = blk(P0, cmax0, k + 1, bi), blk(P1, cmax1, k + 2, bi)
+            for bj in range(k + 2, bi + 1):
+                B0, B1 = blk(P0, cmax0, k + 1, bj), blk(P1, cmax1, k + 2, bj)
+                for half in (0, 1):
+                    tcol = 2 * (bj - k - 2) + half
+                    if col_lo <= tcol < col_hi:
+                        c0 = bj * BLK + half * 128
+                        s = slice(half * 128, (half + 1) * 128)
+                        self.rows[bi][:, c0:c0 + 128] -= A0 @ B0[s, :].T + A1 @ B1[s, :].T
+
+    def update(self, k, gathered, cmax, col_lo=0, col_hi=-1, side=False):
         G = self.G
         P = gathered.numpy()
         ncol = 2 * (self.nB - k - 1)

@@ -77,6 +77,12 @@ int tgp_dd_update(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t N
     return launch_syrk_dist(ctx, d_Aloc, d_loff, Np, kpanel, G, g, d_gathered, cmax, col_lo, col_hi);
 }
 
+int tgp_dd_update2(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
+                   const double *d_gathered0, int cmax0, const double *d_gathered1, int cmax1, int col_lo, int col_hi) {
+    TGP_ARG(d_Aloc && d_loff && d_gathered0 && d_gathered1 && cmax0 >= 0 && cmax1 >= 0);
+    return launch_syrk_dist2(ctx, d_Aloc, d_loff, Np, kpanel, G, g, d_gathered0, cmax0, d_gathered1, cmax1, col_lo, col_hi);
+}
+
 // forward sweep, block kb (owner): y_k (256) <- L_kk^-1 y_k
 int tgp_dd_fwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_yk) {
     const double *W0 = d_W + (int64_t)(2 * kb) * TGP_TB * TGP_TB;

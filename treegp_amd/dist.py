@@ -201,9 +201,16 @@ class HipLocalOps(object):
         o = int(self.loff[k]) + skip * BLK
         return self.A[o:o + cmax * BLK * BLK]
 
-    def update(self, k, gathered, cmax, col_lo=0, col_hi=-1):
-        self._chk(self.lib.tgp_dd_update(self.ctx, self._p(self.A), self._p(self.d_loff), self.Np, k, self.G, self.g,
-                                         self._p(gathered), cmax, col_lo, col_hi), "tgp_dd_update")
+    def update(self, k, gathered, cmax, col_lo=0, col_hi=-1, side=False):
+        ctx = self.ctx_side if side else self.ctx
+        self._chk(self.lib.tgp_dd_update(ctx, self._p(self.A), self._p(self.d_loff), self.Np, k, self.G, self.g,
+                                         self._p(gathered), cmax, col_lo, col_hi), "tgp_dd_update", ctx)
+
+    def update2(self, k, gathered0, cmax0, gathered1, cmax1, col_lo=0, col_hi=-1):
+        """after the pair of panels (k, k+1), depth 512; tile columns count from block k+2"""
+        self._chk(self.lib.tgp_dd_update2(self.ctx, self._p(self.A), self._p(self.d_loff), self.Np, k, self.G, self.g,
+                                          self._p(gathered0), cmax0, self._p(gathered1), cmax1, col_lo, col_hi),
+                  "tgp_dd_update2")
 
     def info(self):
         a = int(self.lib.tgp_dd_info(self.ctx, 1))
@@ -244,8 +251,8 @@ class DistributedCholesky(object):
         self.G, self.g = comm.size, comm.rank
         assert (ops.G, ops.g) == (self.G, self.g)
         self.nB, self.Np = ops.nB, ops.Np
-        self.gathered = ops.empty(max(self.G * ops.cmax0, 1) * BLK * BLK)
-        self.gathered2 = ops.empty(max(self.G * ops.cmax0, 1) * BLK * BLK)    # look-ahead double buffer
+        # all-gathered panels: two pairs (the pair the bulk update reads, the pair being produced underneath it)
+        self.gathered = [ops.empty(max(self.G * ops.cmax0, 1) * BLK * BLK) for _ in range(4)]
         self.timer = timer            # optional callable(): returns an event-like with .record()/.elapsed_time()
         self.update_ms = 0.0          # local trailing-update kernel time of the last factorize()
         self.update_flops = 0.0       # algorithmic flops of this rank's share
@@ -261,14 +268,17 @@ class DistributedCholesky(object):
         return 2.0 * BLK * elems
 
     def factorize(self):
-        """Right-looking factorisation with look-ahead on two streams.  Main stream: the two tile
-        columns of panel k+1 first (strip), then the bulk of update k.  Side stream, started as soon
-        as the strip is done: diagonal block of panel k+1 on its owner, broadcast, local solves, and
-        the (asynchronous) all-gather of panel k+1 -- all of it underneath the bulk update."""
+        """Right-looking factorisation, panels taken in PAIRS, look-ahead on two streams.
+
+        Side stream (high priority), for the pair (k, k+1): diagonal block of panel k on its owner,
+        broadcast, local solves, all-gather of panel k; depth-256 update of panel k+1's two tile
+        columns with it; then the same chain for panel k+1.  Main stream: U2a, the four tile columns of
+        the NEXT pair with both gathered panels (depth 512), after which the side stream may start on
+        that pair; then U2b, the bulk of the trailing matrix in one depth-512 pass, concurrent with it.
+        Halves the C traffic and the per-tile prologues of the bulk update (as the single-GPU driver does)."""
         ops, comm, G, g, nB = self.ops, self.comm, self.G, self.g, self.nB
         events = []
         self.update_flops, self.update_launches = 0.0, 0
-        bufs = [self.gathered, self.gathered2]
 
         def factor_and_gather(k, buf):
             """panel k on the side stream: diagonal block on its owner, broadcast, local solves, all-gather"""
@@ -284,33 +294,45 @@ class DistributedCholesky(object):
             send = ops.panel_send_view(k, cmax)
             return comm.all_gather_start(buf[:G * cmax * BLK * BLK], send), cmax
 
-        def timed_update(k, buf, cmax, lo, hi):
+        def side_pair(k, bufs):
+            """panels k and k+1 (where they exist) on the side stream; returns their gather handles"""
+            w0, c0 = factor_and_gather(k, bufs[0])
+            w1, c1 = None, 0
+            if k + 1 < nB:
+                w0.wait()                                        # side stream: panel k is on every rank
+                ops.update(k, bufs[0], c0, 0, 2, side=True)      # panel k+1's columns, depth 256
+                w1, c1 = factor_and_gather(k + 1, bufs[1])
+            return (w0, c0), (w1, c1)
+
+        def timed(fn):
             if self.timer is not None:
                 e0, e1 = self.timer(), self.timer()
                 e0.record()
-                ops.update(k, buf, cmax, lo, hi)
+                fn()
                 e1.record()
                 events.append((e0, e1))
             else:
-                ops.update(k, buf, cmax, lo, hi)
+                fn()
 
         ops.side_wait_main()                                     # K build (main) precedes panel 0
         with ops.on_side():
-            work, cmax = factor_and_gather(0, bufs[0])
-        for k in range(nB - 1):
-            cur = bufs[k & 1]
-            work.wait()                                          # main stream: panel k is on every rank
-            ops.update(k, cur, cmax, 0, 2)                       # columns of panel k+1 first
+            (w0, c0), (w1, c1) = side_pair(0, self.gathered[0:2])
+        k = 0
+        while k + 2 < nB:
+            cur = self.gathered[(k & 2):(k & 2) + 2]
+            nxt = self.gathered[2 - (k & 2):4 - (k & 2)]
+            w0.wait()
+            w1.wait()                                            # main stream: both panels are on every rank
+            timed(lambda: ops.update2(k, cur[0], c0, cur[1], c1, 0, 4))          # U2a: the next pair's columns
             ops.side_wait_main()
             with ops.on_side():
-                nwork, ncmax = factor_and_gather(k + 1, bufs[(k + 1) & 1])
-            timed_update(k, cur, cmax, 2, -1)                    # the bulk, concurrent with the side chain
-            fl = self._local_update_flops(k)
-            if fl > 0:
-                self.update_flops += fl
-                self.update_launches += 1
-            work, cmax = nwork, ncmax
-        ops.main_wait_side()                                     # last panel's chain has no gather to wait on
+                (n0, nc0), (n1, nc1) = side_pair(k + 2, nxt)
+            timed(lambda: ops.update2(k, cur[0], c0, cur[1], c1, 4, -1))         # U2b: the bulk
+            self.update_flops += 2.0 * self._local_update_flops(k + 1)
+            self.update_launches += 2
+            (w0, c0), (w1, c1) = (n0, nc0), (n1, nc1)
+            k += 2
+        ops.main_wait_side()                                     # the last chain has no gather to wait on
         # any rank's failure is everybody's failure; report the smallest failing index
         big = 1e18
         mine = ops.info()                                        # synchronises the stream
