@@ -34,55 +34,44 @@ class GPInterpolation(object):
     def __init__(self, kernel="RBF(1)", optimizer="two-pcf", normalize=True, p0=[3000.0, 0.0, 0.0],
                  white_noise=0.0, n_neighbors=4, average_fits=None, indice_meanify=None, nbins=20,
                  min_sep=None, max_sep=None):
-        self.normalize = normalize
-        self.optimizer = optimizer
-        self.white_noise = white_noise
-        self.n_neighbors = n_neighbors
-        self.nbins = nbins
-        self.min_sep = min_sep
-        self.max_sep = max_sep
-        self.robust_fit = (self.optimizer == "anisotropic")
+        self.normalize, self.optimizer, self.white_noise = normalize, optimizer, white_noise
+        self.n_neighbors, self.indice_meanify = n_neighbors, indice_meanify
+        self.nbins, self.min_sep, self.max_sep = nbins, min_sep, max_sep
+        self.robust_fit = optimizer == "anisotropic"       # the 2-D fit of (size, g1, g2) goes with the TwoD pcf
         self.p0_robust_fit = p0
-        self.indice_meanify = indice_meanify
 
         if not isinstance(kernel, str):
             raise TypeError("kernel should be a string a list or a numpy.ndarray of string")
         self.kernel_template = eval_kernel(kernel)
 
-        if self.optimizer not in ["anisotropic", "two-pcf", "log-likelihood", "none"]:
+        if optimizer not in ("anisotropic", "two-pcf", "log-likelihood", "none"):
             raise ValueError("Only anisotropic, two-pcf, log-likelihood and none are supported for optimizer. "
-                             "Current value: %s" % (self.optimizer))
+                             "Current value: %s" % (optimizer))
 
+        # mean function: the meanify table (gp_interp.py:97-107, read there with fitsio) or none yet
+        self._X0 = self._y0 = None
         if average_fits is not None:
-            # gp_interp.py:97-102 (fitsio.read(...)["COORDS0"][0]); fitsio is replaced by a
-            # minimal BINTABLE reader so the path has no dependency the image lacks
-            average = read_bintable_row(average_fits)
-            X0 = average["COORDS0"]
-            y0 = average["PARAMS0"]
-        else:
-            X0 = None
-            y0 = None
-        self._X0 = X0
-        self._y0 = y0
+            table = read_bintable_row(average_fits)
+            self._X0, self._y0 = table["COORDS0"], table["PARAMS0"]
         self._alpha = None
         self._factor = None
 
     # -- hyper-parameter fit ---------------------------------------------------------------------
     def _fit(self, kernel, X, y, y_err):
-        """gp_interp.py:111-141."""
+        """Run the requested optimiser on the (mean-subtracted) data and return the fitted kernel; the
+        cached solution is dropped either way (gp_interp.py:111-141)."""
         from .two_pcf import two_pcf
         from .log_likelihood import log_likelihood
         self._drop_solution()
-        if self.optimizer != "none":
-            if self.optimizer in ["two-pcf", "anisotropic"]:
-                self._optimizer = two_pcf(X, y, y_err, self.min_sep, self.max_sep, nbins=self.nbins,
-                                          anisotropic=(self.optimizer == "anisotropic"),
-                                          robust_fit=self.robust_fit, p0=self.p0_robust_fit)
-                kernel = self._optimizer.optimizer(kernel)
-            if self.optimizer == "log-likelihood":
-                self._optimizer = log_likelihood(X, y, y_err)
-                kernel = self._optimizer.optimizer(kernel)
-        return kernel
+        if self.optimizer in ("two-pcf", "anisotropic"):
+            self._optimizer = two_pcf(X, y, y_err, self.min_sep, self.max_sep, nbins=self.nbins,
+                                      anisotropic=(self.optimizer == "anisotropic"),
+                                      robust_fit=self.robust_fit, p0=self.p0_robust_fit)
+        elif self.optimizer == "log-likelihood":
+            self._optimizer = log_likelihood(X, y, y_err)
+        else:
+            return kernel
+        return self._optimizer.optimizer(kernel)
 
     def _drop_solution(self):
         self._alpha = None
@@ -93,17 +82,12 @@ class GPInterpolation(object):
     # -- prediction ------------------------------------------------------------------------------
     def predict(self, X, return_cov=False):
         """Interpolated values (and optionally the posterior covariance) at X (n_samples, 1 or 2).
-        gp_interp.py:143-166."""
-        y_init = copy.deepcopy(self._y)
-        y_err = copy.deepcopy(self._y_err)
-        y_interp, y_cov = self.return_gp_predict(y_init - self._mean - self._spatial_average, self._X, X,
-                                                 self.kernel, y_err=y_err, return_cov=return_cov)
-        y_interp = y_interp.T
-        spatial_average = self._build_average_meanify(X)
-        y_interp += self._mean + spatial_average
-        if return_cov:
-            return y_interp, y_cov
-        return y_interp
+        gp_interp.py:143-166: the GP acts on y - mean - mean function; both are added back."""
+        residual = self._y - self._mean - self._spatial_average
+        y_star, y_cov = self.return_gp_predict(residual, self._X, X, self.kernel, y_err=self._y_err,
+                                               return_cov=return_cov)
+        y_star = y_star + (self._mean + self._build_average_meanify(X))
+        return (y_star, y_cov) if return_cov else y_star
 
     def return_gp_predict(self, y, X1, X2, kernel, y_err, return_cov=False):
         """gp_interp.py:168-194 on the GPU: fused K build + Cholesky + solve (tgp_gp_solve), fused
@@ -126,33 +110,26 @@ class GPInterpolation(object):
 
     # -- data ------------------------------------------------------------------------------------
     def initialize(self, X, y, y_err=None):
-        """gp_interp.py:196-227."""
+        """Take the data: coordinates (n, 1 or 2), values, errors (zeros when None).  gp_interp.py:196-227:
+        a fresh copy of the kernel template, white noise added to the errors in quadrature, the mean taken
+        of y minus the mean function, any cached solution dropped."""
         self.kernel = copy.deepcopy(self.kernel_template)
-        self._X = X
-        self._y = y
-        if y_err is None:
-            y_err = np.zeros_like(y)
-        self._y_err = y_err
-
+        self._X, self._y = X, y
+        sigma = np.zeros_like(y) if y_err is None else y_err
         if self._X0 is None:
-            self._X0 = np.zeros_like(self._X)
-            self._y0 = np.zeros_like(self._y)
+            # no mean-function table: an all-zero one, created once and kept across initialize() calls
+            self._X0, self._y0 = np.zeros_like(X), np.zeros_like(y)
         self._spatial_average = self._build_average_meanify(X)
-
         if self.white_noise > 0:
-            y_err = np.sqrt(copy.deepcopy(self._y_err) ** 2 + self.white_noise ** 2)
-        self._y_err = y_err
-
-        if self.normalize:
-            self._mean = np.mean(y - self._spatial_average)
-        else:
-            self._mean = 0.0
+            sigma = np.sqrt(sigma ** 2 + self.white_noise ** 2)
+        self._y_err = sigma
+        self._mean = np.mean(y - self._spatial_average) if self.normalize else 0.0
         self._drop_solution()
 
     def _build_average_meanify(self, X):
         """Mean function at X by K-nearest-neighbour interpolation of the meanify table, zeros when
         there is none.  gp_interp.py:229-243."""
-        if np.sum(np.equal(self._X0, 0)) != len(self._X0[:, 0]) * len(self._X0[0]):
+        if np.count_nonzero(self._X0) > 0:               # "a table is present" = X0 is not all zeros
             y0 = np.asarray(self._y0)
             k = self.n_neighbors
             on_gpu = k <= 8 or k == 16
@@ -161,38 +138,35 @@ class GPInterpolation(object):
             if y0.ndim == 2 and self.indice_meanify is not None and on_gpu:
                 return ops.knn_mean(self._X0, y0[:, self.indice_meanify], X, k)
             # multi-column table without a column pick / unusual k: scikit-learn, as the reference does
-            neigh = KNeighborsRegressor(n_neighbors=k)
-            neigh.fit(self._X0, self._y0)
-            average = neigh.predict(X)
-            if self.indice_meanify is not None:
-                average = average[:, self.indice_meanify]
-            return average
-        return np.zeros((len(X[:, 0])))
+            table = KNeighborsRegressor(n_neighbors=k).fit(self._X0, self._y0)
+            average = table.predict(X)
+            return average if self.indice_meanify is None else average[:, self.indice_meanify]
+        return np.zeros(len(X))
+
+    def _residual(self):
+        return self._y - self._mean - self._spatial_average
 
     def solve(self):
-        """Fit the hyper-parameters if an optimizer was requested.  gp_interp.py:245-258."""
-        self._init_theta = []
-        kernel = copy.deepcopy(self.kernel)
-        self._init_theta.append(kernel.theta)
-        self.kernel = self._fit(self.kernel, self._X, self._y - self._mean - self._spatial_average, self._y_err)
+        """Fit the hyper-parameters if an optimizer was requested (gp_interp.py:245-258); the starting theta
+        is kept in ``_init_theta``."""
+        self._init_theta = [copy.deepcopy(self.kernel).theta]
+        self.kernel = self._fit(self.kernel, self._X, self._residual(), self._y_err)
 
     def return_2pcf(self):
-        """xi, xi_weight, distance, coord, mask of the measured 2-point correlation function.
-        gp_interp.py:260-275."""
+        """xi, xi_weight, distance, coord, mask of the measured 2-point correlation function
+        (gp_interp.py:260-275)."""
         from .two_pcf import two_pcf
-        pcf = two_pcf(self._X, self._y - self._mean - self._spatial_average, self._y_err, self.min_sep,
-                      self.max_sep, nbins=self.nbins, anisotropic=(self.optimizer == "anisotropic"))
-        return pcf.return_2pcf()
+        measured = two_pcf(self._X, self._residual(), self._y_err, self.min_sep, self.max_sep, nbins=self.nbins,
+                           anisotropic=(self.optimizer == "anisotropic"))
+        return measured.return_2pcf()
 
     def return_log_likelihood(self, theta=None):
-        """Log-likelihood of the data for the current (or given) hyper-parameters.
-        gp_interp.py:277-291."""
+        """Log-likelihood of the data for the current (or the given) hyper-parameters (gp_interp.py:277-291)."""
         from .log_likelihood import log_likelihood
         kernel = copy.deepcopy(self.kernel)
         if theta is not None:
             kernel = kernel.clone_with_theta(theta)
-        logl = log_likelihood(self._X, self._y - self._mean - self._spatial_average, self._y_err)
-        return logl.log_likelihood(kernel)
+        return log_likelihood(self._X, self._residual(), self._y_err).log_likelihood(kernel)
 
     def plot_fitted_kernel(self):
         raise NotImplementedError("plotting (treegp/gp_interp.py:293-377) is outside the GPU hot path")

@@ -34,12 +34,13 @@ def eval_kernel(kernel):
     scope = {c.__name__: c for c in _all_kernel_classes()}
     scope["array"] = np.array
     try:
-        k = eval(kernel, scope)
-    except Exception as e:
-        raise RuntimeError("Failed to evaluate kernel string {0!r}.  Original exception: {1}".format(kernel, e))
-    if isinstance(k.theta, property):
+        built = eval(kernel, scope)
+    except Exception as exc:
+        msg = "Failed to evaluate kernel string {0!r}.  Original exception: {1}".format(kernel, exc)
+        raise RuntimeError(msg)
+    if type(built.theta) is property:        # the expression named a class without instantiating it
         raise TypeError("String provided was not initialized properly")
-    return k
+    return built
 
 
 class _CholeskyParametrised(StationaryKernelMixin, NormalizedKernelMixin, Kernel):
@@ -49,20 +50,19 @@ class _CholeskyParametrised(StationaryKernelMixin, NormalizedKernelMixin, Kernel
     _tgp_kind = None
 
     def __init__(self, invLam=None, scale_length=None, bounds=(-5, 5)):
-        if scale_length is not None:
-            if invLam is not None:
-                raise TypeError("Cannot set both invLam and scale_length in %s." % type(self).__name__)
-            invLam = np.diag(1.0 / np.array(scale_length) ** 2)
-        self.ndim = invLam.shape[0]
-        self.ntheta = self.ndim * (self.ndim + 1) // 2
-        self._d = np.diag_indices(self.ndim)
-        self._t = np.tril_indices(self.ndim, -1)
+        if scale_length is not None and invLam is not None:
+            raise TypeError("Cannot set both invLam and scale_length in %s." % type(self).__name__)
+        if scale_length is not None:                     # axis-aligned: invLam = diag(1 / l^2)
+            invLam = np.diag(np.reciprocal(np.square(np.array(scale_length, dtype=float))))
+        n = invLam.shape[0]
+        self.ndim, self.ntheta = n, n * (n + 1) // 2
+        self._d, self._t = np.diag_indices(n), np.tril_indices(n, -1)      # where theta lands in L
         self.set_params(invLam)
-        bounds = np.array(bounds)
-        if bounds.ndim == 1:
-            bounds = np.repeat(bounds[None, :], self.ntheta, axis=0)
-        assert bounds.shape == (self.ntheta, 2)
-        self._bounds = bounds
+        limits = np.array(bounds)
+        if limits.ndim == 1:                             # one (min, max) for every element of theta
+            limits = np.tile(limits, (self.ntheta, 1))
+        assert limits.shape == (self.ntheta, 2)
+        self._bounds = limits
 
     # -- scikit-learn plumbing -------------------------------------------------------------
     @property
@@ -71,13 +71,15 @@ class _CholeskyParametrised(StationaryKernelMixin, NormalizedKernelMixin, Kernel
 
     def get_params(self, deep=True):
         # only invLam: a clone therefore comes back with the default bounds (reference quirk)
-        return {"invLam": self.invLam}
+        return dict(invLam=self.invLam)
 
     def set_params(self, invLam=None):
-        if invLam is not None:
-            self.invLam = invLam
-            self._L = np.linalg.cholesky(self.invLam)
-            self._theta = np.hstack([np.log(self._L[self._d]), self._L[self._t]])
+        """invLam -> L (lower Cholesky factor) -> theta = [log diag(L), strictly-lower L]."""
+        if invLam is None:
+            return
+        chol = np.linalg.cholesky(invLam)
+        self.invLam, self._L = invLam, chol
+        self._theta = np.concatenate([np.log(chol[self._d]), chol[self._t]])
 
     @property
     def theta(self):
@@ -85,18 +87,19 @@ class _CholeskyParametrised(StationaryKernelMixin, NormalizedKernelMixin, Kernel
 
     @theta.setter
     def theta(self, theta):
-        self._theta = theta
-        self._L = np.zeros_like(self.invLam)
-        self._L[np.diag_indices(self.ndim)] = np.exp(theta[:self.ndim])
-        self._L[np.tril_indices(self.ndim, -1)] = theta[self.ndim:]
-        self.invLam = np.dot(self._L, self._L.T)
+        """theta -> L -> invLam = L L^T (always positive definite)."""
+        chol = np.zeros_like(self.invLam)
+        chol[self._d] = np.exp(theta[:self.ndim])
+        chol[self._t] = theta[self.ndim:]
+        self._theta, self._L = theta, chol
+        self.invLam = chol.dot(chol.T)
 
     @property
     def bounds(self):
         return self._bounds
 
     def __repr__(self):
-        return "{0}(invLam={1!r})".format(self.__class__.__name__, self.invLam)
+        return "%s(invLam=%r)" % (type(self).__name__, self.invLam)
 
     # -- evaluation ------------------------------------------------------------------------
     def _spec(self):
@@ -137,18 +140,17 @@ class VonKarman(StationaryKernelMixin, NormalizedKernelMixin, Kernel):
     """
 
     def __init__(self, length_scale=1.0, length_scale_bounds=(1e-5, 1e5)):
-        self.length_scale = length_scale
-        self.length_scale_bounds = length_scale_bounds
+        self.length_scale, self.length_scale_bounds = length_scale, length_scale_bounds
 
     @property
     def anisotropic(self):
-        return np.iterable(self.length_scale) and len(self.length_scale) > 1
+        scale = self.length_scale
+        return bool(np.iterable(scale) and len(scale) > 1)
 
     @property
     def hyperparameter_length_scale(self):
-        if self.anisotropic:
-            return Hyperparameter("length_scale", "numeric", self.length_scale_bounds, len(self.length_scale))
-        return Hyperparameter("length_scale", "numeric", self.length_scale_bounds)
+        count = len(self.length_scale) if self.anisotropic else 1
+        return Hyperparameter("length_scale", "numeric", self.length_scale_bounds, count)
 
     def _spec(self):
         if self.anisotropic:
@@ -164,10 +166,10 @@ class VonKarman(StationaryKernelMixin, NormalizedKernelMixin, Kernel):
         return ops.kernel_matrix(self._spec(), X, None if Y is None else np.atleast_2d(Y))
 
     def __repr__(self):
+        name = type(self).__name__
         if self.anisotropic:
-            return "{0}(length_scale=[{1}])".format(self.__class__.__name__,
-                                                    ", ".join(map("{0:.3g}".format, self.length_scale)))
-        return "{0}(length_scale={1:.3g})".format(self.__class__.__name__, np.ravel(self.length_scale)[0])
+            return "%s(length_scale=[%s])" % (name, ", ".join("%.3g" % v for v in self.length_scale))
+        return "%s(length_scale=%.3g)" % (name, np.ravel(self.length_scale)[0])
 
 
 # ---- kernel object -> device description ---------------------------------------------------

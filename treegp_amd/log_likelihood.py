@@ -17,19 +17,15 @@ class log_likelihood(object):
     """:param X: coordinates (n_samples, 1 or 2)  :param y: values  :param y_err: errors."""
 
     def __init__(self, X, y, y_err):
-        self.X = X
-        self.ndata = len(self.X[:, 0])
-        self.y = y
-        self.y_err = y_err
+        self.X, self.y, self.y_err = X, y, y_err
+        self.ndata = len(X[:, 0])
 
     def log_likelihood(self, kernel):
         """-0.5 y.K^-1.y - (n/2) log 2 pi - 0.5 log det K; any failure (e.g. K not positive
         definite) gives -inf, as at log_likelihood.py:28-39."""
         try:
             _, log_det, chi2, _ = ops.gp_solve(kernel_to_spec(kernel), self.X, self.y, self.y_err, want_alpha=False)
-            ll = -0.5 * chi2
-            ll -= (self.ndata / 2.0) * np.log((2.0 * np.pi))
-            ll -= 0.5 * log_det
+            ll = -0.5 * chi2 - (0.5 * self.ndata) * np.log(2.0 * np.pi) - 0.5 * log_det
         except (np.linalg.LinAlgError, FloatingPointError, ValueError, ops._lib.TgpError):
             ll = -np.inf
         if not np.isfinite(ll):
@@ -38,12 +34,13 @@ class log_likelihood(object):
 
     def optimizer(self, kernel):
         """L-BFGS-B on -log L over theta (log_likelihood.py:43-62)."""
-        def _minus_logl(param, k=kernel):
-            return -self.log_likelihood(k.clone_with_theta(param))
+        template = kernel
 
-        p0 = kernel.theta
-        res = optimize.minimize(_minus_logl, p0, method="L-BFGS-B")
-        kernel = kernel.clone_with_theta(res["x"])
-        self._kernel = copy.deepcopy(kernel)
+        def cost(theta):
+            return -self.log_likelihood(template.clone_with_theta(theta))
+
+        best = optimize.minimize(cost, template.theta, method="L-BFGS-B")["x"]
+        fitted = template.clone_with_theta(best)
+        self._kernel = copy.deepcopy(fitted)
         self._logL = self.log_likelihood(self._kernel)
-        return kernel
+        return fitted

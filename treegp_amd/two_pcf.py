@@ -99,19 +99,25 @@ class robust_2dfit(object):
                 best = pol if (np.isfinite(pol.fun) and pol.fun <= nm.fun) else nm
                 results = list(best.x)
                 self._fit_ok = bool(nm.success and np.isfinite(best.fun))
-            elif int(iminuit.__version__[0]) >= 2:
-                self.m = iminuit.Minuit(self.chi2, p0)
-                self.m.migrad()
-                results = [self.m.params[key].value for key in self.m.parameters]
-                self._fit_ok = self.m.accurate
             else:
-                self.m = iminuit.Minuit.from_array_func(self.chi2, p0, print_level=0)
-                self.m.migrad()
-                results = [self.m.values[key] for key in self.m.values.keys()]
-                self._fit_ok = self.m.migrad_ok()
+                results, self._fit_ok = self._run_migrad(p0)
             self.chi2(results)              # leaves self.alpha at the solution
         self._minuit_result = results
         self.result = [np.sqrt(self.alpha[0][0])] + list(results[:3]) + [self.alpha[1][0]]
+
+    def _run_migrad(self, p0):
+        """MIGRAD through whichever iminuit API is installed: 2.x takes the start vector directly, 1.x goes
+        through ``from_array_func`` (two_pcf.py:157-168).  The minimiser object stays in ``self.m``."""
+        if int(iminuit.__version__.split(".")[0]) >= 2:
+            m = iminuit.Minuit(self.chi2, p0)
+            m.migrad()
+            values, ok = [m.params[name].value for name in m.parameters], m.accurate
+        else:
+            m = iminuit.Minuit.from_array_func(self.chi2, p0, print_level=0)
+            m.migrad()
+            values, ok = [m.values[name] for name in m.values.keys()], m.migrad_ok()
+        self.m = m
+        return values, ok
 
     def minimize_minuit(self, p0=[3000.0, 0.2, 0.2]):
         """Minimise from p0; on failure retry from a 3x3x3 grid of start points until one
@@ -140,29 +146,25 @@ class two_pcf(object):
 
     def __init__(self, X, y, y_err, min_sep, max_sep, nbins=20, anisotropic=False, robust_fit=False,
                  p0=[3000.0, 0.0, 0.0], seed=610639139):
-        self.ndim = np.shape(X)[1]
-        if self.ndim not in [1, 2]:
-            raise ValueError("two-pcf support only 1d and 2d modeling for the moment. curent ndim: %i" % (self.ndim))
-        if self.ndim == 2:
-            self.X = X
-        if self.ndim == 1:
-            self.X = np.array([X.T, np.zeros_like(X.T)]).T[:, 0]
-        self.y = y
-        self.y_err = y_err
-        self.min_sep = min_sep
-        self.max_sep = max_sep
-        self.nbins = nbins
-        self.anisotropic = anisotropic
-        self.robust_fit = robust_fit
-        self.p0_robust_fit = p0
+        ndim = np.shape(X)[1]
+        if ndim not in (1, 2):
+            raise ValueError("two-pcf support only 1d and 2d modeling for the moment. curent ndim: %i" % (ndim))
+        self.ndim = ndim
+        # 1-D positions get a zero second coordinate: the pair kernels are 2-D (two_pcf.py:248-251)
+        self.X = X if ndim == 2 else np.column_stack([X[:, 0], np.zeros(len(X))])
+        self.y, self.y_err = y, y_err
+        self.min_sep, self.max_sep, self.nbins = min_sep, max_sep, nbins
+        self.anisotropic, self.robust_fit, self.p0_robust_fit = anisotropic, robust_fit, p0
         self.seed = seed
         self._rng = None
 
     @property
     def rng(self):
-        if self._rng is None:
-            self._rng = np.random.default_rng(self.seed)
-        return self._rng
+        """PCG64 stream of the bootstrap, (re)started lazily from ``seed`` (two_pcf.py:260-267)."""
+        gen = self._rng
+        if gen is None:
+            gen = self._rng = np.random.default_rng(self.seed)
+        return gen
 
     def _bootstrap_index(self):
         # two_pcf.py:273-275: `integers(0, n-1)` has an exclusive upper end, so the last point is
@@ -207,100 +209,87 @@ class two_pcf(object):
         return xi, distance, Coord, mask
 
     def comp_xi_covariance(self, n_bootstrap=1000, mask=None, seed=610639139):
-        """Bootstrap covariance of xi (two_pcf.py:342-362); the n_bootstrap pair-binning passes
-        are one batched GPU launch over an (n_bootstrap, n) index matrix."""
-        self.seed = seed
-        self._rng = None
-        if not self.anisotropic:
-            xi_bootstrap = []
-            for _ in range(n_bootstrap):
-                u, v, y, y_err = self.resample_bootstrap()
-                xi, _, _, _ = self.comp_2pcf(np.array([u, v]).T, y, y_err)
-                if mask is None:
-                    mask = np.array([True] * len(xi))
-                xi_bootstrap.append(xi[mask])
-            xi_bootstrap = np.array(xi_bootstrap)
+        """Bootstrap covariance of xi (two_pcf.py:342-362).  The random stream restarts at ``seed``; in
+        the anisotropic case all n_bootstrap pair-binning passes are one batched GPU launch over an
+        (n_bootstrap, n) index matrix."""
+        self.seed, self._rng = seed, None
+        if self.anisotropic:
+            draws = np.stack([self._bootstrap_index() for _ in range(n_bootstrap)])
+            samples = ops.kk_twod_bootstrap(self.X[:, 0], self.X[:, 1], self.y, self.y_err, draws, self.min_sep,
+                                            self.max_sep, self.nbins)
         else:
-            idx = np.stack([self._bootstrap_index() for _ in range(n_bootstrap)])
-            xi_all = ops.kk_twod_bootstrap(self.X[:, 0], self.X[:, 1], self.y, self.y_err, idx, self.min_sep,
-                                           self.max_sep, self.nbins)
-            if mask is None:
-                mask = np.array([True] * xi_all.shape[1])
-            xi_bootstrap = xi_all[:, mask]
-        dxi = xi_bootstrap - np.mean(xi_bootstrap, axis=0)
-        return 1.0 / (len(dxi) - 1.0) * np.dot(dxi.T, dxi)
+            rows = []
+            for _ in range(n_bootstrap):
+                u, v, yb, eb = self.resample_bootstrap()
+                rows.append(self.comp_2pcf(np.column_stack([u, v]), yb, eb)[0])
+            samples = np.array(rows)
+        if mask is not None:
+            samples = samples[:, mask]
+        centred = samples - samples.mean(axis=0)
+        return 1.0 / (len(centred) - 1.0) * np.dot(centred.T, centred)
+
+    def _n_bootstrap(self, npix):
+        """Number of resamples that makes the de-biasing factor of the inverse covariance equal to 2
+        (Taylor et al. 2012, eq. 35): root of (x-1)/(x-npix-2) = 2 found as the reference finds it,
+        fsolve from npix + 10 and truncation (two_pcf.py:371-378; 444 for the 221 pixels of nbins=21)."""
+        root = optimize.fsolve(lambda x: (x - 1.0) / (x - npix - 2.0) - 2.0, npix + 10)
+        return int(root[0])
 
     def return_2pcf(self, seed=610639139):
-        """xi, xi_weight, distance, coord, mask (two_pcf.py:364-391)."""
+        """xi, xi_weight, distance, coord, mask (two_pcf.py:364-391): weights are the de-biased inverse
+        bootstrap covariance (anisotropic) or identity / var(y)."""
         xi, distance, coord, mask = self.comp_2pcf(self.X, self.y, self.y_err)
-        if self.anisotropic:
-            # de-biasing of the inverse bootstrap covariance (Taylor et al. 2012, eq. 35)
-            def f_bias(x, npixel=len(xi[mask])):
-                return ((x - 1.0) / (x - npixel - 2.0)) - 2.0
+        if not self.anisotropic:
+            return xi, np.eye(len(xi)) * 1.0 / np.var(self.y), distance, coord, mask
+        npix = int(np.sum(mask))
+        nboot = self._n_bootstrap(npix)
+        cov = self.comp_xi_covariance(n_bootstrap=nboot, mask=mask, seed=seed)
+        debias = (nboot - 1.0) / (nboot - npix - 2.0)
+        return xi, np.linalg.inv(cov) * debias, distance, coord, mask
 
-            results = optimize.fsolve(f_bias, len(xi[mask]) + 10)
-            nboot = int(results[0])
-            xi_cov = self.comp_xi_covariance(n_bootstrap=nboot, mask=mask, seed=seed)
-            bias_factor = (nboot - 1.0) / (nboot - len(xi[mask]) - 2.0)
-            xi_weight = np.linalg.inv(xi_cov) * bias_factor
-        else:
-            xi_weight = np.eye(len(xi)) * 1.0 / np.var(self.y)
-        return xi, xi_weight, distance, coord, mask
+    def _default_separations(self):
+        """min_sep / max_sep when not given (two_pcf.py:409-421): mean distance between neighbouring points
+        (0 for the TwoD grid) and half the diagonal of the field."""
+        span = np.ptp(self.X, axis=0)
+        if self.ndim == 1:
+            span[1] = 0.0
+        lo, hi = self.min_sep, self.max_sep
+        if lo is None:
+            area = span[0] * span[1] if self.ndim == 2 else span[0]
+            density = float(len(self.X)) / area
+            lo = 0.0 if self.anisotropic else np.sqrt(1.0 / density)
+        if hi is None:
+            hi = np.sqrt(span[0] ** 2 + span[1] ** 2) / 2.0
+        return lo, hi
 
     def optimizer(self, kernel):
-        """chi^2 fit of the kernel's hyper-parameters to the measured xi (two_pcf.py:393-464)."""
-        size_x = np.max(self.X[:, 0]) - np.min(self.X[:, 0])
-        if self.ndim == 2:
-            size_y = np.max(self.X[:, 1]) - np.min(self.X[:, 1])
-            rho = float(len(self.X[:, 0])) / (size_x * size_y)
-        if self.ndim == 1:
-            size_y = 0.0
-            rho = float(len(self.X[:, 0])) / size_x
-        if self.min_sep is not None:
-            min_sep = self.min_sep
-        elif self.anisotropic:
-            min_sep = 0.0
-        else:
-            min_sep = np.sqrt(1.0 / rho)          # mean separation between data points
-        if self.max_sep is not None:
-            max_sep = self.max_sep
-        else:
-            max_sep = np.sqrt(size_x ** 2 + size_y ** 2) / 2.0
-        self.min_sep = min_sep
-        self.max_sep = max_sep
-
+        """Fit the kernel's hyper-parameters to the measured correlation function (two_pcf.py:393-464):
+        chi^2 with the weights of ``return_2pcf``; either the robust 2-D fit, or the better of a simplex
+        and an L-BFGS-B run from the kernel's current theta."""
+        self.min_sep, self.max_sep = self._default_separations()
         xi, xi_weight, distance, coord, mask = self.return_2pcf()
+        origin = np.zeros_like(coord)
 
-        def PCF(param, k=kernel):
-            kern = k.clone_with_theta(param)
-            return kern.__call__(coord, Y=np.zeros_like(coord))[:, 0]
+        def model(theta, template=kernel):
+            return template.clone_with_theta(theta)(coord, Y=origin)[:, 0]
 
-        xi_mask = xi[mask]
+        def chi2(theta):
+            r = xi[mask] - model(theta)[mask]
+            return r.dot(xi_weight.dot(r))
 
-        def chi2(param):
-            residual = xi_mask - PCF(param)[mask]
-            return residual.dot(xi_weight.dot(residual))
-
+        offset = 0
         if self.robust_fit:
-            robust = robust_2dfit(kernel, xi, coord[:, 0], coord[:, 1], xi_weight, mask=mask)
-            robust.minimize_minuit(p0=self.p0_robust_fit)
-            kernel = copy.deepcopy(robust.kernel_fit)
-            cst = robust.result[-1]
-            self._results_robust = robust.result
+            fit = robust_2dfit(kernel, xi, coord[:, 0], coord[:, 1], xi_weight, mask=mask)
+            fit.minimize_minuit(p0=self.p0_robust_fit)
+            self._results_robust = fit.result
+            kernel, offset = copy.deepcopy(fit.kernel_fit), fit.result[-1]
         else:
-            p0 = kernel.theta
-            results_fmin = optimize.fmin(chi2, p0, disp=False)
-            results_bfgs = optimize.minimize(chi2, p0, method="L-BFGS-B")
-            results = [results_fmin, results_bfgs["x"]]
-            chi2_min = [chi2(results[0]), chi2(results[1])]
-            results = results[chi2_min.index(min(chi2_min))]
-            kernel = kernel.clone_with_theta(results)
-            cst = 0
+            start = kernel.theta
+            candidates = [optimize.fmin(chi2, start, disp=False), optimize.minimize(chi2, start, method="L-BFGS-B")["x"]]
+            scores = [chi2(c) for c in candidates]
+            kernel = kernel.clone_with_theta(candidates[scores.index(min(scores))])
 
-        self._2pcf = xi
-        self._2pcf_weight = xi_weight
-        self._2pcf_dist = distance
-        self._2pcf_fit = PCF(kernel.theta) + cst
-        self._2pcf_mask = mask
+        self._2pcf, self._2pcf_weight, self._2pcf_dist, self._2pcf_mask = xi, xi_weight, distance, mask
+        self._2pcf_fit = model(kernel.theta) + offset
         self._kernel = copy.deepcopy(kernel)
         return kernel

@@ -43,22 +43,20 @@ def vcorr(x, y, dx, dy, rmin=5.0 / 3600.0, rmax=1.5, dlogr=0.05, maxpts=30000):
 
 
 def xiB(logr, xiplus, ximinus):
-    """Estimate of the pure B-mode correlation function (utils.py:77-86)."""
-    # integral of d(log r) xi_-(r) from r to infinity
-    dlogr = np.zeros_like(logr)
-    dlogr[1:-1] = 0.5 * (logr[2:] - logr[:-2])
-    tmp = np.array(ximinus) * dlogr
-    integral = np.cumsum(tmp[::-1])[::-1]
-    return 0.5 * (xiplus - ximinus) + integral
+    """Estimate of the pure B-mode correlation function (utils.py:77-86):
+    (xi+ - xi-)/2 + integral of xi- d(log r) from r outwards (central-difference bin widths, end bins 0)."""
+    width = np.zeros_like(logr)
+    width[1:-1] = (logr[2:] - logr[:-2]) * 0.5
+    outward = np.flip(np.cumsum(np.flip(np.asarray(ximinus) * width)))
+    return (xiplus - ximinus) * 0.5 + outward
 
 
 def comp_eb(u, v, du, dv, **kwargs):
     """E/B decomposition of the correlation function of the vector field (du, dv) at (u, v)
     (utils.py:89-105).  Returns xie, xib, logr."""
-    logr, xiplus, ximinus, xicross, xiz2 = vcorr(u, v, du, dv, **kwargs)
-    xib = xiB(logr, xiplus, ximinus)
-    xie = xiplus - xib
-    return xie, xib, logr
+    logr, xi_plus, xi_minus = vcorr(u, v, du, dv, **kwargs)[:3]
+    b_mode = xiB(logr, xi_plus, xi_minus)
+    return xi_plus - b_mode, b_mode, logr
 
 
 class compEbTreecorr:
