@@ -162,3 +162,15 @@ def test_device_bessel_function_on_host():
     assert out[0] == 1.0
     np.testing.assert_allclose(out, ref, rtol=2e-13, atol=1e-13)      # kernel tables are pinned at atol 1e-12
     assert np.all(out[2 * np.pi * u > 697.874] == 0.0) and np.all(ref[2 * np.pi * u > 697.874] == 0.0)
+
+
+def test_potrf128_register_budget():
+    """potrf128 must fit on a SIMD beside one trailing-update wave (<= 264 VGPRs), or the look-ahead stalls until a
+    compute unit is empty; checked on the generated ISA (cross-compiles, no GPU needed)."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_potrf_regs.sh")
+    r = subprocess.run(["bash", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr

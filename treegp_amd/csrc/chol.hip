@@ -479,6 +479,12 @@ int tgp_debug_syrk_loop(tgp_ctx *ctx, double *d_A, int64_t Np, int reps, double 
     return 0;
 }
 
+#ifdef TGP_POTRF_STAMPS
+extern "C" int tgp_debug_potrf_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_potrf_stamps), 32 * sizeof(unsigned long long));
+}
+#endif
+
 int tgp_debug_tilemap(int64_t T, int32_t *ti, int32_t *tj, int64_t cap) {
     const int64_t g = tilemap_grid(T);
     if (cap < g) return -1;

@@ -19,6 +19,13 @@
 #include <utility>
 #include "tgp_internal.h"
 
+#ifdef TGP_POTRF_STAMPS
+__device__ unsigned long long tgp_potrf_stamps[32];
+#define POTRF_STAMP(i) do { if (threadIdx.x == 0) tgp_potrf_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define POTRF_STAMP(i) do { } while (0)
+#endif
+
 namespace potrf_v2 {
 typedef double d4v __attribute__((ext_vector_type(4)));
 // LDS image: only the 10 lower 32x32 blocks of the 4x4 block matrix, each with row stride 34 doubles
@@ -87,6 +94,7 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
     }
     return y;
 }
+#include "gj16_dpp.h"
 template <int J, int C>
 __device__ __forceinline__ void gj16_elem(double (&t)[16], const double li, const double lm) {
     if constexpr (C > J) t[C] = __builtin_fma(-lm, bcast16<C>(li), t[C]);            // L[C][J] lives in lane C
@@ -103,7 +111,11 @@ __device__ __forceinline__ void gj16_column(double (&t)[16], double (&ls)[16], c
     const double scale = (i == J) ? inv : 1.0;            // row J of L^-1: scale the pivot row
     ((t[Cs] = (Cs < J) ? t[Cs] * scale : t[Cs]), ...);
     const double lm = (i > J) ? li : 0.0;                 // rows <= J are finished: multiplier 0
-    (gj16_elem<J, Cs>(t, li, lm), ...);
+#ifdef TGP_GJ16_PORTABLE
+    (gj16_elem<J, Cs>(t, li, lm), ...);                   // two DPP moves + one FMA per element
+#else
+    gj16_update<J>(t, li, -lm);                           // one v_fmac_f64_dpp per element (gj16_dpp.h)
+#endif
     t[J] = (i > J) ? -li * inv : ((i == J) ? inv : t[J]);
     ls[J] = (i > J) ? li : ((i == J) ? d : 0.0);
 }
@@ -118,6 +130,8 @@ __device__ __forceinline__ void gauss_jordan16(double (&t)[16], double (&ls)[16]
 }
 
 // acc += A[ra.., ca..ca+31] (16 x 32) * B[rb.., cb..cb+31]^T (16 x 32), both row-major in T
+// (splitting these products over two accumulator chains was tried and is slower: the extra adds and LDS
+//  traffic cost more than the dependent-MFMA latency they hide)
 __device__ __forceinline__ d4v mma_nt32(const double *T, int ra, int ca, int rb, int cb, d4v acc, int l15, int l4) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -175,19 +189,37 @@ __device__ __forceinline__ void diag16(double *T, double *A, int lda, int q, int
     }
 }
 
+// Register budget: at most 264 VGPRs (arch + acc), so that a wave of this kernel fits on a SIMD next to one wave of
+// the trailing update (248 of 512) -- with more it has to wait for an EMPTY compute unit during the look-ahead
+// (measured: 268 VGPRs cost 25 ms of exposed panel time at N = 65536).  The initial load is batched in two halves
+// for that reason; tools/check_potrf_regs.sh (run by the build) fails if the budget is exceeded.
 template <bool DIAG16>
 __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, double *W, int *info, int base) {
-    __shared__ double T[T_ELEMS];
+    __shared__ double T[T_ELEMS + BLK_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const d4v zero4 = {0.0, 0.0, 0.0, 0.0};
+    POTRF_STAMP(0);
 
-    for (int idx = tid; idx < 128 * 64; idx += 256) {          // two columns per thread, coalesced rows
-        const int i = idx >> 6, c = (idx & 63) * 2;
-        const double2 v = *reinterpret_cast<const double2 *>(A + (int64_t)i * lda + c);
-        if ((c >> 5) <= (i >> 5)) {                              // lower blocks only
-            T[taddr(i, c)] = (c <= i) ? v.x : 0.0;
-            T[taddr(i, c + 1)] = (c + 1 <= i) ? v.y : 0.0;
+    {   // the block comes in with all its loads in flight at once (two columns per thread, coalesced rows);
+        // only the 10 lower 32x32 blocks are fetched
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            double2 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int idx = tid + 256 * (16 * half + u), i = idx >> 6, c = (idx & 63) * 2;
+                v[u] = make_double2(0.0, 0.0);
+                if ((c >> 5) <= (i >> 5)) v[u] = *reinterpret_cast<const double2 *>(A + (int64_t)i * lda + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int idx = tid + 256 * (16 * half + u), i = idx >> 6, c = (idx & 63) * 2;
+                if ((c >> 5) <= (i >> 5)) {
+                    T[taddr(i, c)] = (c <= i) ? v[u].x : 0.0;
+                    T[taddr(i, c + 1)] = (c + 1 <= i) ? v[u].y : 0.0;
+                }
+            }
         }
     }
     __syncthreads();
@@ -196,6 +228,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
 #pragma unroll 1
     for (int jb = 0; jb < 4; ++jb) {
         const int r0 = 32 * jb;
+        POTRF_STAMP(1 + 3 * jb);
         if (DIAG16 && wave == 0) {
             // whole wave, no workgroup barrier: LDS operations of one wave execute in program order
             diag16(T, A, lda, r0, lane, info, base);
@@ -231,6 +264,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
             }
         }
         __syncthreads();
+        POTRF_STAMP(2 + 3 * jb);
         const int r1 = r0 + 32;
         const int nr16 = (128 - r1) / 16;
         // rows below: X = A_panel D_j^T, one 16-row strip (two 16x16 tiles) per wave at a time
@@ -252,28 +286,64 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
             }
         }
         __syncthreads();
-        // Schur complement: lower 16x16 tiles of T[r1:, r1:] -= X X^T
+        POTRF_STAMP(3 + 3 * jb);
+        // Schur complement: lower 16x16 tiles of T[r1:, r1:] -= X X^T.  Tiles 0..2 are the NEXT diagonal
+        // 32x32 block: wave 0 takes exactly those (three interleaved accumulator chains) and goes straight on
+        // to factor that block; waves 1..3 share the rest and meet wave 0 again at the barrier after the
+        // diagonal step -- the bulk of the update is off the critical path.  No barrier here: what wave 0
+        // touches next (the diagonal block of step jb+1) is disjoint from what the others still read and write.
         const int ntile = nr16 * (nr16 + 1) / 2;
-        for (int tt = wave; tt < ntile; tt += 4) {
-            int ti = 0;
-            while ((ti + 1) * (ti + 2) / 2 <= tt) ++ti;
-            const int tj = tt - ti * (ti + 1) / 2;
-            const d4v p = mma_nt32(T, r1 + 16 * ti, r0, r1 + 16 * tj, r0, zero4, l15, l4);
+        if (wave == 0) {
+            if (nr16 >= 2) {
+                d4v p00 = zero4, p10 = zero4, p11 = zero4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) T[taddr(r1 + 16 * ti + l4 + 4 * r, r1 + 16 * tj + l15)] -= p[r];
+                for (int ks = 0; ks < 8; ++ks) {
+                    const double x0 = T[taddr(r1 + l15, r0 + 4 * ks + l4)];
+                    const double x1 = T[taddr(r1 + 16 + l15, r0 + 4 * ks + l4)];
+                    p00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, p00, 0, 0, 0);
+                    p10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, p10, 0, 0, 0);
+                    p11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, p11, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    T[taddr(r1 + l4 + 4 * r, r1 + l15)] -= p00[r];
+                    T[taddr(r1 + 16 + l4 + 4 * r, r1 + l15)] -= p10[r];
+                    T[taddr(r1 + 16 + l4 + 4 * r, r1 + 16 + l15)] -= p11[r];
+                }
+            }
+        } else {
+            for (int tt = 3 + (wave - 1); tt < ntile; tt += 3) {
+                int ti = 0;
+                while ((ti + 1) * (ti + 2) / 2 <= tt) ++ti;
+                const int tj = tt - ti * (ti + 1) / 2;
+                const d4v p = mma_nt32(T, r1 + 16 * ti, r0, r1 + 16 * tj, r0, zero4, l15, l4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[taddr(r1 + 16 * ti + l4 + 4 * r, r1 + 16 * tj + l15)] -= p[r];
+            }
         }
-        __syncthreads();
-    }
-
-    // off-diagonal blocks of L are final: write them out (diagonal blocks went out from registers)
-    for (int idx = tid; idx < 128 * 128; idx += 256) {
-        const int i = idx >> 7, c = idx & 127;
-        if ((c >> 5) < (i >> 5)) A[(int64_t)i * lda + c] = T[taddr(i, c)];
     }
     __syncthreads();
 
+    POTRF_STAMP(13);
+    // off-diagonal blocks of L are final: write them out (diagonal blocks went out from registers).
+    // Block row bi holds 32 rows x 32 bi columns = 16 bi column pairs per row; 12 pairs per thread in all.
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+        const int bi = s < 2 ? 1 : (s < 6 ? 2 : 3);
+        const int first = s < 2 ? 0 : (s < 6 ? 2 : 6);
+        const int local = tid + 256 * (s - first);
+        const int row = 32 * bi + local / (16 * bi), c = 2 * (local % (16 * bi));
+        double2 v;
+        v.x = T[taddr(row, c)];
+        v.y = T[taddr(row, c + 1)];
+        *reinterpret_cast<double2 *>(A + (int64_t)row * lda + c) = v;
+    }
+    __syncthreads();
+
+    POTRF_STAMP(14);
     // ---- phase 2: W = L^-1 in place, block column by block column ----------------------------------
     const int rt = wave >> 1, ct = wave & 1;           // this wave's 16x16 tile of a 32x32 block
+    double *SC = T + T_ELEMS;                          // one spare 32x32 block: S goes there, so W can be written in place
 #pragma unroll 1
     for (int cb = 0; cb < 3; ++cb) {
 #pragma unroll 1
@@ -281,23 +351,28 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
             d4v s = zero4;
             for (int kb = cb; kb < ib; ++kb)            // S = sum_k L_ik W_k,cb
                 s = mma_nn32(T, 32 * ib + 16 * rt, 32 * kb, 32 * kb, 32 * cb + 16 * ct, s, l15, l4);
-            __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) T[taddr(32 * ib + 16 * rt + l4 + 4 * r, 32 * cb + 16 * ct + l15)] = s[r];
+            for (int r = 0; r < 4; ++r) SC[(16 * rt + l4 + 4 * r) * BS + 16 * ct + l15] = s[r];
             __syncthreads();
-            const d4v w = mma_nn32(T, 32 * ib + 16 * rt, 32 * ib, 32 * ib, 32 * cb + 16 * ct, zero4, l15, l4);   // D_i S
-            __syncthreads();
+            d4v w = zero4;                              // D_i S
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                w = __builtin_amdgcn_mfma_f64_16x16x4f64(T[taddr(32 * ib + 16 * rt + l15, 32 * ib + 4 * ks + l4)],
+                                                         SC[(4 * ks + l4) * BS + 16 * ct + l15], w, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[taddr(32 * ib + 16 * rt + l4 + 4 * r, 32 * cb + 16 * ct + l15)] = -w[r];
             __syncthreads();
         }
     }
-    for (int idx = tid; idx < 128 * 64; idx += 256) {
-        const int i = idx >> 6, c = (idx & 63) * 2;
+    POTRF_STAMP(15);
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+        const int idx = tid + 256 * it, i = idx >> 6, c = (idx & 63) * 2;
         double2 v;
         v.x = (c <= i) ? T[taddr(i, c)] : 0.0;
         v.y = (c + 1 <= i) ? T[taddr(i, c + 1)] : 0.0;
         *reinterpret_cast<double2 *>(W + i * 128 + c) = v;
     }
+    POTRF_STAMP(16);
 }
 }  // namespace potrf_v2
