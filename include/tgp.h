@@ -208,6 +208,12 @@ int tgp_dd_update(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t N
 int tgp_dd_update2(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
                    const double *d_gathered0, int cmax0, const double *d_gathered1, int cmax1, int col_lo,
                    int col_hi);
+/* Replicated factor for the solves: store panel kpanel into d_Afull, a full single-GPU packed matrix
+ * (tgp_panel_elems(Np) doubles) kept on every rank -- its 256x256 diagonal block from the broadcast buffer
+ * (d_bcast, may be NULL) and/or the rows below it from the all-gathered panel (d_gathered, may be NULL).
+ * After the last panel, tgp_d_potrs(ctx, d_Afull, d_W, Np, rhs) solves on every rank without communication. */
+int tgp_dd_keep_panel(tgp_ctx *ctx, double *d_Afull, int64_t Np, int kpanel, int G, const double *d_bcast,
+                      const double *d_gathered, int cmax);
 /* block-row-cyclic triangular solves (scipy cho_solve, gp_interp.py:182) */
 int tgp_dd_fwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_yk);
 int tgp_dd_fwd_update(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int64_t Np, int kb, int G, int g,

@@ -72,8 +72,9 @@ class NumpyLocalOps(object):
     """Same interface as treegp_amd.dist.HipLocalOps, dense NumPy rows on the CPU.  Exists only so
     the orchestration (ownership, collectives, gather indexing) can be tested without a GPU."""
 
-    def __init__(self, Kfull, n, G, g):
+    def __init__(self, Kfull, n, G, g, replicated=False):
         self.n, self.G, self.g = n, G, g
+        self.replicated = replicated
         self.Np = (n + BLK - 1) // BLK * BLK
         self.nB = self.Np // BLK
         self.nloc = panel_blocks(0, self.nB, g, G)
@@ -84,6 +85,22 @@ class NumpyLocalOps(object):
         self.rows = {b: Kp[b * BLK:(b + 1) * BLK, :].copy() for b in self.blocks}     # full-width rows
         self.bcast = torch.zeros(BCAST_ELEMS, dtype=torch.float64)
         self._info = 0
+        self.Lfull = np.zeros((self.Np, self.Np)) if replicated else None       # the replicated factor
+
+    def keep_diag(self, k):
+        self.Lfull[k * BLK:(k + 1) * BLK, k * BLK:(k + 1) * BLK] = np.tril(self.bcast[:BLK * BLK].numpy().reshape(BLK, BLK))
+
+    def keep_rows(self, k, gathered, cmax):
+        P = gathered.numpy()
+        for b in range(k + 1, self.nB):
+            r = b % self.G
+            idx = (b - first_ge(k + 1, r, self.G)) // self.G
+            o = (r * cmax + idx) * BLK * BLK
+            self.Lfull[b * BLK:(b + 1) * BLK, k * BLK:(k + 1) * BLK] = P[o:o + BLK * BLK].reshape(BLK, BLK)
+
+    def potrs_full(self, rhs):
+        z = np.linalg.solve(self.Lfull, rhs.numpy())
+        rhs.copy_(torch.from_numpy(np.linalg.solve(self.Lfull.T, z)))
 
     def empty(self, n):
         return torch.empty(n, dtype=torch.float64)

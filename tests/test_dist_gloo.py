@@ -33,16 +33,17 @@ def _worker(rank, world, port, n, out_dir):
         K = np.exp(-0.5 * d2 / 0.1 ** 2) + np.diag(0.05 + 0.01 * rng.uniform(size=n))
         y = rng.standard_normal(n)
         comm = TorchComm()
-        ops = NumpyLocalOps(K, n, world, rank)
-        ch = DistributedCholesky(ops, comm)
-        assert ch.factorize() == 0
-        ypad = torch.zeros(ops.Np, dtype=torch.float64)
-        ypad[:n] = torch.from_numpy(y)
-        alpha = ch.solve(ypad).numpy()[:n]
-        logdet = float(ch.logdet()[0])
         ref = np.linalg.solve(K, y)
-        np.testing.assert_allclose(alpha, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
-        np.testing.assert_allclose(logdet, np.linalg.slogdet(K)[1], rtol=1e-11)
+        for replicated in (False, True):          # distributed sweeps / sweeps on the replicated factor
+            ops = NumpyLocalOps(K, n, world, rank, replicated=replicated)
+            ch = DistributedCholesky(ops, comm)
+            assert ch.factorize() == 0
+            ypad = torch.zeros(ops.Np, dtype=torch.float64)
+            ypad[:n] = torch.from_numpy(y)
+            alpha = ch.solve(ypad).numpy()[:n]
+            logdet = float(ch.logdet()[0])
+            np.testing.assert_allclose(alpha, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+            np.testing.assert_allclose(logdet, np.linalg.slogdet(K)[1], rtol=1e-11)
         # a matrix that is not positive definite is reported on every rank
         Kbad = K.copy()
         Kbad[300, 300] = -1.0

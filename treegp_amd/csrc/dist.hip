@@ -83,6 +83,38 @@ int tgp_dd_update2(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t 
     return launch_syrk_dist2(ctx, d_Aloc, d_loff, Np, kpanel, G, g, d_gathered0, cmax0, d_gathered1, cmax1, col_lo, col_hi);
 }
 
+// ---- replicated factor for the solves ---------------------------------------------------------------------------
+// Every rank sees every panel once (diagonal block in the broadcast, the rows below in the all-gather).  Keeping them,
+// in the single-GPU packed layout (17 GB at N = 65536, 69 GB at 131072: what 288 GB of HBM per GPU are for), lets each
+// rank run the two triangular sweeps locally (tgp_d_potrs) instead of 2 N/256 latency-bound collectives.
+namespace {
+// one workgroup per 2048-double slice of a 256x256 block: blockIdx.x = block index above kpanel, blockIdx.y = slice
+__global__ __launch_bounds__(256) void keep_rows_kernel(const double *__restrict__ gathered, int cmax, int kpanel, int G,
+                                                        double *__restrict__ panel) {
+    const int64_t b = (int64_t)kpanel + 1 + blockIdx.x;
+    const int r = (int)(b % G);
+    const int64_t idx = (b - dist_first_ge(kpanel + 1, r, G)) / G;
+    const double2 *src = reinterpret_cast<const double2 *>(gathered + ((int64_t)r * cmax + idx) * TGP_PW * TGP_PW) + blockIdx.y * 1024;
+    double2 *dst = reinterpret_cast<double2 *>(panel + (b - kpanel) * TGP_PW * TGP_PW) + blockIdx.y * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dst[threadIdx.x + 256 * u] = src[threadIdx.x + 256 * u];
+}
+}  // namespace
+
+int tgp_dd_keep_panel(tgp_ctx *ctx, double *d_Afull, int64_t Np, int kpanel, int G, const double *d_bcast,
+                      const double *d_gathered, int cmax) {
+    TGP_ARG(d_Afull && Np % TGP_PW == 0 && kpanel >= 0 && kpanel < Np / TGP_PW && G >= 1);
+    hipStream_t st = ctx->stream;
+    double *panel = d_Afull + panel_off(kpanel, Np);
+    if (d_bcast) TGP_HIP(hipMemcpyAsync(panel, d_bcast, (size_t)TGP_PW * TGP_PW * 8, hipMemcpyDeviceToDevice, st));
+    const int64_t above = Np / TGP_PW - kpanel - 1;
+    if (d_gathered && above > 0) {
+        keep_rows_kernel<<<dim3((unsigned)above, 32), 256, 0, st>>>(d_gathered, cmax, kpanel, G, panel);
+        TGP_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
 // forward sweep, block kb (owner): y_k (256) <- L_kk^-1 y_k
 int tgp_dd_fwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_yk) {
     const double *W0 = d_W + (int64_t)(2 * kb) * TGP_TB * TGP_TB;

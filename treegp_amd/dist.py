@@ -23,6 +23,7 @@ product implementation (device pointers into libtgp.so); tests substitute a NumP
 exercise the communication logic under ``gloo`` on CPUs.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -150,6 +151,14 @@ class HipLocalOps(object):
         self.side_stream = torch.cuda.Stream(device=device, priority=-1)
         self.ctx_side = _lib.new_ctx(device.index if device.index is not None else 0)
         self.lib.tgp_set_stream(self.ctx_side, C.c_void_p(self.side_stream.cuda_stream))
+        # replicated factor for the solves: every panel is seen by every rank anyway (broadcast + all-gather); kept
+        # in the single-GPU packed layout it lets the triangular sweeps run locally, without their 2 N/256 collectives
+        self.Afull = None
+        full_bytes = int(self.lib.tgp_panel_elems(self.Np)) * 8
+        if G > 1 or os.environ.get("TGP_DIST_REPLICATE") == "1":
+            free_bytes = torch.cuda.mem_get_info(device)[0]
+            if os.environ.get("TGP_DIST_REPLICATE", "1") != "0" and full_bytes < 0.5 * free_bytes:
+                self.Afull = torch.empty(full_bytes // 8, dtype=torch.float64, device=device)
 
     def _chk(self, rc, what, ctx=None):
         self._lib.check(ctx or self.ctx, rc, what)
@@ -211,6 +220,21 @@ class HipLocalOps(object):
         self._chk(self.lib.tgp_dd_update2(self.ctx, self._p(self.A), self._p(self.d_loff), self.Np, k, self.G, self.g,
                                           self._p(gathered0), cmax0, self._p(gathered1), cmax1, col_lo, col_hi),
                   "tgp_dd_update2")
+
+    @property
+    def replicated(self):
+        return self.Afull is not None
+
+    def keep_diag(self, k):                # side stream, after the broadcast of panel k
+        self._chk(self.lib.tgp_dd_keep_panel(self.ctx_side, self._p(self.Afull), self.Np, k, self.G, self._p(self.bcast),
+                                             None, 0), "tgp_dd_keep_panel", self.ctx_side)
+
+    def keep_rows(self, k, gathered, cmax):   # side stream, after the all-gather of panel k
+        self._chk(self.lib.tgp_dd_keep_panel(self.ctx_side, self._p(self.Afull), self.Np, k, self.G, None,
+                                             self._p(gathered), cmax), "tgp_dd_keep_panel", self.ctx_side)
+
+    def potrs_full(self, rhs):             # main stream: rhs (Np) <- L^-T L^-1 rhs with the replicated factor
+        self._chk(self.lib.tgp_d_potrs(self.ctx, self._p(self.Afull), self._p(self.W), self.Np, self._p(rhs)), "tgp_d_potrs")
 
     def info(self):
         a = int(self.lib.tgp_dd_info(self.ctx, 1))
@@ -279,6 +303,7 @@ class DistributedCholesky(object):
         ops, comm, G, g, nB = self.ops, self.comm, self.G, self.g, self.nB
         events = []
         self.update_flops, self.update_launches = 0.0, 0
+        keep = bool(getattr(ops, "replicated", False))           # also build the replicated factor for the solves
 
         def factor_and_gather(k, buf):
             """panel k on the side stream: diagonal block on its owner, broadcast, local solves, all-gather"""
@@ -286,6 +311,8 @@ class DistributedCholesky(object):
             if g == owner:
                 ops.factor_diag(k)
             comm.broadcast(ops.bcast, owner)
+            if keep:
+                ops.keep_diag(k)
             ops.trsm(k)
             rem = nB - k - 1
             if rem == 0:
@@ -294,14 +321,27 @@ class DistributedCholesky(object):
             send = ops.panel_send_view(k, cmax)
             return comm.all_gather_start(buf[:G * cmax * BLK * BLK], send), cmax
 
+        pending = []                                             # gathered panels not yet copied into the replicated factor
+
+        def flush_keeps():
+            while pending:
+                w, kk, buf, cc = pending.pop(0)
+                w.wait()                                         # side stream: that gather has landed
+                ops.keep_rows(kk, buf, cc)
+
         def side_pair(k, bufs):
             """panels k and k+1 (where they exist) on the side stream; returns their gather handles"""
+            flush_keeps()
             w0, c0 = factor_and_gather(k, bufs[0])
             w1, c1 = None, 0
             if k + 1 < nB:
                 w0.wait()                                        # side stream: panel k is on every rank
                 ops.update(k, bufs[0], c0, 0, 2, side=True)      # panel k+1's columns, depth 256
+                if keep:
+                    ops.keep_rows(k, bufs[0], c0)
                 w1, c1 = factor_and_gather(k + 1, bufs[1])
+                if keep and w1 is not None:
+                    pending.append((w1, k + 1, bufs[1], c1))     # copied at the start of the next side chain
             return (w0, c0), (w1, c1)
 
         def timed(fn):
@@ -332,6 +372,9 @@ class DistributedCholesky(object):
             self.update_launches += 2
             (w0, c0), (w1, c1) = (n0, nc0), (n1, nc1)
             k += 2
+        if pending:
+            with ops.on_side():
+                flush_keeps()
         ops.main_wait_side()                                     # the last chain has no gather to wait on
         # any rank's failure is everybody's failure; report the smallest failing index
         big = 1e18
@@ -349,6 +392,12 @@ class DistributedCholesky(object):
         result; every rank then updates its own rows.  Backward: every rank contributes the partial
         sum of its rows, one 2 KB all-reduce, the owner finishes the block."""
         ops, comm, G, g, nB = self.ops, self.comm, self.G, self.g, self.nB
+        if getattr(ops, "replicated", False):
+            # every rank holds the whole factor (factorize() kept the panels): both sweeps locally, no communication
+            alpha = ops.zeros(self.Np)
+            alpha.copy_(y_full)
+            ops.potrs_full(alpha)
+            return alpha
         nloc = ops.nloc
         yloc = ops.zeros(max(nloc, 1) * BLK)
         yv = [yloc[lb * BLK:(lb + 1) * BLK] for lb in range(nloc)]
