@@ -9,5 +9,6 @@ for n, m in ((8192, 4096), (2048, 2048), (16384, 8192)):
     ts = []
     for it in range(4):
         t0 = time.perf_counter(); cov = ops.gp_predict_cov(spec, fac, X, Xs); ts.append((time.perf_counter()-t0)*1e3)
-    print("cov N=%d M=%d: %s ms, min diag %.3e" % (n, m, ["%.1f" % t for t in ts], cov.diagonal().min()))
+        tm = _lib.timings(_lib.get_ctx()); dev = (tm[3], tm[9])
+    print("cov N=%d M=%d: %s ms wall; last call: device compute %.2f ms, D2H of the result %.2f ms; min diag %.3e" % (n, m, ["%.1f" % t for t in ts], dev[0], dev[1], cov.diagonal().min()))
     fac.free()

@@ -90,6 +90,7 @@ extern "C" int tgp_gp_predict_cov(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel 
     auto take = [&](size_t b) { char *p = base + off; off += rup(b); return (double *)p; };
     double *d_X = take(2 * n * 8), *d_Xs = take(2 * m * 8), *d_Bt = take((size_t)Mp * Np * 8),
            *d_C = take((size_t)Mp * Mp * 8);
+    TGP_HIP(hipEventRecord(ctx->ev[0], st));
     TGP_HIP(hipMemcpyAsync(d_X, X, 2 * n * 8, hipMemcpyHostToDevice, st));
     TGP_HIP(hipMemcpyAsync(d_Xs, Xs, 2 * m * 8, hipMemcpyHostToDevice, st));
     // HT (gp_interp.py:177) and k(X2) (gp_interp.py:191), zero padded, in panels
@@ -107,12 +108,19 @@ extern "C" int tgp_gp_predict_cov(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel 
     }
     cov_syrk_kernel<<<dim3(mt, mt), 256, 0, st>>>(d_C, d_Bt, Mp, nP);
     TGP_HIP(hipGetLastError());
+    TGP_HIP(hipEventRecord(ctx->ev[1], st));
     for (int p = 0; p < nPm; ++p) {
         const int64_t w = (m - (int64_t)p * TGP_PW < TGP_PW) ? m - (int64_t)p * TGP_PW : TGP_PW;
         if (w <= 0) break;
         TGP_HIP(hipMemcpy2DAsync(cov + (int64_t)p * TGP_PW, (size_t)m * 8, d_C + (int64_t)p * Mp * TGP_PW, (size_t)TGP_PW * 8,
                                  (size_t)w * 8, (size_t)m, hipMemcpyDeviceToHost, st));
     }
+    TGP_HIP(hipEventRecord(ctx->ev[2], st));
     TGP_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timings[3] = ms;                       // device compute
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+    ctx->timings[9] = ms;                       // (m, m) result to the caller's buffer
     return 0;
 }
