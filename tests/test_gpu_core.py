@@ -138,3 +138,37 @@ def test_golden_config1_and_aniso2d(tg, golden):
     alpha, _, _, _ = ops.gp_solve(spec, g["X"], g["y"] - mean, g["y_err_eff"])
     yp = ops.gp_predict(spec, g["X"], alpha, g["Xs"]) + mean
     np.testing.assert_allclose(yp, g["y_pred"], rtol=0, atol=1e-10 * np.abs(g["y_pred"]).max())
+
+
+@pytest.mark.parametrize("env", [{"TGP_SYRK_TILE": "0"}, {"TGP_SYRK_TILE": "8"}, {"TGP_POTRF_VARIANT": "1"},
+                                 {"TGP_POTRF_VARIANT": "0"}, {"TGP_SMALL_T": "0", "TGP_SMALL_ROWS": "0"},
+                                 {"TGP_CHOL_MODE": "0"}, {"TGP_CHOL_MODE": "1"}, {"TGP_PREDICT_GENERIC": "1"}])
+def test_alternative_kernel_paths_agree(env):
+    """The A/B switches kept in the library (older tiles, schedules and diagonal-block kernels) must stay correct:
+    each one solves and predicts the same problem in a fresh process (the switches are read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from treegp_amd import _lib, ops
+from oracle import gp_oracle as O
+rng = np.random.default_rng(3)
+n, m = 3000, 500
+X = rng.uniform(0, 1, (n, 2)); y = np.sin(5 * X[:, 0]) + 0.1 * rng.standard_normal(n); e = rng.uniform(0.05, 0.1, n)
+Xs = rng.uniform(0, 1, (m, 2))
+spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.3, a=60.0, b=8.0, c=45.0)
+kw = dict(amp=1.3, a=60.0, b=8.0, c=45.0)
+alpha, logdet, _, _ = ops.gp_solve(spec, X, y, e)
+a_ref, ld_ref = O.gp_solve(O.kernel_matrix("gauss", X, **kw), y, e)
+yp = ops.gp_predict(spec, X, alpha, Xs)
+yp_ref = O.kernel_matrix("gauss", Xs, X, **kw) @ a_ref
+assert np.abs(alpha - a_ref).max() <= 1e-10 * np.abs(a_ref).max(), np.abs(alpha - a_ref).max()
+assert abs(logdet - ld_ref) <= 1e-11 * abs(ld_ref)
+assert np.abs(yp - yp_ref).max() <= 1e-10 * np.abs(yp_ref).max()
+print("OK")
+''' % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
