@@ -168,14 +168,14 @@ def main():
         if acc.get("syrk_ms", 0) > 0:
             ach = acc["syrk_flops"] / (acc["syrk_ms"] * 1e-3) / 1e12          # per GPU (rank 0's share when N > 1)
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_v4_pmc_bench_n65536.json")
+            pmc = os.path.join(ROOT, "profiles", "r01_v6_pmc_bench_n65536.json")
             if world == 1 and n == 65536 and os.path.exists(pmc):
                 # HBM bytes per launch of this kernel for this exact workload, from separate rocprofv3 --pmc
                 # passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_bench.sh), calibration notes inside the file
                 traffic = json.load(open(pmc))["_derived"]["syrk_hbm_bytes_per_launch"]
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                               "kernel": "syrk_dtv_kernel<4, NSEG=2>" if world == 1 else "syrk_dist_kernel (rank 0)",
+                               "kernel": ("syrk_segs_kernel<4>" if n >= 28672 else "syrk_dtv_kernel<4, 2>") if world == 1 else "syrk_dist2_kernel (rank 0)",
                                "launches": int(acc["syrk_launches"]),
                                "avg_launch_ms": acc["syrk_ms"] / max(acc["syrk_launches"], 1)}
         if "chol_ms" in acc:

@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = co
 for fn in glob.glob(R + "/gpurun_out/pmcb_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
         nm = r["Kernel_Name"]
-        k = "syrk_dtv_kernel<4, NSEG=2>" if ("syrk_dtv" in nm and "<4, 2>(" in nm) else ("kbuild_lower_kernel" if "kbuild_lower" in nm else None)
+        k = "syrk_segs_kernel<4>" if ("syrk_segs_kernel<4>" in nm) else ("kbuild_lower_kernel" if "kbuild_lower" in nm else None)
         if k is None: continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 out = {}

@@ -110,6 +110,32 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void syrk_dtv_kernel(doub
     gemm_tile_dtv<NW, TGP_PW, NSEG>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
 }
 
+// Trailing update with a compile-time list of NSEG factored panels (depth 256 * NSEG): P.a[s] points at the row of
+// panel s that corresponds to the first trailing row (P.b is filled in per tile).  Same tile map as above.
+template <int NSEG>
+__global__ __launch_bounds__(256, 2) void syrk_segs_kernel(double *Abase, int64_t Np, int ob, int T, int strip, SegPtrs<NSEG> P) {
+    int ti, tj;
+    if (strip == 0) {
+        tilemap(blockIdx.x, T, ti, tj);
+        if (ti < 0) return;
+    } else {
+        tj = (int)(blockIdx.x % strip);
+        ti = (int)(blockIdx.x / strip);
+        if (ti < tj || ti >= T) return;
+    }
+    const int64_t pj = ob + (tj >> 1);
+    const int64_t I = (int64_t)TGP_PW * ob + (int64_t)TGP_TB * ti;
+    double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
+    const int64_t oa = (int64_t)ti * TGP_TB * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
+    SegPtrs<NSEG> sp;
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        sp.a[s] = P.a[s] + oa;
+        sp.b[s] = P.a[s] + obb;
+    }
+    gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, C);
+}
+
 // First-generation 128x128 diagonal-block kernel (kept for A/B runs, TGP_POTRF_VARIANT=0; the
 // default is potrf_v2::potrf128_kernel in potrf128.h).  In-LDS Gauss-Jordan: after step j, columns <= j of T hold L^-1 rows, columns > j the Schur
 // complement; column j of L goes to global memory as soon as it is final.
@@ -269,13 +295,16 @@ void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int str
 }
 }  // namespace
 
-// Right-looking factorisation.  Panels are taken in pairs so that the bulk of the trailing matrix is
-// updated once per 512 columns (half the C traffic and half the tile prologues of a depth-256
-// update):   F(k) -> U1: panel k+1 only, depth 256 -> F(k+1) -> U2: everything right of it, depth 512.
-// Default (TGP_CHOL_MODE=2) adds look-ahead: the update is split into the tile columns of the next pair
-// (U2a) and the rest (U2b), and the next pair is factored on a high-priority side stream under U2b.
-// TGP_CHOL_MODE=1: pairs without look-ahead; =0: plain depth-256 schedule (both kept for A/B runs:
-// N=65536 Cholesky 1694 / 1571 / 1551 ms for modes 0 / 1 / 2).
+// Right-looking factorisation.  Panels are taken in groups so that the bulk of the trailing matrix is updated once
+// per 512 (pairs) or 1024 (groups of four) columns: the per-tile fixed costs of the update (C read + write, pipeline
+// fill) are 13 % of a depth-256 launch, 6.8 % at depth 512 and 3.5 % at depth 1024.
+//   pairs:  F(k) -> U1: panel k+1 only, depth 256 -> F(k+1) -> U2: everything right of it, depth 512
+//   fours:  F(k) -> S1 -> F(k+1) -> S2 -> F(k+2) -> S3 -> F(k+3) -> U4: everything right of it, depth 1024
+//           (Sj: the two tile columns of panel k+j against the j panels before it, one launch of depth 256 j)
+// Both with look-ahead: the update is split into the tile columns of the next group (U2a / U4a) and the rest (U2b / U4b),
+// and the next group is factored on a high-priority side stream under the rest.
+// History at N=65536 (same tile): 1694 ms one panel at a time, 1571 pairs, 1551 pairs + look-ahead; with the DTV tile
+// 1423 ms pairs + look-ahead, 1362 ms fours + look-ahead (68.9 TF, 87.6 % of the fp64 MFMA peak).
 int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
     TGP_ARG(Np > 0 && Np % TGP_PW == 0);
     hipStream_t st = ctx->stream;
@@ -289,11 +318,21 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
             ctx->prof_events.push_back(e);
         }
     }
-    static const int mode = [] { const char *e = getenv("TGP_CHOL_MODE"); return e ? atoi(e) : 2; }();
+    // TGP_CHOL_MODE: 3 = groups of four panels (depth-1024 bulk update) with a pair-wise tail, 2 = pairs with look-ahead,
+    // 1 = pairs without look-ahead, 0 = one panel at a time.  Default: 3 from N = 28672 on (measured crossover), else 2.
+    static const int mode_env = [] { const char *e = getenv("TGP_CHOL_MODE"); return e ? atoi(e) : -1; }();
+    const int mode = mode_env >= 0 ? mode_env : (Np >= 28672 ? 3 : 2);
     static const bool want_stamps = getenv("TGP_SYRK_STAMPS") != nullptr;      // development diagnostics
     double flops = 0.0;
     int nlaunch = 0;
+    // the roofline accounting (timings 5..7) covers ONE kernel: the bulk update of the schedule in use; in mode 3 the
+    // pair-wise tail launches are run but not counted
+    bool counting = true;
     auto timed = [&](auto &&fn, double fl) -> int {
+        if (!counting) {
+            fn();
+            return 0;
+        }
         if (prof) TGP_HIP(hipEventRecord(ctx->prof_events[2 * nlaunch], st));
         fn();
         if (prof) TGP_HIP(hipEventRecord(ctx->prof_events[2 * nlaunch + 1], st));
@@ -303,22 +342,10 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
     };
     auto Wk = [&](int k) { return d_W + (int64_t)(2 * k) * TGP_TB * TGP_TB; };
     auto panel = [&](int k) { return d_A + panel_off(k, Np); };
-    if (mode == 0) {
-        for (int k = 0; k < nP; ++k) {
-            const int64_t mk = Np - (int64_t)TGP_PW * k;
-            factor_panel(st, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW);
-            const int T = (int)((mk - TGP_PW) / TGP_TB);
-            if (T > 0) {
-                const double m = (double)T * TGP_TB;
-                int rc = timed([&] { launch_syrk<1>(st, d_A, Np, k + 1, T, 0, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr); },
-                               (double)TGP_PW * m * (m + 1.0));
-                if (rc) return rc;
-            }
-        }
-    } else if (mode == 2) {
-        // look-ahead: the update after pair (k, k+1) is split into the 4 tile columns the NEXT pair lives
-        // in (U2a) and the rest (U2b); the next pair is factored on a high-priority side stream while
-        // U2b keeps the chip busy.
+    // ---- pairs with look-ahead (the schedule of TGP_CHOL_MODE=2, also the tail of mode 3) --------------------------
+    // The update after pair (k, k+1) is split into the 4 tile columns the NEXT pair lives in (U2a) and the rest
+    // (U2b); the next pair is factored on a high-priority side stream while U2b keeps the chip busy.
+    auto run_pairs = [&](int kstart, bool pairs_from_scratch) -> int {
         hipStream_t sd = ctx->side_stream;
         auto factor_pair = [&](hipStream_t s, int k) {       // F(k), U1(k), F(k+1)
             const int64_t mk = Np - (int64_t)TGP_PW * k;
@@ -328,8 +355,8 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
             launch_syrk<1>(s, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
             factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW);
         };
-        factor_pair(st, 0);
-        for (int k = 0; k + 2 < nP; k += 2) {
+        if (pairs_from_scratch) factor_pair(st, kstart);
+        for (int k = kstart; k + 2 < nP; k += 2) {
             const int T2 = (int)((Np - (int64_t)TGP_PW * (k + 2)) / TGP_TB);       // tiles from block k+2
             const double *P0 = panel(k) + (int64_t)2 * TGP_PW * TGP_PW;
             const double *P1 = panel(k + 1) + (int64_t)TGP_PW * TGP_PW;
@@ -353,6 +380,110 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
             }
             TGP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));
         }
+        return 0;
+    };
+    if (mode == 0) {
+        for (int k = 0; k < nP; ++k) {
+            const int64_t mk = Np - (int64_t)TGP_PW * k;
+            factor_panel(st, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW);
+            const int T = (int)((mk - TGP_PW) / TGP_TB);
+            if (T > 0) {
+                const double m = (double)T * TGP_TB;
+                int rc = timed([&] { launch_syrk<1>(st, d_A, Np, k + 1, T, 0, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr); },
+                               (double)TGP_PW * m * (m + 1.0));
+                if (rc) return rc;
+            }
+        }
+    } else if (mode == 3) {
+        // Groups of four panels: inside a group, panel j is brought up to date by one strip launch of depth 256 j
+        // (its two tile columns against the j panels before it) and factored; everything right of the group is then
+        // updated in one pass of depth 1024 -- U4a (the 8 tile columns of the next group) and U4b (the rest), the next
+        // group running on the side stream under U4b.
+        hipStream_t sd = ctx->side_stream;
+        auto seg_rows = [&](int kpanel, int first_block) {       // row of panel `kpanel` that belongs to `first_block`
+            return (const double *)(panel(kpanel) + (int64_t)(first_block - kpanel) * TGP_PW * TGP_PW);
+        };
+        auto small = [&](int T) {                                // steps with few tiles: the latency tile, one panel at a time
+            static const int small_t = [] { const char *e = getenv("TGP_SMALL_T"); return e ? atoi(e) : 8; }();
+            return T <= small_t;
+        };
+        auto strip_update = [&](hipStream_t s, int k0, int j) {  // panel k0+j's columns -= sum_{i<j} P_{k0+i}
+            const int ob = k0 + j;
+            const int T = (int)((Np - (int64_t)TGP_PW * ob) / TGP_TB);
+            if (small(T)) {
+                for (int i = 0; i < j; ++i)
+                    syrk_small_kernel<1><<<dim3((unsigned)(T * 8), 2u), 256, 0, s>>>(d_A, Np, ob, T, seg_rows(k0 + i, ob), nullptr);
+                return;
+            }
+            const unsigned gs = (unsigned)((int64_t)T * 2);
+            if (j == 1) {
+                SegPtrs<1> P{{seg_rows(k0, ob)}, {nullptr}};
+                syrk_segs_kernel<1><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P);
+            } else if (j == 2) {
+                SegPtrs<2> P{{seg_rows(k0, ob), seg_rows(k0 + 1, ob)}, {nullptr, nullptr}};
+                syrk_segs_kernel<2><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P);
+            } else {
+                SegPtrs<3> P{{seg_rows(k0, ob), seg_rows(k0 + 1, ob), seg_rows(k0 + 2, ob)}, {nullptr, nullptr, nullptr}};
+                syrk_segs_kernel<3><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P);
+            }
+        };
+        auto factor_group = [&](hipStream_t s, int k0) {
+            for (int j = 0; j < 4 && k0 + j < nP; ++j) {
+                if (j > 0) strip_update(s, k0, j);
+                factor_panel(s, panel(k0 + j), Np - (int64_t)TGP_PW * (k0 + j), Wk(k0 + j), ctx->d_info, (k0 + j) * TGP_PW);
+            }
+        };
+        auto bulk = [&](int k0, int ob, int T, int strip) {      // depth-1024 update from block `ob` on, T tile rows
+            if (small(T)) {
+                const int cols = strip == 0 ? T : (strip < T ? strip : T);
+                for (int i = 0; i < 4; i += 2)
+                    syrk_small_kernel<2><<<dim3((unsigned)(T * 8), (unsigned)cols), 256, 0, st>>>(
+                        d_A, Np, ob, T, seg_rows(k0 + i, ob), seg_rows(k0 + i + 1, ob));
+                return;
+            }
+            SegPtrs<4> P{{seg_rows(k0, ob), seg_rows(k0 + 1, ob), seg_rows(k0 + 2, ob), seg_rows(k0 + 3, ob)},
+                         {nullptr, nullptr, nullptr, nullptr}};
+            const unsigned gs = strip == 0 ? (unsigned)tilemap_grid(T) : (unsigned)((int64_t)T * strip);
+            syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, ob, T, strip, P);
+        };
+        // Below `tail_tiles` rows of trailing matrix the deeper grouping no longer pays (its strips and the longer
+        // serial chain cost more than the per-tile overhead it saves: crossover at N ~ 24k): the tail runs in pairs.
+        static const int tail_tiles = [] { const char *e = getenv("TGP_QUAD_TAIL_TILES"); return e ? atoi(e) : 128; }();
+        factor_group(st, 0);
+        for (int k = 0; k + 4 < nP; k += 4) {
+            const int T4 = (int)((Np - (int64_t)TGP_PW * (k + 4)) / TGP_TB);        // tiles from block k+4
+            if (T4 <= tail_tiles) {
+                // hand-over: apply this group to everything right of it in one go, then continue pair-wise from k+4
+                const double m = (double)T4 * TGP_TB;
+                int rc = timed([&] { bulk(k, k + 4, T4, 0); }, 4.0 * TGP_PW * m * (m + 1.0));
+                if (rc) return rc;
+                counting = false;
+                rc = run_pairs(k + 4, true);
+                counting = true;
+                if (rc) return rc;
+                break;
+            }
+            {   // U4a: the 8 tile columns of the next group
+                const double rows = (double)T4 * TGP_TB, w = (T4 < 8 ? T4 : 8) * (double)TGP_TB;
+                const double elems = w * (rows - w) + w * (w + 1.0) / 2.0;
+                int rc = timed([&] { bulk(k, k + 4, T4, 8); }, 2.0 * 4.0 * TGP_PW * elems);
+                if (rc) return rc;
+            }
+            TGP_HIP(hipEventRecord(ctx->ev[4], st));
+            TGP_HIP(hipStreamWaitEvent(sd, ctx->ev[4], 0));
+            factor_group(sd, k + 4);
+            TGP_HIP(hipEventRecord(ctx->ev[5], sd));
+            const int T5 = T4 - 8;
+            if (T5 > 0) {   // U4b: everything from block k+8 on
+                const double m = (double)T5 * TGP_TB;
+                int rc = timed([&] { bulk(k, k + 8, T5, 0); }, 4.0 * TGP_PW * m * (m + 1.0));
+                if (rc) return rc;
+            }
+            TGP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));
+        }
+    } else if (mode == 2) {
+        int rc = run_pairs(0, true);
+        if (rc) return rc;
     } else {
         for (int k = 0; k < nP; k += 2) {
             const int64_t mk = Np - (int64_t)TGP_PW * k;

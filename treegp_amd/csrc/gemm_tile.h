@@ -551,3 +551,127 @@ __device__ __forceinline__ void nt_small_tile(const double *a, int lda, const do
             else *p = acc[n][r];
         }
 }
+
+
+// The same tile for a compile-time list of NSEG operand pairs (segment s: A = ap[s], B = bp[s], both 256-wide
+// panels): C -= sum_s A_s B_s^T in one pass of depth NSEG * KDEPTH.  Used by the single-GPU trailing update
+// with NSEG = 4 (depth 1024 after a group of four panels): per-tile fixed costs (C read + write, pipeline fill)
+// are 6.8 % of a depth-512 launch and 3.5 % of a depth-1024 one.
+template <int NSEG>
+struct SegPtrs {
+    const double *a[NSEG];
+    const double *b[NSEG];
+};
+
+template <int NW, int KDEPTH, int NSEG>
+__device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, double *c_ptr) {
+    static_assert(NSEG >= 1, "compile-time segment list");
+    constexpr int LD = TGP_PW;
+    constexpr int LSB = 18;
+    constexpr int BPT = 16 / NW;
+    constexpr int BROWS = 8 * NW;
+    __shared__ __attribute__((aligned(16))) double ldsB[2][128 * LSB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    __amdgpu_buffer_rsrc_t ra[NSEG], rb[NSEG];
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        ra[s] = tile_rsrc(sp.a[s], 32 * NW * LD * 8);
+        rb[s] = tile_rsrc(sp.b[s], 128 * LD * 8);
+    }
+    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(c_ptr, 32 * NW * LD * 8);
+    const int va = ((32 * w + l15) * LD + 2 * l4) * 8;
+    const int srow = tid >> 3, kp = (tid & 7) * 2;
+    const int vb = (srow * LD + kp) * 8;
+    const int vc = ((32 * w + l4) * LD + l15) * 8;
+    const int fb = l15 * LSB + 2 * l4;
+
+    double2 areg[2][2][2];                                      // [set][m][h]
+    double2 rbst[BPT];
+    auto load_a = [&](double2 (&dst)[2][2], __amdgpu_buffer_rsrc_t src, int k0) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) dst[m][h] = buf_ld2(src, va, (m * 16 * LD + k0 + 8 * h) * 8);
+    };
+    auto load_b = [&](__amdgpu_buffer_rsrc_t src, int k0) {
+#pragma unroll
+        for (int s = 0; s < BPT; ++s) rbst[s] = buf_ld2(src, vb, (s * BROWS * LD + k0) * 8);
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < BPT; ++s) *reinterpret_cast<double2 *>(&ldsB[buf][(srow + BROWS * s) * LSB + kp]) = rbst[s];
+    };
+    load_a(areg[0], ra[0], 0);
+    load_b(rb[0], 0);
+
+    d4 acc[2][8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][n][r] = buf_ld1(rc, vc, ((m * 16 + 4 * r) * LD + n * 16) * 8);
+    store_b(0);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[m][n] = -acc[m][n];
+
+    constexpr int cps = KDEPTH / KB;
+    static_assert(cps % 2 == 0, "chunks are processed in register-set pairs");
+    // chunk cc of a segment; `nsrc_*` = where the chunk after it comes from (same segment, or chunk 0 of the next)
+    auto step = [&](const int cc, const bool last_seg, __amdgpu_buffer_rsrc_t sa, __amdgpu_buffer_rsrc_t sb,
+                    __amdgpu_buffer_rsrc_t na, __amdgpu_buffer_rsrc_t nb, double2 (&cur)[2][2], double2 (&nxt)[2][2]) {
+        const int buf = cc & 1;
+        const bool wrap = (cc + 1 == cps);                       // wave-uniform
+        const bool more = !(wrap && last_seg);
+        if (more) {
+            const int k0 = wrap ? 0 : (cc + 1) * KB;
+            load_a(nxt, wrap ? na : sa, k0);
+            load_b(wrap ? nb : sb, k0);
+        }
+        const double *Bs = ldsB[buf];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double2 bf[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) bf[n] = *reinterpret_cast<const double2 *>(&Bs[fb + n * 16 * LSB + 8 * h]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m][h].x, bf[n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m][h].y, bf[n].y, acc[m][n], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) store_b(buf ^ 1);
+        __syncthreads();
+    };
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        const bool last = (s == NSEG - 1);
+        const __amdgpu_buffer_rsrc_t na = ra[last ? s : s + 1], nb = rb[last ? s : s + 1];
+#pragma unroll 1
+        for (int cc = 0; cc < cps; cc += 2) {
+            step(cc, last, ra[s], rb[s], na, nb, areg[0], areg[1]);
+            step(cc + 1, last, ra[s], rb[s], na, nb, areg[1], areg[0]);
+        }
+    }
+
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf_st1(-acc[m][n][r], rc, vc, ((m * 16 + 4 * r) * LD + n * 16) * 8);
+}
