@@ -39,7 +39,7 @@ def test_world_of_one_matches_single_gpu_path():
     _lib.load_library().tgp_reset_stream(ctx)
 
 
-@pytest.mark.parametrize("G,n", [(2, 1500), (3, 2300), (4, 1100), (8, 4500)])
+@pytest.mark.parametrize("G,n", [(2, 1500), (3, 2300), (4, 1100), (8, 4500), (5, 7000), (8, 12000), (6, 257), (4, 513)])
 def test_virtual_ranks(G, n):
     import torch
     from treegp_amd import _lib, ops
