@@ -208,6 +208,11 @@ int tgp_dd_update(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t N
 int tgp_dd_update2(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
                    const double *d_gathered0, int cmax0, const double *d_gathered1, int cmax1, int col_lo,
                    int col_hi);
+/* general form: after the GROUP of nseg (1..4) consecutive panels kpanel .. kpanel+nseg-1 in one pass of depth
+ * 256 nseg.  d_gathered[s] / cmax[s] (host arrays) describe the all-gathered panel kpanel+s (blocks > kpanel+s);
+ * tile columns col_lo..col_hi count from block kpanel+nseg.  nseg = 1 and 2 are tgp_dd_update / tgp_dd_update2.   */
+int tgp_dd_update_group(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
+                        int nseg, const double *const *d_gathered, const int *cmax, int col_lo, int col_hi);
 /* Replicated factor for the solves: store panel kpanel into d_Afull, a full single-GPU packed matrix
  * (tgp_panel_elems(Np) doubles) kept on every rank -- its 256x256 diagonal block from the broadcast buffer
  * (d_bcast, may be NULL) and/or the rows below it from the all-gathered panel (d_gathered, may be NULL).

@@ -147,6 +147,30 @@ class NumpyLocalOps(object):
             out[i * BLK * BLK:(i + 1) * BLK * BLK] = torch.from_numpy(self.rows[b][:, k * BLK:(k + 1) * BLK].ravel())
         return out
 
+    def update_group(self, k, bufs, cmaxs, col_lo=0, col_hi=-1, side=False):
+        """group k .. k+ns-1: the blocks > k+ns-1 get all ns panels' contributions; columns count from block k+ns"""
+        G, ns = self.G, len(bufs)
+        Ps = [b.numpy() for b in bufs]
+        ncol = 2 * (self.nB - k - ns)
+        if col_hi < 0 or col_hi > ncol:
+            col_hi = ncol
+
+        def blk(s, b):
+            r = b % G
+            idx = (b - first_ge(k + s + 1, r, G)) // G
+            o = (r * cmaxs[s] + idx) * BLK * BLK
+            return Ps[s][o:o + BLK * BLK].reshape(BLK, BLK)
+        for bi in self.blocks:
+            if bi <= k + ns - 1:
+                continue
+            for bj in range(k + ns, bi + 1):
+                for half in (0, 1):
+                    tcol = 2 * (bj - k - ns) + half
+                    if col_lo <= tcol < col_hi:
+                        c0 = bj * BLK + half * 128
+                        sl = slice(half * 128, (half + 1) * 128)
+                        self.rows[bi][:, c0:c0 + 128] -= sum(blk(s, bi) @ blk(s, bj)[sl, :].T for s in range(ns))
+
     def update2(self, k, gathered0, cmax0, gathered1, cmax1, col_lo=0, col_hi=-1):
         """pair (k, k+1): the blocks > k+1 get both panels' contributions; columns count from block k+2"""
         G = self.G

@@ -39,8 +39,10 @@ def test_world_of_one_matches_single_gpu_path():
     _lib.load_library().tgp_reset_stream(ctx)
 
 
-@pytest.mark.parametrize("G,n", [(2, 1500), (3, 2300), (4, 1100), (8, 4500), (5, 7000), (8, 12000), (6, 257), (4, 513)])
-def test_virtual_ranks(G, n):
+@pytest.mark.parametrize("G,n,group", [(2, 1500, 2), (3, 2300, 2), (4, 1100, 2), (8, 4500, 2), (5, 7000, 2), (8, 12000, 2),
+                                       (6, 257, 2), (4, 513, 2), (3, 3000, 4), (8, 6000, 4), (2, 2700, 3), (4, 1900, 1)])
+def test_virtual_ranks(G, n, group, monkeypatch):
+    monkeypatch.setenv("TGP_DIST_GROUP", str(group))
     import torch
     from treegp_amd import _lib, ops
     from treegp_amd.dist import DistributedGP

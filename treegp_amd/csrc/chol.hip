@@ -236,6 +236,55 @@ __global__ __launch_bounds__(256, 2) void syrk_dist2_kernel(double *Aloc, const 
     gemm_tile_dtv<4, TGP_PW, 2>(a0, b0, c, a1, b1);
 }
 
+// the same after a GROUP of NSEG consecutive panels kpanel .. kpanel+NSEG-1 in one pass of depth 256 NSEG.
+// Gathered panel s holds the blocks > kpanel+s ([rank][cmax[s]][256][256]); tiles are counted from block kpanel+NSEG.
+template <int NSEG>
+struct DistSegs {
+    const double *P[NSEG];
+    int cmax[NSEG];
+};
+// Tile enumeration of a rank's share, XCD-aware like the single-GPU tilemap: blocks b, b+8, ... share an XCD (and its
+// L2); each XCD works through 8 x 8 super-tiles (8 local tile rows against 8 tile columns) dealt round-robin.  The
+// share is a staircase (local tile row lt reaches up to its own global column), so only super-tiles that contain
+// valid tiles are enumerated: `start` holds, per group of 8 local tile rows, the index of its first super-tile.
+struct DistMap {
+    int start[258];           // prefix of super-tiles per row group; start[ngroups] = total  (N up to 262144 on one rank)
+    int ngroups;
+};
+template <int NSEG>
+__global__ __launch_bounds__(256, 2) void syrk_distn_kernel(double *Aloc, const int64_t *__restrict__ loff, int kpanel, int G,
+                                                            int g, DistSegs<NSEG> S, int col_lo, int ncol, int nrows,
+                                                            DistMap M) {
+    const int64_t b = blockIdx.x;
+    const int64_t st = ((b >> 3) >> 6) * 8 + (b & 7);
+    if (st >= M.start[M.ngroups]) return;
+    int R = 0;
+    for (int step = 128; step > 0; step >>= 1)
+        if (R + step <= M.ngroups && M.start[R + step] <= st) R += step;      // last group with start <= st
+    const int within = (int)((b >> 3) & 63);
+    const int lt = R * 8 + (within >> 3);
+    const int ct = (int)(st - M.start[R]) * 8 + (within & 7);
+    if (lt >= nrows || ct >= ncol) return;
+    const int64_t gtj = (int64_t)ct + col_lo;
+    const int64_t s0 = kpanel + NSEG;
+    const int64_t bi = dist_first_ge(s0, g, G) + (int64_t)(lt >> 1) * G;
+    const int64_t gti = 2 * (bi - s0) + (lt & 1);
+    if (gtj > gti) return;
+    const int64_t bj = s0 + (gtj >> 1);
+    const int rj = (int)(bj % G);
+    const int64_t hi = (lt & 1) * TGP_TB, hj = (gtj & 1) * TGP_TB;
+    SegPtrs<NSEG> sp;
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        const int64_t first = kpanel + s + 1;                 // first block held by gathered panel s
+        const int64_t is = (bi - dist_first_ge(first, g, G)) / G, js = (bj - dist_first_ge(first, rj, G)) / G;
+        sp.a[s] = S.P[s] + (((int64_t)g * S.cmax[s] + is) * TGP_PW + hi) * TGP_PW;
+        sp.b[s] = S.P[s] + (((int64_t)rj * S.cmax[s] + js) * TGP_PW + hj) * TGP_PW;
+    }
+    double *c = Aloc + loff[bj] + (((bi - dist_first_ge(bj, g, G)) / G) * TGP_PW + hi) * TGP_PW + hj;
+    gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, c);
+}
+
 inline void run_potrf128(hipStream_t st, double *A, int lda, double *W, int *info, int base) {
     static const int variant = [] { const char *e = getenv("TGP_POTRF_VARIANT"); return e ? atoi(e) : 2; }();
     if (variant == 0) potrf128_lds_kernel<<<1, 256, 0, st>>>(A, lda, W, info, base);
@@ -584,6 +633,56 @@ int launch_syrk_dist2(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64
     if (nloc <= 0 || ncol <= 0) return 0;
     dim3 grid((unsigned)ncol, (unsigned)(2 * nloc));
     syrk_dist2_kernel<<<grid, 256, 0, ctx->stream>>>(d_Aloc, d_loff, kpanel, G, g, cmax0, d_P0, cmax1, d_P1, col_lo);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int NSEG>
+static void launch_distn(hipStream_t st, unsigned grid, double *d_Aloc, const int64_t *d_loff, int kpanel, int G, int g,
+                         const double *const *P, const int *cmax, int col_lo, int ncol, int nrows, const DistMap &M) {
+    DistSegs<NSEG> S;
+    for (int s = 0; s < NSEG; ++s) {
+        S.P[s] = P[s];
+        S.cmax[s] = cmax[s];
+    }
+    syrk_distn_kernel<NSEG><<<grid, 256, 0, st>>>(d_Aloc, d_loff, kpanel, G, g, S, col_lo, ncol, nrows, M);
+}
+
+int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
+                      const double *const *d_P, const int *cmax, int col_lo, int col_hi) {
+    TGP_ARG(nseg >= 1 && nseg <= 4);
+    const int64_t nB = Np / TGP_PW;
+    const int64_t nloc = dist_panel_blocks(kpanel + nseg, nB, g, G);      // local blocks > kpanel + nseg - 1
+    const int64_t ncol_all = 2 * (nB - kpanel - nseg);
+    if (col_hi < 0 || col_hi > ncol_all) col_hi = (int)ncol_all;
+    if (col_lo < 0) col_lo = 0;
+    const int64_t ncol = (int64_t)col_hi - col_lo;
+    if (nloc <= 0 || ncol <= 0) return 0;
+    // staircase of valid tiles: local tile row lt reaches global tile column gti(lt); super-tiles per group of 8 rows
+    const int nrows = (int)(2 * nloc);
+    const int64_t s0 = kpanel + nseg, fb = dist_first_ge(s0, g, G);
+    DistMap M;
+    M.ngroups = (nrows + 7) / 8;
+    TGP_ARG(M.ngroups <= 257);
+    int total = 0;
+    for (int R = 0; R < M.ngroups; ++R) {
+        M.start[R] = total;
+        const int ltmax = (R * 8 + 7 < nrows ? R * 8 + 7 : nrows - 1);
+        const int64_t gti = 2 * (fb + (int64_t)(ltmax >> 1) * G - s0) + (ltmax & 1);     // last valid global column
+        int64_t reach = gti - col_lo + 1;                                                // valid columns of this launch
+        if (reach > ncol) reach = ncol;
+        total += reach > 0 ? (int)((reach + 7) / 8) : 0;
+    }
+    M.start[M.ngroups] = total;
+    if (total == 0) return 0;
+    const unsigned grid = (unsigned)(((total + 7) / 8) * 8 * 64);
+    hipStream_t st = ctx->stream;
+    switch (nseg) {
+        case 1: launch_distn<1>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M); break;
+        case 2: launch_distn<2>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M); break;
+        case 3: launch_distn<3>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M); break;
+        default: launch_distn<4>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M); break;
+    }
     TGP_HIP(hipGetLastError());
     return 0;
 }

@@ -83,6 +83,13 @@ int tgp_dd_update2(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t 
     return launch_syrk_dist2(ctx, d_Aloc, d_loff, Np, kpanel, G, g, d_gathered0, cmax0, d_gathered1, cmax1, col_lo, col_hi);
 }
 
+int tgp_dd_update_group(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
+                        const double *const *d_gathered, const int *cmax, int col_lo, int col_hi) {
+    TGP_ARG(d_Aloc && d_loff && d_gathered && cmax && nseg >= 1 && nseg <= 4);
+    for (int s = 0; s < nseg; ++s) TGP_ARG(d_gathered[s] && cmax[s] >= 0);
+    return launch_syrk_distn(ctx, d_Aloc, d_loff, Np, kpanel, G, g, nseg, d_gathered, cmax, col_lo, col_hi);
+}
+
 // ---- replicated factor for the solves ---------------------------------------------------------------------------
 // Every rank sees every panel once (diagonal block in the broadcast, the rows below in the all-gather).  Keeping them,
 // in the single-GPU packed layout (17 GB at N = 65536, 69 GB at 131072: what 288 GB of HBM per GPU are for), lets each

@@ -221,6 +221,16 @@ class HipLocalOps(object):
                                           self._p(gathered0), cmax0, self._p(gathered1), cmax1, col_lo, col_hi),
                   "tgp_dd_update2")
 
+    def update_group(self, k, bufs, cmaxs, col_lo=0, col_hi=-1, side=False):
+        """after the group of len(bufs) consecutive panels k, k+1, ... in one pass of depth 256 len(bufs); tile columns
+        count from block k + len(bufs)"""
+        ns = len(bufs)
+        ctx = self.ctx_side if side else self.ctx
+        ptrs = (C.c_void_p * ns)(*[b.data_ptr() for b in bufs])
+        cm = (C.c_int * ns)(*[int(c) for c in cmaxs])
+        self._chk(self.lib.tgp_dd_update_group(ctx, self._p(self.A), self._p(self.d_loff), self.Np, k, self.G, self.g, ns,
+                                               ptrs, cm, col_lo, col_hi), "tgp_dd_update_group", ctx)
+
     @property
     def replicated(self):
         return self.Afull is not None
@@ -275,8 +285,11 @@ class DistributedCholesky(object):
         self.G, self.g = comm.size, comm.rank
         assert (ops.G, ops.g) == (self.G, self.g)
         self.nB, self.Np = ops.nB, ops.Np
-        # all-gathered panels: two pairs (the pair the bulk update reads, the pair being produced underneath it)
-        self.gathered = [ops.empty(max(self.G * ops.cmax0, 1) * BLK * BLK) for _ in range(4)]
+        # panels are taken in groups of `group` (4 from N = 28672 on, else 2: the single-GPU crossover); all-gathered
+        # panels: two groups of buffers (the group the bulk update reads, the group being produced underneath it)
+        self.group = int(os.environ.get("TGP_DIST_GROUP", "4" if self.Np >= 28672 else "2"))
+        assert self.group in (1, 2, 3, 4)
+        self.gathered = [ops.empty(max(self.G * ops.cmax0, 1) * BLK * BLK) for _ in range(2 * self.group)]
         self.timer = timer            # optional callable(): returns an event-like with .record()/.elapsed_time()
         self.update_ms = 0.0          # local trailing-update kernel time of the last factorize()
         self.update_flops = 0.0       # algorithmic flops of this rank's share
@@ -292,15 +305,16 @@ class DistributedCholesky(object):
         return 2.0 * BLK * elems
 
     def factorize(self):
-        """Right-looking factorisation, panels taken in PAIRS, look-ahead on two streams.
+        """Right-looking factorisation, panels taken in GROUPS of `self.group`, look-ahead on two streams.
 
-        Side stream (high priority), for the pair (k, k+1): diagonal block of panel k on its owner,
-        broadcast, local solves, all-gather of panel k; depth-256 update of panel k+1's two tile
-        columns with it; then the same chain for panel k+1.  Main stream: U2a, the four tile columns of
-        the NEXT pair with both gathered panels (depth 512), after which the side stream may start on
-        that pair; then U2b, the bulk of the trailing matrix in one depth-512 pass, concurrent with it.
-        Halves the C traffic and the per-tile prologues of the bulk update (as the single-GPU driver does)."""
-        ops, comm, G, g, nB = self.ops, self.comm, self.G, self.g, self.nB
+        Side stream (high priority), for the group k .. k+GS-1: for every panel j of it, first the depth-256 j
+        update of its two tile columns with the j gathered panels before it (one launch), then its diagonal block
+        on its owner, broadcast, local solves, all-gather.  Main stream: Ua, the 2 GS tile columns of the NEXT
+        group with all GS gathered panels (depth 256 GS), after which the side stream may start on that group,
+        and then Ub, the bulk of the trailing matrix in one pass of the same depth, concurrent with it.
+        Per-tile fixed costs of the update (C read + write, pipeline fill) fall from 13 % at depth 256 to 6.8 %
+        at 512 and 3.5 % at 1024 -- the single-GPU driver's schedule, with collectives."""
+        ops, comm, G, g, nB, GS = self.ops, self.comm, self.G, self.g, self.nB, self.group
         events = []
         self.update_flops, self.update_launches = 0.0, 0
         keep = bool(getattr(ops, "replicated", False))           # also build the replicated factor for the solves
@@ -329,20 +343,24 @@ class DistributedCholesky(object):
                 w.wait()                                         # side stream: that gather has landed
                 ops.keep_rows(kk, buf, cc)
 
-        def side_pair(k, bufs):
-            """panels k and k+1 (where they exist) on the side stream; returns their gather handles"""
+        def side_group(k, bufs):
+            """panels k .. k+GS-1 (those that exist) on the side stream; returns [(gather handle, cmax)] per panel"""
             flush_keeps()
-            w0, c0 = factor_and_gather(k, bufs[0])
-            w1, c1 = None, 0
-            if k + 1 < nB:
-                w0.wait()                                        # side stream: panel k is on every rank
-                ops.update(k, bufs[0], c0, 0, 2, side=True)      # panel k+1's columns, depth 256
-                if keep:
-                    ops.keep_rows(k, bufs[0], c0)
-                w1, c1 = factor_and_gather(k + 1, bufs[1])
-                if keep and w1 is not None:
-                    pending.append((w1, k + 1, bufs[1], c1))     # copied at the start of the next side chain
-            return (w0, c0), (w1, c1)
+            out = []
+            for j in range(GS):
+                if k + j >= nB:
+                    break
+                if j > 0:
+                    w, c = out[j - 1]
+                    w.wait()                                     # side stream: panel k+j-1 is on every rank
+                    if keep:
+                        ops.keep_rows(k + j - 1, bufs[j - 1], c)
+                    # panel k+j's two tile columns against the j panels before it, one launch of depth 256 j
+                    ops.update_group(k, bufs[:j], [oc for _, oc in out], 0, 2, side=True)
+                out.append(factor_and_gather(k + j, bufs[j]))
+            if keep and out and out[-1][0] is not None:
+                pending.append((out[-1][0], k + len(out) - 1, bufs[len(out) - 1], out[-1][1]))   # copied by the next chain
+            return out
 
         def timed(fn):
             if self.timer is not None:
@@ -356,22 +374,22 @@ class DistributedCholesky(object):
 
         ops.side_wait_main()                                     # K build (main) precedes panel 0
         with ops.on_side():
-            (w0, c0), (w1, c1) = side_pair(0, self.gathered[0:2])
-        k = 0
-        while k + 2 < nB:
-            cur = self.gathered[(k & 2):(k & 2) + 2]
-            nxt = self.gathered[2 - (k & 2):4 - (k & 2)]
-            w0.wait()
-            w1.wait()                                            # main stream: both panels are on every rank
-            timed(lambda: ops.update2(k, cur[0], c0, cur[1], c1, 0, 4))          # U2a: the next pair's columns
+            cur_w = side_group(0, self.gathered[:GS])
+        k, flip = 0, 0
+        while k + GS < nB:
+            cur = self.gathered[flip * GS:(flip + 1) * GS]
+            nxt = self.gathered[(1 - flip) * GS:(2 - flip) * GS]
+            for w, _ in cur_w:
+                w.wait()                                         # main stream: the whole group is on every rank
+            cm = [c for _, c in cur_w]
+            timed(lambda: ops.update_group(k, cur, cm, 0, 2 * GS))           # Ua: the next group's columns
             ops.side_wait_main()
             with ops.on_side():
-                (n0, nc0), (n1, nc1) = side_pair(k + 2, nxt)
-            timed(lambda: ops.update2(k, cur[0], c0, cur[1], c1, 4, -1))         # U2b: the bulk
-            self.update_flops += 2.0 * self._local_update_flops(k + 1)
+                nxt_w = side_group(k + GS, nxt)
+            timed(lambda: ops.update_group(k, cur, cm, 2 * GS, -1))          # Ub: the bulk
+            self.update_flops += GS * self._local_update_flops(k + GS - 1)
             self.update_launches += 2
-            (w0, c0), (w1, c1) = (n0, nc0), (n1, nc1)
-            k += 2
+            cur_w, k, flip = nxt_w, k + GS, 1 - flip
         if pending:
             with ops.on_side():
                 flush_keeps()
