@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The depth-512 trailing update alone, back to back on random data (same conditions as
-tools/vendor_dgemm.py's sustained GEMM), with rocm-smi clock/power samples alongside."""
+"""The trailing update alone, back to back on random data (same conditions as tools/vendor_dgemm.py's
+sustained GEMM), with rocm-smi clock/power samples alongside.  Default: the depth-512 kernel; with
+TGP_DEBUG_SEGS=1 in the environment the depth-1024 kernel of the groups-of-four schedule."""
 import ctypes as C
 import subprocess
 import sys

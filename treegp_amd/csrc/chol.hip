@@ -696,6 +696,21 @@ int tgp_debug_syrk_loop(tgp_ctx *ctx, double *d_A, int64_t Np, int reps, double 
     const int T2 = (int)((Np - (int64_t)TGP_PW * 2) / TGP_TB);
     const double *P0 = d_A + panel_off(0, Np) + (int64_t)2 * TGP_PW * TGP_PW;
     const double *P1 = d_A + panel_off(1, Np) + (int64_t)TGP_PW * TGP_PW;
+    if (getenv("TGP_DEBUG_SEGS")) {           // the depth-1024 kernel on the same two panels twice
+        SegPtrs<4> P{{P0, P1, P0, P1}, {nullptr, nullptr, nullptr, nullptr}};
+        const unsigned gs = (unsigned)tilemap_grid(T2);
+        syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, 2, T2, 0, P);
+        TGP_HIP(hipEventRecord(ctx->ev[0], st));
+        for (int r = 0; r < reps; ++r) syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, 2, T2, 0, P);
+        TGP_HIP(hipEventRecord(ctx->ev[1], st));
+        TGP_HIP(hipStreamSynchronize(st));
+        float ms2 = 0.f;
+        TGP_HIP(hipEventElapsedTime(&ms2, ctx->ev[0], ctx->ev[1]));
+        const double m2 = (double)T2 * TGP_TB;
+        *ms_per_launch = ms2 / reps;
+        *flops_per_launch = 4.0 * TGP_PW * m2 * (m2 + 1.0);
+        return 0;
+    }
     launch_syrk<2>(st, d_A, Np, 2, T2, 0, P0, P1);
     TGP_HIP(hipEventRecord(ctx->ev[0], st));
     for (int r = 0; r < reps; ++r) launch_syrk<2>(st, d_A, Np, 2, T2, 0, P0, P1);

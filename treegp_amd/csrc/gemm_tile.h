@@ -675,3 +675,4 @@ __device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, doub
 #pragma unroll
             for (int r = 0; r < 4; ++r) buf_st1(-acc[m][n][r], rc, vc, ((m * 16 + 4 * r) * LD + n * 16) * 8);
 }
+
