@@ -39,18 +39,31 @@ def cpu_baseline(n_s, m_s):
     tm = {}
     R.solve_predict(X, y - y.mean(), y_err, Xs, iL, 1.0, timings=tm)       # single pass, first touch included
     threads = os.cpu_count()
+    blas = "unknown BLAS"
     try:
         from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        pools = threadpool_info()
+        threads = max([p.get("num_threads", 1) for p in pools] + [1])
+        blas = ", ".join(sorted({"%s %s" % (p.get("internal_api", "?"), p.get("version", "")) for p in pools
+                                 if p.get("user_api") == "blas"})) or blas
+    except Exception:
+        pass
+    cpu = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
     except Exception:
         pass
     return {
         "value": (n_s + m_s) / tm["total"], "unit": "points/s", "cores": threads, "kind": "port",
         "sample": "same star field at N=%d train / M=%d predict, one pass of the reference's SciPy calls "
                   "(pdist+exp+squareform %.2fs, dpotrf %.2fs = %.1f GFLOP/s on %d BLAS threads, cho_solve %.3fs, "
-                  "cdist+exp %.2fs single-thread); the O(N^3) factorisation makes points/s size-dependent"
+                  "cdist+exp %.2fs single-thread); host: %s, %d logical CPUs, %s; the O(N^3) factorisation makes "
+                  "points/s size-dependent"
                   % (n_s, m_s, tm["kbuild"], tm["cholesky"], n_s ** 3 / 3 / tm["cholesky"] / 1e9, threads,
-                     tm["cho_solve"], tm["cross_kernel"]),
+                     tm["cho_solve"], tm["cross_kernel"], cpu, os.cpu_count() or 0, blas),
         "phases_s": {k: round(v, 4) for k, v in tm.items()},
     }
 
