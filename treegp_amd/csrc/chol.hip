@@ -7,10 +7,12 @@
 //   gemm<1>   column half 1    A[:,128:256] -= X X_d^T (depth 128)
 //   potrf128  diag block 1     L22, W22
 //   gemm<0>   rows below       X = A W22^T
-// Schedule (launch_potrf): panels in pairs, F(k) -> U1 (panel k+1 only, depth 256) -> F(k+1) ->
-// U2 (everything to the right, depth 512, <- N^3/3 flops), with U2 split so that the next pair is
-// factored on a priority side stream underneath it.
-// All GEMMs are the NT tile of gemm_tile.h on v_mfma_f64_16x16x4_f64; two workgroups per CU.
+// Schedule (launch_potrf): panels in groups of four (pairs below N = 28672): inside a group every panel is first
+// brought up to date by one strip launch against the panels before it, then factored; everything to the right of
+// the group is updated in ONE pass of depth 1024 (512) -- that is where the N^3/3 flops are -- split so that the
+// next group is factored on a priority side stream underneath it.
+// The GEMMs are the NT tiles of gemm_tile.h on v_mfma_f64_16x16x4_f64 (trailing update: the DTV tile, A straight
+// into VGPRs; panel solves: the 2x2-wave tile; few-tile steps: the latency tile); two workgroups per CU.
 #include "tgp_internal.h"
 
 #include "gemm_tile.h"
