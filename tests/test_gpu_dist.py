@@ -140,3 +140,36 @@ def test_sharded_pair_binning_virtual_ranks(G):
         for a, b in zip(lg[:4], one[1][:4]):
             np.testing.assert_allclose(a, b, rtol=0, atol=1e-12 * np.abs(b).max())
         np.testing.assert_allclose(boot, one[2], rtol=0, atol=1e-12 * np.abs(one[2]).max())
+
+
+def test_update_entry_points_agree():
+    """tgp_dd_update / tgp_dd_update2 are the one- and two-panel forms of tgp_dd_update_group: same bytes out."""
+    import torch
+    from treegp_amd import _lib
+    from treegp_amd.dist import HipLocalOps, BLK
+    spec, X, y, y_err, Xs = _problem(2300, 10)
+    dev = torch.device("cuda", 0)
+    ops_ = HipLocalOps(_lib.new_ctx(0), spec, len(y), 1, 0, dev)
+    from treegp_amd._lib import as_xy
+    dX, de = ops_.to_device(as_xy(X)), ops_.to_device(y_err)
+    ops_.kbuild(dX, de)
+    torch.cuda.synchronize()
+    base = ops_.A.clone()
+    rng = np.random.default_rng(0)
+    nB = ops_.nB
+    g0 = ops_.to_device(1e-3 * rng.standard_normal((nB - 1) * BLK * BLK))       # stand-ins for gathered panels 0 and 1
+    g1 = ops_.to_device(1e-3 * rng.standard_normal((nB - 2) * BLK * BLK))
+    outs = []
+    for variant in range(2):
+        ops_.A.copy_(base)
+        if variant == 0:
+            ops_.update(0, g0, nB - 1)
+            ops_.update2(0, g0, nB - 1, g1, nB - 2, 0, -1)
+        else:
+            ops_.update_group(0, [g0], [nB - 1])
+            ops_.update_group(0, [g0, g1], [nB - 1, nB - 2], 0, -1)
+        torch.cuda.synchronize()
+        outs.append(ops_.A.clone())
+    assert torch.equal(outs[0], outs[1])
+    assert not torch.equal(outs[0], base)
+    _lib.load_library().tgp_reset_stream(ops_.ctx)

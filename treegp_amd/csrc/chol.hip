@@ -191,54 +191,8 @@ __global__ __launch_bounds__(256) void potrf128_lds_kernel(double *A, int lda, d
     }
 }
 
-// multi-GPU trailing update: rank g updates its own block rows.  P is the all-gathered panel,
-// laid out [rank][cmax blocks][256][256]; blockIdx.y = local tile row among blocks > k,
-// blockIdx.x = trailing tile column (tiles right of the diagonal exit).
-__global__ __launch_bounds__(256, 2) void syrk_dist_kernel(double *Aloc, const int64_t *__restrict__ loff, int kpanel,
-                                                           int G, int g, int cmax, const double *P, int col_lo) {
-    const int lt = blockIdx.y;
-    const int64_t gtj = (int64_t)blockIdx.x + col_lo;
-    const int64_t s0 = kpanel + 1;
-    const int64_t bi = dist_first_ge(s0, g, G) + (int64_t)(lt >> 1) * G;
-    const int64_t gti = 2 * (bi - s0) + (lt & 1);
-    if (gtj > gti) return;
-    const int64_t bj = s0 + (gtj >> 1);
-    const int rj = (int)(bj % G);
-    const int64_t idxj = (bj - dist_first_ge(s0, rj, G)) / G;
-    const double *a = P + (((int64_t)g * cmax + (lt >> 1)) * TGP_PW + (lt & 1) * TGP_TB) * TGP_PW;
-    const double *b = P + (((int64_t)rj * cmax + idxj) * TGP_PW + (gtj & 1) * TGP_TB) * TGP_PW;
-    double *c = Aloc + loff[bj] + (((bi - dist_first_ge(bj, g, G)) / G) * TGP_PW + (lt & 1) * TGP_TB) * TGP_PW +
-                (gtj & 1) * TGP_TB;
-    gemm_tile_dtv<4, TGP_PW, 1>(a, b, c, nullptr, nullptr);
-}
-
-// the same after a PAIR of panels (kpanel, kpanel + 1), depth 512: P0 / P1 are the two all-gathered panels
-// ([rank][cmax0 | cmax1 blocks][256][256]; panel k holds the blocks > k, panel k+1 the blocks > k+1), tiles
-// are counted from block kpanel + 2.  (An XCD-aware 8x8 super-tile enumeration of the rank's rectangular share
-// was tried here and lost: 54.3 vs 59.3 TF for a world of one at N = 32768.)
-__global__ __launch_bounds__(256, 2) void syrk_dist2_kernel(double *Aloc, const int64_t *__restrict__ loff, int kpanel,
-                                                            int G, int g, int cmax0, const double *P0, int cmax1,
-                                                            const double *P1, int col_lo) {
-    const int lt = blockIdx.y;
-    const int64_t gtj = (int64_t)blockIdx.x + col_lo;
-    const int64_t s0 = kpanel + 2;
-    const int64_t bi = dist_first_ge(s0, g, G) + (int64_t)(lt >> 1) * G;
-    const int64_t gti = 2 * (bi - s0) + (lt & 1);
-    if (gtj > gti) return;
-    const int64_t bj = s0 + (gtj >> 1);
-    const int rj = (int)(bj % G);
-    const int64_t hi = (lt & 1) * TGP_TB, hj = (gtj & 1) * TGP_TB;
-    const int64_t i0 = (bi - dist_first_ge(s0 - 1, g, G)) / G, j0 = (bj - dist_first_ge(s0 - 1, rj, G)) / G;
-    const int64_t i1 = (bi - dist_first_ge(s0, g, G)) / G, j1 = (bj - dist_first_ge(s0, rj, G)) / G;
-    const double *a0 = P0 + (((int64_t)g * cmax0 + i0) * TGP_PW + hi) * TGP_PW;
-    const double *b0 = P0 + (((int64_t)rj * cmax0 + j0) * TGP_PW + hj) * TGP_PW;
-    const double *a1 = P1 + (((int64_t)g * cmax1 + i1) * TGP_PW + hi) * TGP_PW;
-    const double *b1 = P1 + (((int64_t)rj * cmax1 + j1) * TGP_PW + hj) * TGP_PW;
-    double *c = Aloc + loff[bj] + (((bi - dist_first_ge(bj, g, G)) / G) * TGP_PW + hi) * TGP_PW + hj;
-    gemm_tile_dtv<4, TGP_PW, 2>(a0, b0, c, a1, b1);
-}
-
-// the same after a GROUP of NSEG consecutive panels kpanel .. kpanel+NSEG-1 in one pass of depth 256 NSEG.
+// multi-GPU trailing update: rank g updates its own block rows, after a GROUP of NSEG consecutive panels
+// kpanel .. kpanel+NSEG-1, in one pass of depth 256 NSEG.
 // Gathered panel s holds the blocks > kpanel+s ([rank][cmax[s]][256][256]); tiles are counted from block kpanel+NSEG.
 template <int NSEG>
 struct DistSegs {
@@ -609,35 +563,7 @@ int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, 
     return 0;
 }
 
-int launch_syrk_dist(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
-                     const double *d_P, int cmax, int col_lo, int col_hi) {
-    const int64_t nB = Np / TGP_PW;
-    const int64_t nloc = dist_panel_blocks(kpanel + 1, nB, g, G);     // local blocks > k
-    const int64_t ncol_all = 2 * (nB - kpanel - 1);
-    if (col_hi < 0 || col_hi > ncol_all) col_hi = (int)ncol_all;
-    if (col_lo < 0) col_lo = 0;
-    const int64_t ncol = (int64_t)col_hi - col_lo;
-    if (nloc <= 0 || ncol <= 0) return 0;
-    dim3 grid((unsigned)ncol, (unsigned)(2 * nloc));
-    syrk_dist_kernel<<<grid, 256, 0, ctx->stream>>>(d_Aloc, d_loff, kpanel, G, g, cmax, d_P, col_lo);
-    TGP_HIP(hipGetLastError());
-    return 0;
-}
 
-int launch_syrk_dist2(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
-                      const double *d_P0, int cmax0, const double *d_P1, int cmax1, int col_lo, int col_hi) {
-    const int64_t nB = Np / TGP_PW;
-    const int64_t nloc = dist_panel_blocks(kpanel + 2, nB, g, G);     // local blocks > k + 1
-    const int64_t ncol_all = 2 * (nB - kpanel - 2);
-    if (col_hi < 0 || col_hi > ncol_all) col_hi = (int)ncol_all;
-    if (col_lo < 0) col_lo = 0;
-    const int64_t ncol = (int64_t)col_hi - col_lo;
-    if (nloc <= 0 || ncol <= 0) return 0;
-    dim3 grid((unsigned)ncol, (unsigned)(2 * nloc));
-    syrk_dist2_kernel<<<grid, 256, 0, ctx->stream>>>(d_Aloc, d_loff, kpanel, G, g, cmax0, d_P0, cmax1, d_P1, col_lo);
-    TGP_HIP(hipGetLastError());
-    return 0;
-}
 
 template <int NSEG>
 static void launch_distn(hipStream_t st, unsigned grid, double *d_Aloc, const int64_t *d_loff, int kpanel, int G, int g,

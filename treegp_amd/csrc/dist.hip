@@ -71,16 +71,20 @@ int tgp_dd_trsm(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int64_t Np,
                             d_bcast + TGP_PW * TGP_PW + TGP_TB * TGP_TB);
 }
 
+// tgp_dd_update / tgp_dd_update2: the one- and two-panel forms of tgp_dd_update_group
 int tgp_dd_update(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
                   const double *d_gathered, int cmax, int col_lo, int col_hi) {
     TGP_ARG(d_Aloc && d_loff && d_gathered && cmax >= 0);
-    return launch_syrk_dist(ctx, d_Aloc, d_loff, Np, kpanel, G, g, d_gathered, cmax, col_lo, col_hi);
+    const double *P[1] = {d_gathered};
+    return launch_syrk_distn(ctx, d_Aloc, d_loff, Np, kpanel, G, g, 1, P, &cmax, col_lo, col_hi);
 }
 
 int tgp_dd_update2(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
                    const double *d_gathered0, int cmax0, const double *d_gathered1, int cmax1, int col_lo, int col_hi) {
     TGP_ARG(d_Aloc && d_loff && d_gathered0 && d_gathered1 && cmax0 >= 0 && cmax1 >= 0);
-    return launch_syrk_dist2(ctx, d_Aloc, d_loff, Np, kpanel, G, g, d_gathered0, cmax0, d_gathered1, cmax1, col_lo, col_hi);
+    const double *P[2] = {d_gathered0, d_gathered1};
+    const int cm[2] = {cmax0, cmax1};
+    return launch_syrk_distn(ctx, d_Aloc, d_loff, Np, kpanel, G, g, 2, P, cm, col_lo, col_hi);
 }
 
 int tgp_dd_update_group(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,

@@ -115,10 +115,6 @@ int launch_kbuild_lower_dist(tgp_ctx *ctx, const tgp_kernel *k, const double *d_
                              const double *d_yerr, double *d_Aloc, const int64_t *d_loff, int G, int g);
 int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base);
 int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, const double *W0, const double *W1);
-int launch_syrk_dist(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
-                     const double *d_P, int cmax, int col_lo, int col_hi);
-int launch_syrk_dist2(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
-                      const double *d_P0, int cmax0, const double *d_P1, int cmax1, int col_lo, int col_hi);
 int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
                       const double *const *d_P, const int *cmax, int col_lo, int col_hi);
 int launch_diag256_fwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y);
