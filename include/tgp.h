@@ -1,14 +1,18 @@
 /* tgp.h -- C-ABI of libtgp.so: the MI355X-native GP hot path behind treegp's Python API.
  *
  * The reference (PFLeget/treegp, pure Python) has no FFI of its own; it calls SciPy /
- * TreeCorr at three seams.  Each entry point below replaces one of those seams and cites
- * the reference lines it stands in for (paths relative to the reference root).
+ * scikit-learn / TreeCorr at a handful of seams.  Each entry point below replaces one of those
+ * seams and cites the reference lines it stands in for (paths relative to the reference root).
  *
  *   S1  kernel.__call__(X[,Y])           treegp/kernels.py:114-126, 249-276, 355-381
  *   S2  cholesky + cho_solve (+ logdet)  treegp/gp_interp.py:180-182, treegp/log_likelihood.py:29-33
  *   S3  HT @ alpha                       treegp/gp_interp.py:177,183
  *   S3b posterior covariance             treegp/gp_interp.py:184-192
  *   S4  treecorr KKCorrelation.process   treegp/two_pcf.py:297-305, 330-334, 342-362
+ *   S5  KNeighborsRegressor.predict      treegp/gp_interp.py:236-238
+ *   S6  binned_statistic_2d              treegp/meanify.py:76-107
+ *   S7  vcorr pair accumulation          treegp/utils.py:36-72
+ * followed by a device-resident tier (bench, tests) and the multi-GPU tier driven by treegp_amd/dist.py.
  *
  * Conventions
  *   - plain C types only; every array is C-contiguous float64 (or int64 where named so).
@@ -60,7 +64,8 @@ int tgp_device_count(void);
 /* phase timings (ms, hipEvent on the ctx stream) of the last call that recorded them:
  * [0] K build  [1] Cholesky total  [2] triangular solves  [3] predict  [4] pair binning
  * [5] trailing-update (syrk) kernel time summed  [6] number of trailing-update launches
- * [7] trailing-update flops (sum over launches)  [8] K-build bytes written  [9] H2D+D2H  */
+ * [7] trailing-update flops (sum over launches)  [8] K-build bytes written
+ * [9] result transfer of tgp_gp_predict_cov ([3] is then its device compute time)       */
 #define TGP_NTIMINGS 10
 int tgp_last_timings(tgp_ctx *ctx, double *ms, int n);
 /* when on (default off) the Cholesky brackets every trailing-update launch with events */
