@@ -259,6 +259,29 @@ def test_hyperparameter_search_loglikelihood():
     np.testing.assert_allclose(kernel_skl.theta, gp.kernel.theta, atol=5e-1)               # :141
 
 
+def test_ml_fit_concurrent_differences_follow_the_sequential_path():
+    """The ntheta+1 likelihood evaluations of one finite-difference gradient run concurrently (one context each):
+    same formula and step as SciPy's own numerical gradient, so the fit visits the same iterates."""
+    import time
+    from treegp_amd.log_likelihood import log_likelihood
+    invL = np.linalg.inv(get_correlation_length_matrix(0.5, 0.2, 0.2))
+    kernel = treegp.eval_kernel("%f**2*%s" % (2.0, "AnisotropicRBF") + "(invLam={0!r})".format(invL))
+    x, y, y_err = _grf(kernel, 0.01, 600, 2)
+    start = kernel.clone_with_theta(kernel.theta + np.array([0.3, -0.2, 0.25, 0.1]))
+    fits, walls = [], []
+    for parallel in (False, True):
+        ll = log_likelihood(x, y - np.mean(y), y_err)
+        ll.parallel_fd = parallel
+        t0 = time.perf_counter()
+        fitted = ll.optimizer(start)
+        walls.append(time.perf_counter() - t0)
+        fits.append((fitted.theta, ll._logL))
+    np.testing.assert_allclose(fits[1][0], fits[0][0], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(fits[1][1], fits[0][1], rtol=1e-10)
+    np.testing.assert_allclose(fits[0][0], kernel.theta, atol=5e-1)
+    print("ML fit N=600: sequential %.1f ms, concurrent differences %.1f ms" % (walls[0] * 1e3, walls[1] * 1e3))
+
+
 def test_hyperparameter_search_two_pcf_1d():
     for ker, sig, ell, max_sep in (("RBF", 1.0, 0.5, 1.75), ("RBF", 2.0, 0.8, 1.75), ("VonKarman", 1.0, 8.0, 1.25),
                                    ("VonKarman", 2.0, 10.0, 1.25)):
