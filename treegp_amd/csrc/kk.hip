@@ -12,6 +12,8 @@
 // broadcasts; every wave keeps a private histogram in LDS (fp64 ds_add), flushed once per
 // workgroup with global fp64 atomics.  VALU + LDS-atomic bound; HBM traffic is ~32 N bytes.
 #include "tgp_internal.h"
+#include <algorithm>
+#include <thread>
 
 namespace {
 constexpr int KT = 256;           // points per tile
@@ -262,9 +264,20 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
         std::vector<uint32_t> key;
         int nbuckets = 1;
         morton_keys(x, y, n, key, nbuckets);
-        std::vector<int64_t> count;
-        for (int64_t b = 0; b < n_boot; ++b)
-            counting_sort_row(idx ? idx + b * n : nullptr, n, key, nbuckets, count, sorted.data() + b * n);
+        // the resamples are independent: sort their index rows on a few host threads
+        const int nthr = (int)std::min<int64_t>(n_boot, std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
+        auto work = [&](int tno) {
+            std::vector<int64_t> count;
+            for (int64_t b = tno; b < n_boot; b += nthr)
+                counting_sort_row(idx ? idx + b * n : nullptr, n, key, nbuckets, count, sorted.data() + b * n);
+        };
+        if (nthr <= 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (int tno = 0; tno < nthr; ++tno) pool.emplace_back(work, tno);
+            for (auto &th : pool) th.join();
+        }
     } else {
         // log bins reach across most of the field: nothing to cull, and neighbouring i-points of a wave
         // would hit the same bin for the same j (LDS-atomic serialisation), so keep the caller's order
@@ -387,7 +400,14 @@ int tgp_kk_twod_bootstrap(tgp_ctx *ctx, const double *x, const double *y, const 
                           int64_t n, const int64_t *idx, int64_t n_boot, double min_sep, double max_sep, int nbins,
                           double *xi_out) {
     TGP_ARG(idx && xi_out && n_boot >= 1);
-    for (int64_t t = 0; t < n_boot * n; ++t) TGP_ARG(idx[t] >= 0 && idx[t] < n);
+    {   // every index must name a point (checked before anything is launched)
+        int64_t lo = 0, hi = 0;
+        for (int64_t t = 0; t < n_boot * n; ++t) {
+            lo = idx[t] < lo ? idx[t] : lo;
+            hi = idx[t] > hi ? idx[t] : hi;
+        }
+        TGP_ARG(lo >= 0 && hi < n);
+    }
     std::vector<double> acc;
     int rc = kk_run(ctx, true, x, y, yv, nullptr, yerr, n, idx, n_boot, min_sep, max_sep, nbins, acc);
     if (rc) return rc;
