@@ -67,7 +67,9 @@ class robust_2dfit(object):
             return None
         invLam = np.linalg.inv(get_correlation_length_matrix(corr_length, g1, g2))
         self.kernel_fit = sigma ** 2 * self.kernel_class(invLam=invLam)
-        return self.kernel_fit(self.coord, Y=np.zeros_like(self.coord))[:, 0]
+        # the reference evaluates the kernel against a whole array of zeros and keeps column 0 (two_pcf.py:111-113);
+        # one origin row gives the same column at 1/npix of the work
+        return self.kernel_fit(self.coord, Y=np.zeros((1, self.coord.shape[1])))[:, 0]
 
     def chi2(self, param):
         """chi^2 over the non-linear parameters; the best amplitude (made positive) and constant
@@ -268,7 +270,7 @@ class two_pcf(object):
         and an L-BFGS-B run from the kernel's current theta."""
         self.min_sep, self.max_sep = self._default_separations()
         xi, xi_weight, distance, coord, mask = self.return_2pcf()
-        origin = np.zeros_like(coord)
+        origin = np.zeros((1, coord.shape[1]))      # the reference passes zeros_like(coord) and keeps column 0: same values
 
         def model(theta, template=kernel):
             return template.clone_with_theta(theta)(coord, Y=origin)[:, 0]
