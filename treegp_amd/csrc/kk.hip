@@ -24,6 +24,8 @@ struct KKArgs {
     const double *x, *y, *v, *w;  // v: value before mean subtraction
     const int64_t *idx;           // (n_boot, n) point order: spatially sorted (resample) indices
     const double *mean;           // (n_boot) mean to subtract from v (nullptr: 0)
+    const double *uw;             // (n_boot, n) per-entry weight (bootstrap: multiplicity x weight of the unique point), or nullptr
+    const int64_t *cnt;           // (n_boot) entries in use per resample (bootstrap: number of DISTINCT points), or nullptr
     const double *bbox;           // (n_boot, ntile, 4) xmin, xmax, ymin, ymax of every 256-point tile
     int64_t n;
     double min_sep, max_sep, bs, inv_bs, minsq, maxsq, lmin;
@@ -57,7 +59,8 @@ __global__ __launch_bounds__(256) void kk_bbox_kernel(KKArgs a, double *__restri
     const int64_t ntile = (a.n + KT - 1) / KT;
     const int64_t i = tile * KT + tid;
     double xv = 0, yv = 0;
-    const bool ok = i < a.n;
+    const int64_t npts = a.cnt ? a.cnt[boot] : a.n;
+    const bool ok = i < npts;
     if (ok) { const int64_t s = a.idx[boot * a.n + i]; xv = a.x[s]; yv = a.y[s]; }
     const double big = __builtin_huge_val();
     r[0][tid] = ok ? xv : big; r[1][tid] = ok ? xv : -big; r[2][tid] = ok ? yv : big; r[3][tid] = ok ? yv : -big;
@@ -88,15 +91,19 @@ __global__ __launch_bounds__(256) void kk_pairs_kernel(KKArgs a, double *__restr
     const int64_t *idx = a.idx + boot * a.n;
     const double mean = a.mean ? a.mean[boot] : 0.0;
     const int64_t ti = (int64_t)blockIdx.x * a.nparts + a.part;
-    const int64_t ntile = (a.n + KT - 1) / KT;
-    const double *bb = a.bbox + boot * ntile * 4;
+    const int64_t ntile0 = (a.n + KT - 1) / KT;                   // row stride of the bbox table
+    const int64_t npts = a.cnt ? a.cnt[boot] : a.n;
+    const int64_t ntile = (npts + KT - 1) / KT;
+    if (ti >= ntile) return;
+    const double *uw = a.uw ? a.uw + boot * a.n : nullptr;
+    const double *bb = a.bbox + boot * ntile0 * 4;
     const double bxl = bb[ti * 4], bxh = bb[ti * 4 + 1], byl = bb[ti * 4 + 2], byh = bb[ti * 4 + 3];
     const int64_t i = ti * KT + tid;
     double xi = 0, yi = 0, ki = 0, wi = 0;
-    const bool ivalid = i < a.n;
+    const bool ivalid = i < npts;
     if (ivalid) {
         const int64_t s = idx[i];
-        xi = a.x[s]; yi = a.y[s]; ki = a.v[s] - mean; wi = a.w ? a.w[s] : 1.0;
+        xi = a.x[s]; yi = a.y[s]; ki = a.v[s] - mean; wi = uw ? uw[i] : (a.w ? a.w[s] : 1.0);
     }
     // j tiles tj >= ti, dealt round-robin over gridDim.y chunks; tiles out of reach are skipped whole
     for (int64_t tj = ti + blockIdx.y; tj < ntile; tj += gridDim.y) {
@@ -107,12 +114,12 @@ __global__ __launch_bounds__(256) void kk_pairs_kernel(KKArgs a, double *__restr
         }
         __syncthreads();
         const int64_t j = tj * KT + tid;
-        if (j < a.n) {
+        if (j < npts) {
             const int64_t s = idx[j];
-            sx[tid] = a.x[s]; sy[tid] = a.y[s]; sk[tid] = a.v[s] - mean; sw[tid] = a.w ? a.w[s] : 1.0;
+            sx[tid] = a.x[s]; sy[tid] = a.y[s]; sk[tid] = a.v[s] - mean; sw[tid] = uw ? uw[j] : (a.w ? a.w[s] : 1.0);
         }
         __syncthreads();
-        const int cnt = (int)((a.n - tj * KT < KT) ? (a.n - tj * KT) : KT);
+        const int cnt = (int)((npts - tj * KT < KT) ? (npts - tj * KT) : KT);
         const int t0 = (tj == ti) ? tid + 1 : 0;          // unordered pairs: j > i
         if (!ivalid) continue;
         for (int t = 0; t < cnt; ++t) {
@@ -245,8 +252,10 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
     const size_t accb = (size_t)n_boot * nacc * nb * sizeof(double);
     auto rup = [](size_t b) { return (b + 255) / 256 * 256; };
     const int64_t ntile0 = (n + KT - 1) / KT;
+    const bool weighted_boot = twod && idx != nullptr;      // bootstrap: distinct points with multiplicity weights
     const size_t need = 4 * rup(n * 8) + rup((size_t)n_boot * n * 8) + rup(n_boot * 8) + rup(accb) +
-                        rup((size_t)n_boot * ntile0 * 4 * 8);
+                        rup((size_t)n_boot * ntile0 * 4 * 8) +
+                        (weighted_boot ? rup((size_t)n_boot * n * 8) + rup(n_boot * 8) : 0);
     int rc = tgp_ensure_scratch(ctx, need);
     if (rc) return rc;
     char *base = (char *)ctx->scratch;
@@ -258,9 +267,67 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
     double *d_mean = (double *)take(n_boot * 8);
     double *d_acc = (double *)take(accb);
     double *d_bbox = (double *)take((size_t)n_boot * ntile0 * 4 * 8);
+    double *d_uw = weighted_boot ? (double *)take((size_t)n_boot * n * 8) : nullptr;
+    int64_t *d_cnt = weighted_boot ? (int64_t *)take(n_boot * 8) : nullptr;
     // spatial order of every catalogue (the base points, or each bootstrap resample)
     std::vector<int64_t> sorted((size_t)n_boot * n);
-    if (twod) {
+    std::vector<double> uw_host, mean_host;
+    std::vector<int64_t> cnt_host;
+    if (weighted_boot) {
+        // A resample is a multiset of the base points.  A pair of DISTINCT points (i, j) drawn c_i and c_j times
+        // appears c_i c_j times in the resampled catalogue and pairs of copies of one point have r = 0 (excluded), so
+        // the resample's sums are those of its distinct points with weights c w: ~63 % of the points, 40 % of the
+        // pair tests.  Per resample: multiplicities, mean of the drawn values (two_pcf.py:297), and the distinct
+        // points in the Morton order of the base catalogue.
+        std::vector<uint32_t> key;
+        int nbuckets = 1;
+        morton_keys(x, y, n, key, nbuckets);
+        std::vector<int64_t> order0(n), count0;
+        counting_sort_row(nullptr, n, key, nbuckets, count0, order0.data());
+        std::vector<double> wbase(n, 1.0);
+        if (w_host) {
+            for (int64_t i = 0; i < n; ++i) wbase[i] = w_host[i];
+        } else if (yerr_host) {
+            double s = 0.0;                               // two_pcf.py:291-294: w = None if sum(y_err) == 0
+            for (int64_t i = 0; i < n; ++i) s += yerr_host[i];
+            if (s != 0.0)
+                for (int64_t i = 0; i < n; ++i) wbase[i] = 1.0 / (yerr_host[i] * yerr_host[i]);
+        }
+        uw_host.assign((size_t)n_boot * n, 0.0);
+        mean_host.assign(n_boot, 0.0);
+        cnt_host.assign(n_boot, 0);
+        const int nthr = (int)std::min<int64_t>(n_boot, std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
+        auto work = [&](int tno) {
+            std::vector<int32_t> mult(n);
+            for (int64_t b = tno; b < n_boot; b += nthr) {
+                std::fill(mult.begin(), mult.end(), 0);
+                const int64_t *row = idx + b * n;
+                double s = 0.0;
+                for (int64_t t = 0; t < n; ++t) {
+                    ++mult[row[t]];
+                    s += v[row[t]];
+                }
+                mean_host[b] = s / (double)n;
+                int64_t m = 0;
+                for (int64_t t = 0; t < n; ++t) {
+                    const int64_t p = order0[t];
+                    if (mult[p] > 0) {
+                        sorted[b * n + m] = p;
+                        uw_host[b * n + m] = (double)mult[p] * wbase[p];
+                        ++m;
+                    }
+                }
+                cnt_host[b] = m;
+            }
+        };
+        if (nthr <= 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (int tno = 0; tno < nthr; ++tno) pool.emplace_back(work, tno);
+            for (auto &th : pool) th.join();
+        }
+    } else if (twod) {
         std::vector<uint32_t> key;
         int nbuckets = 1;
         morton_keys(x, y, n, key, nbuckets);
@@ -303,13 +370,21 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
         }
     }
     TGP_HIP(hipMemcpyAsync(d_idx, sorted.data(), (size_t)n_boot * n * 8, hipMemcpyHostToDevice, st));
-    if (idx) boot_mean_kernel<<<(unsigned)n_boot, 256, 0, st>>>(d_v, d_idx, n, d_mean);
+    if (weighted_boot) {
+        TGP_HIP(hipMemcpyAsync(d_uw, uw_host.data(), (size_t)n_boot * n * 8, hipMemcpyHostToDevice, st));
+        TGP_HIP(hipMemcpyAsync(d_cnt, cnt_host.data(), (size_t)n_boot * 8, hipMemcpyHostToDevice, st));
+        TGP_HIP(hipMemcpyAsync(d_mean, mean_host.data(), (size_t)n_boot * 8, hipMemcpyHostToDevice, st));
+    } else if (idx) {
+        boot_mean_kernel<<<(unsigned)n_boot, 256, 0, st>>>(d_v, d_idx, n, d_mean);
+    }
     TGP_HIP(hipMemsetAsync(d_acc, 0, accb, st));
 
     KKArgs a;
     a.x = d_x; a.y = d_y; a.v = d_v; a.w = have_w ? d_w : nullptr;
     a.idx = d_idx;
     a.mean = idx ? d_mean : nullptr;
+    a.uw = d_uw;
+    a.cnt = d_cnt;
     a.bbox = d_bbox;
     a.n = n;
     a.min_sep = min_sep; a.max_sep = max_sep;
