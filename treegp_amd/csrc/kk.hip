@@ -24,7 +24,8 @@ struct KKArgs {
     const double *x, *y, *v, *w;  // v: value before mean subtraction
     const int64_t *idx;           // (n_boot, n) point order: spatially sorted (resample) indices
     const double *mean;           // (n_boot) mean to subtract from v (nullptr: 0)
-    const double *uw;             // (n_boot, n) per-entry weight (bootstrap: multiplicity x weight of the unique point), or nullptr
+    const int32_t *idx32;         // bootstrap: (n_boot, n) distinct points of every resample, Morton order (replaces idx)
+    const uint8_t *mult;          // bootstrap: (n_boot, n) multiplicity of each of them (weight = mult x w)
     const int64_t *cnt;           // (n_boot) entries in use per resample (bootstrap: number of DISTINCT points), or nullptr
     const double *bbox;           // (n_boot, ntile, 4) xmin, xmax, ymin, ymax of every 256-point tile
     int64_t n;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void kk_bbox_kernel(KKArgs a, double *__restri
     double xv = 0, yv = 0;
     const int64_t npts = a.cnt ? a.cnt[boot] : a.n;
     const bool ok = i < npts;
-    if (ok) { const int64_t s = a.idx[boot * a.n + i]; xv = a.x[s]; yv = a.y[s]; }
+    if (ok) { const int64_t s = a.idx32 ? (int64_t)a.idx32[boot * a.n + i] : a.idx[boot * a.n + i]; xv = a.x[s]; yv = a.y[s]; }
     const double big = __builtin_huge_val();
     r[0][tid] = ok ? xv : big; r[1][tid] = ok ? xv : -big; r[2][tid] = ok ? yv : big; r[3][tid] = ok ? yv : -big;
     __syncthreads();
@@ -88,22 +89,24 @@ __global__ __launch_bounds__(256) void kk_pairs_kernel(KKArgs a, double *__restr
     for (int t = tid; t < 4 * NACC * nb; t += 256) hist[t] = 0.0;
 
     const int64_t boot = blockIdx.z;
-    const int64_t *idx = a.idx + boot * a.n;
+    const int64_t *idx = a.idx ? a.idx + boot * a.n : nullptr;
+    const int32_t *idx32 = a.idx32 ? a.idx32 + boot * a.n : nullptr;
+    const uint8_t *mult = a.mult ? a.mult + boot * a.n : nullptr;
     const double mean = a.mean ? a.mean[boot] : 0.0;
     const int64_t ti = (int64_t)blockIdx.x * a.nparts + a.part;
     const int64_t ntile0 = (a.n + KT - 1) / KT;                   // row stride of the bbox table
     const int64_t npts = a.cnt ? a.cnt[boot] : a.n;
     const int64_t ntile = (npts + KT - 1) / KT;
     if (ti >= ntile) return;
-    const double *uw = a.uw ? a.uw + boot * a.n : nullptr;
     const double *bb = a.bbox + boot * ntile0 * 4;
     const double bxl = bb[ti * 4], bxh = bb[ti * 4 + 1], byl = bb[ti * 4 + 2], byh = bb[ti * 4 + 3];
     const int64_t i = ti * KT + tid;
     double xi = 0, yi = 0, ki = 0, wi = 0;
     const bool ivalid = i < npts;
     if (ivalid) {
-        const int64_t s = idx[i];
-        xi = a.x[s]; yi = a.y[s]; ki = a.v[s] - mean; wi = uw ? uw[i] : (a.w ? a.w[s] : 1.0);
+        const int64_t s = idx32 ? (int64_t)idx32[i] : idx[i];
+        xi = a.x[s]; yi = a.y[s]; ki = a.v[s] - mean; wi = a.w ? a.w[s] : 1.0;
+        if (mult) wi *= (double)mult[i];
     }
     // j tiles tj >= ti, dealt round-robin over gridDim.y chunks; tiles out of reach are skipped whole
     for (int64_t tj = ti + blockIdx.y; tj < ntile; tj += gridDim.y) {
@@ -115,8 +118,10 @@ __global__ __launch_bounds__(256) void kk_pairs_kernel(KKArgs a, double *__restr
         __syncthreads();
         const int64_t j = tj * KT + tid;
         if (j < npts) {
-            const int64_t s = idx[j];
-            sx[tid] = a.x[s]; sy[tid] = a.y[s]; sk[tid] = a.v[s] - mean; sw[tid] = uw ? uw[j] : (a.w ? a.w[s] : 1.0);
+            const int64_t s = idx32 ? (int64_t)idx32[j] : idx[j];
+            double wj = a.w ? a.w[s] : 1.0;
+            if (mult) wj *= (double)mult[j];
+            sx[tid] = a.x[s]; sy[tid] = a.y[s]; sk[tid] = a.v[s] - mean; sw[tid] = wj;
         }
         __syncthreads();
         const int cnt = (int)((npts - tj * KT < KT) ? (npts - tj * KT) : KT);
@@ -255,7 +260,7 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
     const bool weighted_boot = twod && idx != nullptr;      // bootstrap: distinct points with multiplicity weights
     const size_t need = 4 * rup(n * 8) + rup((size_t)n_boot * n * 8) + rup(n_boot * 8) + rup(accb) +
                         rup((size_t)n_boot * ntile0 * 4 * 8) +
-                        (weighted_boot ? rup((size_t)n_boot * n * 8) + rup(n_boot * 8) : 0);
+                        (weighted_boot ? rup((size_t)n_boot * n) + rup(n_boot * 8) : 0);
     int rc = tgp_ensure_scratch(ctx, need);
     if (rc) return rc;
     char *base = (char *)ctx->scratch;
@@ -267,11 +272,13 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
     double *d_mean = (double *)take(n_boot * 8);
     double *d_acc = (double *)take(accb);
     double *d_bbox = (double *)take((size_t)n_boot * ntile0 * 4 * 8);
-    double *d_uw = weighted_boot ? (double *)take((size_t)n_boot * n * 8) : nullptr;
+    uint8_t *d_mult = weighted_boot ? (uint8_t *)take((size_t)n_boot * n) : nullptr;
     int64_t *d_cnt = weighted_boot ? (int64_t *)take(n_boot * 8) : nullptr;
     // spatial order of every catalogue (the base points, or each bootstrap resample)
-    std::vector<int64_t> sorted((size_t)n_boot * n);
-    std::vector<double> uw_host, mean_host;
+    std::vector<int64_t> sorted(weighted_boot ? 0 : (size_t)n_boot * n);
+    std::vector<int32_t> sorted32(weighted_boot ? (size_t)n_boot * n : 0);     // bootstrap: 4-byte indices, 1-byte multiplicities
+    std::vector<uint8_t> mult_host;
+    std::vector<double> mean_host;
     std::vector<int64_t> cnt_host;
     if (weighted_boot) {
         // A resample is a multiset of the base points.  A pair of DISTINCT points (i, j) drawn c_i and c_j times
@@ -284,16 +291,8 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
         morton_keys(x, y, n, key, nbuckets);
         std::vector<int64_t> order0(n), count0;
         counting_sort_row(nullptr, n, key, nbuckets, count0, order0.data());
-        std::vector<double> wbase(n, 1.0);
-        if (w_host) {
-            for (int64_t i = 0; i < n; ++i) wbase[i] = w_host[i];
-        } else if (yerr_host) {
-            double s = 0.0;                               // two_pcf.py:291-294: w = None if sum(y_err) == 0
-            for (int64_t i = 0; i < n; ++i) s += yerr_host[i];
-            if (s != 0.0)
-                for (int64_t i = 0; i < n; ++i) wbase[i] = 1.0 / (yerr_host[i] * yerr_host[i]);
-        }
-        uw_host.assign((size_t)n_boot * n, 0.0);
+        TGP_ARG(n < (int64_t)1 << 31);
+        mult_host.assign((size_t)n_boot * n, 0);
         mean_host.assign(n_boot, 0.0);
         cnt_host.assign(n_boot, 0);
         const int nthr = (int)std::min<int64_t>(n_boot, std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
@@ -311,9 +310,11 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
                 int64_t m = 0;
                 for (int64_t t = 0; t < n; ++t) {
                     const int64_t p = order0[t];
-                    if (mult[p] > 0) {
-                        sorted[b * n + m] = p;
-                        uw_host[b * n + m] = (double)mult[p] * wbase[p];
+                    int32_t c = mult[p];
+                    while (c > 0) {                      // multiplicities above 255 (never seen in practice) take several entries
+                        sorted32[b * n + m] = (int32_t)p;
+                        mult_host[b * n + m] = (uint8_t)(c > 255 ? 255 : c);
+                        c -= 255;
                         ++m;
                     }
                 }
@@ -369,21 +370,23 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
             have_w = true;
         }
     }
-    TGP_HIP(hipMemcpyAsync(d_idx, sorted.data(), (size_t)n_boot * n * 8, hipMemcpyHostToDevice, st));
     if (weighted_boot) {
-        TGP_HIP(hipMemcpyAsync(d_uw, uw_host.data(), (size_t)n_boot * n * 8, hipMemcpyHostToDevice, st));
+        TGP_HIP(hipMemcpyAsync(d_idx, sorted32.data(), (size_t)n_boot * n * 4, hipMemcpyHostToDevice, st));
+        TGP_HIP(hipMemcpyAsync(d_mult, mult_host.data(), (size_t)n_boot * n, hipMemcpyHostToDevice, st));
         TGP_HIP(hipMemcpyAsync(d_cnt, cnt_host.data(), (size_t)n_boot * 8, hipMemcpyHostToDevice, st));
         TGP_HIP(hipMemcpyAsync(d_mean, mean_host.data(), (size_t)n_boot * 8, hipMemcpyHostToDevice, st));
-    } else if (idx) {
-        boot_mean_kernel<<<(unsigned)n_boot, 256, 0, st>>>(d_v, d_idx, n, d_mean);
+    } else {
+        TGP_HIP(hipMemcpyAsync(d_idx, sorted.data(), (size_t)n_boot * n * 8, hipMemcpyHostToDevice, st));
+        if (idx) boot_mean_kernel<<<(unsigned)n_boot, 256, 0, st>>>(d_v, d_idx, n, d_mean);
     }
     TGP_HIP(hipMemsetAsync(d_acc, 0, accb, st));
 
     KKArgs a;
     a.x = d_x; a.y = d_y; a.v = d_v; a.w = have_w ? d_w : nullptr;
-    a.idx = d_idx;
+    a.idx = weighted_boot ? nullptr : d_idx;
+    a.idx32 = weighted_boot ? (const int32_t *)d_idx : nullptr;
+    a.mult = d_mult;
     a.mean = idx ? d_mean : nullptr;
-    a.uw = d_uw;
     a.cnt = d_cnt;
     a.bbox = d_bbox;
     a.n = n;
