@@ -360,6 +360,37 @@ def test_kk_bootstrap_vs_oracle_loop():
     np.testing.assert_allclose(cov, d.T @ d / 4.0, rtol=1e-9, atol=1e-14)
 
 
+@pytest.mark.parametrize("shift", [0.0, 250.0])
+def test_kk_bootstrap_pair_lists_vs_oracle(shift, monkeypatch):
+    """n_boot >= 8 takes the pair-list formulation (kk_boot.hip): same resamples as the oracle's loop, and the same
+    numbers as the per-resample kernels (TGP_BOOT_LISTS=0); a large common offset of the values must not matter."""
+    from oracle import gp_oracle as O
+    from treegp_amd import ops
+    rng = np.random.default_rng(11)
+    n, nb, mx, nboot = 700, 11, 0.25, 70
+    X = rng.uniform(0, 1, (n, 2)); yv = rng.standard_normal(n) + shift; yerr = rng.uniform(0.05, 0.1, n)
+    X[5] = X[6]                                     # a coincident pair (r = 0, excluded)
+    idx = O.bootstrap_indices(n, nboot)
+    tol = 1e-10 if shift == 0.0 else 1e-8
+    for err in (yerr, np.zeros(n)):
+        monkeypatch.setenv("TGP_BOOT_LISTS", "1")
+        got = ops.kk_twod_bootstrap(X[:, 0], X[:, 1], yv, err, idx, 0.0, mx, nb)
+        monkeypatch.setenv("TGP_BOOT_LISTS", "0")
+        old = ops.kk_twod_bootstrap(X[:, 0], X[:, 1], yv, err, idx, 0.0, mx, nb)
+        scale = np.abs(old).max()
+        np.testing.assert_allclose(got, old, rtol=tol, atol=tol * 1e-2 * scale)
+        for b in (0, 33, nboot - 1):
+            ii = idx[b]
+            xo, _, _, _ = O.comp_2pcf(X[ii], yv[ii], err[ii], 0.0, mx, nb, True)
+            np.testing.assert_allclose(got[b], xo, rtol=tol, atol=tol * 1e-2 * np.abs(xo).max())
+    # a min_sep > 0 and a pixel grid that leaves pixels empty
+    monkeypatch.setenv("TGP_BOOT_LISTS", "1")
+    got = ops.kk_twod_bootstrap(X[:, 0], X[:, 1], yv, yerr, idx[:9], 0.05, 0.02 + 0.05, 5)
+    monkeypatch.setenv("TGP_BOOT_LISTS", "0")
+    old = ops.kk_twod_bootstrap(X[:, 0], X[:, 1], yv, yerr, idx[:9], 0.05, 0.02 + 0.05, 5)
+    np.testing.assert_allclose(got, old, rtol=tol, atol=tol * 1e-2 * max(np.abs(old).max(), 1e-300))
+
+
 def test_knn_mean_vs_oracle(golden):
     from oracle import gp_oracle as O
     from treegp_amd import ops

@@ -214,7 +214,7 @@ struct IoBuf {
 // Z-order (Morton) key of every point on a 2^b x 2^b grid with ~32 points per cell, and the counting-sort
 // permutation of `src` (indices into the points) by that key.  Spatially compact 256-point tiles let
 // the pair kernel skip tile pairs that are farther apart than max_sep.
-static void morton_keys(const double *x, const double *y, int64_t n, std::vector<uint32_t> &key, int &nbuckets) {
+void tgp_morton_keys(const double *x, const double *y, int64_t n, std::vector<uint32_t> &key, int &nbuckets) {
     double xl = x[0], xh = x[0], yl = y[0], yh = y[0];
     for (int64_t i = 1; i < n; ++i) {
         xl = x[i] < xl ? x[i] : xl; xh = x[i] > xh ? x[i] : xh;
@@ -235,7 +235,7 @@ static void morton_keys(const double *x, const double *y, int64_t n, std::vector
         key[i] = k;
     }
 }
-static void counting_sort_row(const int64_t *src, int64_t n, const std::vector<uint32_t> &key, int nbuckets,
+void tgp_counting_sort_row(const int64_t *src, int64_t n, const std::vector<uint32_t> &key, int nbuckets,
                               std::vector<int64_t> &count, int64_t *dst) {
     count.assign(nbuckets + 1, 0);
     for (int64_t t = 0; t < n; ++t) ++count[key[src ? src[t] : t] + 1];
@@ -288,9 +288,9 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
         // points in the Morton order of the base catalogue.
         std::vector<uint32_t> key;
         int nbuckets = 1;
-        morton_keys(x, y, n, key, nbuckets);
+        tgp_morton_keys(x, y, n, key, nbuckets);
         std::vector<int64_t> order0(n), count0;
-        counting_sort_row(nullptr, n, key, nbuckets, count0, order0.data());
+        tgp_counting_sort_row(nullptr, n, key, nbuckets, count0, order0.data());
         TGP_ARG(n < (int64_t)1 << 31);
         mult_host.assign((size_t)n_boot * n, 0);
         mean_host.assign(n_boot, 0.0);
@@ -331,13 +331,13 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
     } else if (twod) {
         std::vector<uint32_t> key;
         int nbuckets = 1;
-        morton_keys(x, y, n, key, nbuckets);
+        tgp_morton_keys(x, y, n, key, nbuckets);
         // the resamples are independent: sort their index rows on a few host threads
         const int nthr = (int)std::min<int64_t>(n_boot, std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
         auto work = [&](int tno) {
             std::vector<int64_t> count;
             for (int64_t b = tno; b < n_boot; b += nthr)
-                counting_sort_row(idx ? idx + b * n : nullptr, n, key, nbuckets, count, sorted.data() + b * n);
+                tgp_counting_sort_row(idx ? idx + b * n : nullptr, n, key, nbuckets, count, sorted.data() + b * n);
         };
         if (nthr <= 1) {
             work(0);
@@ -426,6 +426,9 @@ static int kk_run(tgp_ctx *ctx, bool twod, const double *x, const double *y, con
     return 0;
 }
 
+int kk_bootstrap_lists(tgp_ctx *ctx, const double *x, const double *y, const double *v, const double *yerr_host, int64_t n,
+                       const int64_t *idx, int64_t n_boot, double min_sep, double max_sep, int nbins, double *xi_out);
+
 extern "C" {
 
 int tgp_kk_twod(tgp_ctx *ctx, const double *x, const double *y, const double *k, const double *w, int64_t n,
@@ -485,6 +488,14 @@ int tgp_kk_twod_bootstrap(tgp_ctx *ctx, const double *x, const double *y, const 
             hi = idx[t] > hi ? idx[t] : hi;
         }
         TGP_ARG(lo >= 0 && hi < n);
+    }
+    TGP_ARG(x && y && yv && n > 1 && nbins > 0 && nbins * nbins <= MAXB2 && max_sep > 0.0);
+    {   // many resamples: one traversal of the base pairs + per-pixel pair lists (kk_boot.hip); 1 = not applicable
+        const char *sw = getenv("TGP_BOOT_LISTS");
+        if (!(sw && sw[0] == '0')) {
+            const int rc = kk_bootstrap_lists(ctx, x, y, yv, yerr, n, idx, n_boot, min_sep, max_sep, nbins, xi_out);
+            if (rc != 1) return rc;
+        }
     }
     std::vector<double> acc;
     int rc = kk_run(ctx, true, x, y, yv, nullptr, yerr, n, idx, n_boot, min_sep, max_sep, nbins, acc);
