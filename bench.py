@@ -107,7 +107,13 @@ def main():
         # sharing one GPU (development boxes have one); the driver's runs use nccl = RCCL
         backend = os.environ.get("TGP_DIST_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # the collectives sit on the factorisation's critical path (panel chain), the bulk update does not:
+            # RCCL's own stream gets high priority like the look-ahead stream whose work it carries
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
+            except (AttributeError, TypeError):
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
         from treegp_amd.dist import DistributedGP

@@ -173,3 +173,16 @@ def test_update_entry_points_agree():
     assert torch.equal(outs[0], outs[1])
     assert not torch.equal(outs[0], base)
     _lib.load_library().tgp_reset_stream(ops_.ctx)
+
+
+def test_driver_on_rccl_backend_world_of_one():
+    """tests/_nccl_world1.py: the torch.distributed calls of the G > 1 path on the real nccl (RCCL) backend"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_nccl_world1.py")
+    r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "nccl world-of-one ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
