@@ -144,7 +144,8 @@ def test_golden_config1_and_aniso2d(tg, golden):
                                  {"TGP_POTRF_VARIANT": "0"}, {"TGP_SMALL_T": "0", "TGP_SMALL_ROWS": "0"},
                                  {"TGP_CHOL_MODE": "0"}, {"TGP_CHOL_MODE": "1"}, {"TGP_CHOL_MODE": "2"},
                                  {"TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "0"}, {"TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "8"},
-                                 {"TGP_CHOL_MODE": "3", "TGP_SMALL_T": "0", "TGP_SMALL_ROWS": "0"}, {"TGP_PREDICT_GENERIC": "1"}])
+                                 {"TGP_CHOL_MODE": "3", "TGP_SMALL_T": "0", "TGP_SMALL_ROWS": "0"}, {"TGP_PREDICT_GENERIC": "1"},
+                                 {"TGP_QUEUE_T": "0"}, {"TGP_QUEUE_T": "200", "TGP_NO_HEAD_START": "1"}])
 def test_alternative_kernel_paths_agree(env):
     """The A/B switches kept in the library (older tiles, schedules and diagonal-block kernels) must stay correct:
     each one solves and predicts the same problem in a fresh process (the switches are read once per process)."""
@@ -174,3 +175,25 @@ print("OK")
 ''' % root
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_concurrent_contexts_agree_with_single_solves():
+    """Several contexts factorising at once (the ML fit's concurrent finite differences).  The bulk update of chain-bound
+    steps is a persistent grid whose workgroups leave the compute units it keeps clear for the panel chain; with other
+    contexts' kernels on the chip it must still get every tile done (it once did not: all its workgroups could land on
+    the units another context kept clear)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from treegp_amd import _lib, ops
+    from treegp_amd.synthetic import star_field, headline_invlam
+    n, K = 4096, 5
+    iL = headline_invlam()
+    specs = [ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=iL[0, 0] * (1 + 0.01 * i), b=iL[0, 1], c=iL[1, 1]) for i in range(K)]
+    X, y, ye, _ = star_field(n, 16)
+    y = y - y.mean()
+    ref = [ops.gp_solve(s, X, y, ye, want_alpha=False)[1:3] for s in specs]
+    ctxs = [_lib.new_ctx(0) for _ in range(K)]
+    with ThreadPoolExecutor(K) as pool:
+        for _ in range(6):
+            got = list(pool.map(lambda i: ops.gp_solve(specs[i], X, y, ye, want_alpha=False, ctx=ctxs[i])[1:3], range(K)))
+            for g, r in zip(got, ref):
+                np.testing.assert_allclose(g, r, rtol=1e-11)

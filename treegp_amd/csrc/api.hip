@@ -106,6 +106,7 @@ int tgp_init(const int *devices, int ndev, tgp_ctx **out) {
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_info, 256) != hipSuccess) { delete ctx; return -2; }
+    if (hipMalloc((void **)&ctx->d_queue, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned)) != hipSuccess) { delete ctx; return -2; }
     if (hipMemset(ctx->d_info, 0, 256) != hipSuccess) { delete ctx; return -2; }
     if (hipHostMalloc((void **)&ctx->h_info, 256, hipHostMallocDefault) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_scal, 16 * sizeof(double)) != hipSuccess) { delete ctx; return -2; }
@@ -125,6 +126,7 @@ void tgp_destroy(tgp_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->h_info) (void)hipHostFree(ctx->h_info);
     if (ctx->d_scal) (void)hipFree(ctx->d_scal);
     if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);

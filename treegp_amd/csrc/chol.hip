@@ -18,18 +18,37 @@
 #include "gemm_tile.h"
 #include "potrf128.h"
 
+#ifdef TGP_POTRF_STAMPS
+__device__ unsigned long long tgp_gemm_stamps[1024 * 4];
+__device__ int tgp_gemm_stamp_grid = 43;
+__device__ unsigned long long tgp_queue_stamps[1024 * 4];      // queued bulk update with T == tgp_queue_stamp_T: per workgroup
+__device__ int tgp_queue_stamp_T = 40;
+#endif
+
 namespace {
 // a column of 128-row tiles: tile t uses A rows [128 t, +128), the fixed B block, C rows [128 t, +128)
 template <int MODE, int LDB>
 __global__ __launch_bounds__(256, 2) void gemm_col_kernel(const double *A, const double *B, double *C) {
     const int64_t t = blockIdx.x;
+    TGP_CHAIN_PRIO();
+#ifdef TGP_POTRF_STAMPS
+    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+#endif
     gemm_tile_128<MODE, LDB, TGP_TB>(A + t * 128 * TGP_PW, B, C + t * 128 * TGP_PW);
+#ifdef TGP_POTRF_STAMPS
+    if (MODE == 0 && threadIdx.x == 0 && (int)gridDim.x == tgp_gemm_stamp_grid) {      // one chosen call: when and where every workgroup ran
+        tgp_gemm_stamps[blockIdx.x * 4 + 0] = t_in;
+        tgp_gemm_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        tgp_gemm_stamps[blockIdx.x * 4 + 2] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 8) | __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));
+    }
+#endif
 }
 
 // The same two jobs on the latency tile (nt_small_tile): 16-row slices, for steps with only a few tiles.
 template <int MODE, int LDB>
 __global__ __launch_bounds__(256) void gemm_col_small_kernel(const double *A, const double *B, double *C) {
     const int64_t o = (int64_t)blockIdx.x * 16 * TGP_PW;
+    TGP_CHAIN_PRIO();
     nt_small_tile<MODE, TGP_TB, 1>(A + o, TGP_PW, B, LDB, C + o, TGP_PW, nullptr, nullptr);
 }
 template <int NSEG>
@@ -38,6 +57,7 @@ __global__ __launch_bounds__(256) void syrk_small_kernel(double *Abase, int64_t 
     const int ri = blockIdx.x;                   // 16-row slice of the trailing matrix
     const int tj = blockIdx.y;                   // 128-column tile
     if (tj > (ri >> 3) || (ri >> 3) >= T) return;
+    TGP_CHAIN_PRIO();
     const int64_t pj = ob + (tj >> 1);
     const int64_t I = (int64_t)TGP_PW * ob + 16 * (int64_t)ri;
     double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
@@ -104,12 +124,82 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void syrk_dtv_kernel(doub
             if (ti >= T2 || tj > 2 * ti + 1) return;
         }
     }
+    if (strip) TGP_CHAIN_PRIO();
     constexpr int RM = 32 * NW;
     const int64_t pj = ob + (tj >> 1);
     const int64_t I = (int64_t)TGP_PW * ob + (int64_t)RM * ti;
     double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
     const int64_t oa = (int64_t)ti * RM * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
     gemm_tile_dtv<NW, TGP_PW, NSEG>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
+}
+
+// The depth-512 bulk update as a PERSISTENT grid that leaves part of the chip free, for steps where the serial panel
+// chain (side stream) is longer than the update.  A bulk workgroup lives ~126 us and a plain launch fills both
+// workgroup slots of all 256 CUs at once, so the chain's kernels -- potrf128 needs a CU with a free slot, the panel
+// GEMMs one slot per 128 rows -- wait for the first round of tiles to finish (measured at N = 8192: 240 us of a 660 us
+// cycle).  Here only gridDim.x < 512 workgroups exist and they take tiles from a queue: the slots they do not occupy
+// stay free for the chain.  One counter per XCD class keeps the XCD-aware tile map (blockIdx.x & 7 = XCD of the
+// workgroup); the loop ends for every workgroup once its class has run out of slots.
+template <int NSEG>
+__global__ __launch_bounds__(256, 2) void syrk_dtv_queue_kernel(double *Abase, int64_t Np, int ob, int T, unsigned slots_per_class,
+                                                                unsigned *__restrict__ queue, const double *P0, const double *P1) {
+    __shared__ unsigned s_slot;
+    const unsigned xcd = blockIdx.x & 7;
+    {   // One compute unit per shader engine and XCD (32 of 256) is kept clear of this kernel: the first workgroup to arrive
+        // on a shader engine names its own CU (queue[8 + 4 XCC_ID + SE_ID]) and leaves, and so does every later one that
+        // lands there.  Per shader engine, because the dispatcher deals the workgroups of a kernel to the shader engines
+        // in strict rotation and stalls on a full one: free CUs on a single engine admit one or two workgroups of the
+        // chain's kernels and the rest wait behind them (measured with in-kernel stamps, tools/potrf_stamps.py).
+        if (threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));      // HW_ID[15:8]: CU_ID[3:0], SH_ID, SE_ID[2:0]
+            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;  // XCC_ID[3:0]
+            const unsigned key = hw + 1;
+            const unsigned prev = atomicCAS(&queue[8 + 4 * xcc + ((hw >> 5) & 3)], 0u, key);
+            unsigned leave = (prev == 0u || prev == key) ? 1u : 0u;
+            // Progress does not depend on where the dispatcher puts workgroups: at most 16 of the 65 of a tile class
+            // may leave.  (With other contexts' kernels on the chip the only free room can be the units those kernels
+            // keep clear; without the cap every workgroup of this one could land there and leave, and no tile be done.)
+            if (leave && atomicAdd(&queue[40 + xcd], 1u) >= 16u) leave = 0u;
+            s_slot = leave;
+        }
+        __syncthreads();
+        const bool leave = s_slot != 0u;
+        __syncthreads();
+#ifdef TGP_POTRF_STAMPS
+        if (threadIdx.x == 0 && T == tgp_queue_stamp_T) {
+            tgp_queue_stamps[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+            tgp_queue_stamps[blockIdx.x * 4 + 2] = (leave ? 1ull << 32 : 0ull) | (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 8) |
+                                                   __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));
+            tgp_queue_stamps[blockIdx.x * 4 + 1] = tgp_queue_stamps[blockIdx.x * 4 + 0];
+            tgp_queue_stamps[blockIdx.x * 4 + 3] = 0;
+        }
+#endif
+        if (leave) return;
+    }
+#ifdef TGP_POTRF_STAMPS
+    unsigned my_tiles = 0;
+#endif
+    for (;;) {
+        if (threadIdx.x == 0) s_slot = atomicAdd(&queue[xcd], 1u);
+        __syncthreads();
+        const unsigned n = s_slot;
+        __syncthreads();                         // s_slot has been read by everyone before the next round overwrites it
+        if (n >= slots_per_class) break;         // uniform
+        int ti, tj;
+        tilemap(((int64_t)n << 3) | xcd, T, ti, tj);
+        if (ti < 0) continue;
+        const int64_t pj = ob + (tj >> 1);
+        const int64_t I = (int64_t)TGP_PW * ob + (int64_t)TGP_TB * ti;
+        double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
+        const int64_t oa = (int64_t)ti * TGP_TB * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
+        gemm_tile_dtv<4, TGP_PW, NSEG>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
+#ifdef TGP_POTRF_STAMPS
+        if (threadIdx.x == 0 && T == tgp_queue_stamp_T) {
+            tgp_queue_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            tgp_queue_stamps[blockIdx.x * 4 + 3] = ++my_tiles;
+        }
+#endif
+    }
 }
 
 // Trailing update with a compile-time list of NSEG factored panels (depth 256 * NSEG): P.a[s] points at the row of
@@ -125,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void syrk_segs_kernel(double *Abase, int64_
         ti = (int)(blockIdx.x / strip);
         if (ti < tj || ti >= T) return;
     }
+    if (strip) TGP_CHAIN_PRIO();
     const int64_t pj = ob + (tj >> 1);
     const int64_t I = (int64_t)TGP_PW * ob + (int64_t)TGP_TB * ti;
     double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
@@ -241,23 +332,33 @@ __global__ __launch_bounds__(256, 2) void syrk_distn_kernel(double *Aloc, const 
     gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, c);
 }
 
-inline void run_potrf128(hipStream_t st, double *A, int lda, double *W, int *info, int base) {
+// `exclusive`: ask for so much LDS (128 KB in all) that no trailing-update workgroup fits on the compute unit beside this
+// one.  A bulk wave on the same SIMD issues fp64 MFMAs back to back and each of them holds the fp64 pipe for 64 cycles:
+// every DEPENDENT instruction of the factorisation's serial chain then waits for one (in-kernel stamps at N = 8192: the
+// 32x32 diagonal steps 14k -> 72-88k cycles, the whole block 44 -> 156 us).  Only used where free compute units are
+// guaranteed (the queued bulk update below keeps one per XCD clear); elsewhere the kernel would wait for a CU to drain.
+inline void run_potrf128(hipStream_t st, double *A, int lda, double *W, int *info, int base, bool exclusive = false) {
     static const int variant = [] { const char *e = getenv("TGP_POTRF_VARIANT"); return e ? atoi(e) : 2; }();
+    constexpr unsigned pad = 128 * 1024 - 95744;
+    static const bool pad_ok = [] {
+        return hipFuncSetAttribute((const void *)potrf_v2::potrf128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)pad) == hipSuccess;
+    }();
     if (variant == 0) potrf128_lds_kernel<<<1, 256, 0, st>>>(A, lda, W, info, base);
     else if (variant == 1) potrf_v2::potrf128_kernel<false><<<1, 256, 0, st>>>(A, lda, W, info, base);
-    else potrf_v2::potrf128_kernel<true><<<1, 256, 0, st>>>(A, lda, W, info, base);
+    else potrf_v2::potrf128_kernel<true><<<1, 256, (exclusive && pad_ok) ? pad : 0u, st>>>(A, lda, W, info, base);
 }
 }  // namespace
 
 namespace {
 // factor one 256-wide panel: the two 128x128 diagonal blocks (L + inverse) and the rows below them
-void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_info, int base) {
+void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_info, int base, bool exclusive = false) {
     double *W1 = W0 + TGP_TB * TGP_TB;
     double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
     const int r1 = (int)((mk - TGP_TB) / TGP_TB);
     // few row blocks: 16-row slices spread a block over 8 workgroups (latency); many: 128-row tiles (throughput)
     static const int small_rows = [] { const char *e = getenv("TGP_SMALL_ROWS"); return e ? atoi(e) : 24; }();
-    run_potrf128(st, Pk, TGP_PW, W0, d_info, base);
+    run_potrf128(st, Pk, TGP_PW, W0, d_info, base, exclusive);
     if (r1 <= small_rows) {
         gemm_col_small_kernel<0, TGP_TB><<<r1 * 8, 256, 0, st>>>(R1, W0, R1);
         gemm_col_small_kernel<1, TGP_PW><<<r1 * 8, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
@@ -265,7 +366,7 @@ void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_inf
         gemm_col_kernel<0, TGP_TB><<<r1, 256, 0, st>>>(R1, W0, R1);
         gemm_col_kernel<1, TGP_PW><<<r1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
     }
-    run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, d_info, base + TGP_TB);
+    run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, d_info, base + TGP_TB, exclusive);
     const int r2 = (int)((mk - TGP_PW) / TGP_TB);
     if (r2 > 0) {
         double *R2 = Pk + (int64_t)TGP_PW * TGP_PW + TGP_TB;    // row 256, column 128
@@ -347,18 +448,32 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
     };
     auto Wk = [&](int k) { return d_W + (int64_t)(2 * k) * TGP_TB * TGP_TB; };
     auto panel = [&](int k) { return d_A + panel_off(k, Np); };
+    // The side chain and the bulk update both become runnable when the strip update before them ends.  The chain's first
+    // kernel is ONE workgroup that needs half a compute unit (96 KB LDS, 260 VGPRs): if the bulk's workgroups get there
+    // first it waits for one of them to finish (measured at N = 8192: 240 us of a 660 us cycle).  So the bulk is made
+    // to wait for an event the side stream records once IT has seen the strip finish -- one more hop than the chain.
+    static const bool no_head_start = getenv("TGP_NO_HEAD_START") != nullptr;
+    auto head_start = [&](hipStream_t sd) -> hipError_t {
+        if (no_head_start) return hipSuccess;
+        hipError_t e = hipEventRecord(ctx->ev[6], sd);
+        return e != hipSuccess ? e : hipStreamWaitEvent(st, ctx->ev[6], 0);
+    };
     // ---- pairs with look-ahead (the schedule of TGP_CHOL_MODE=2, also the tail of mode 3) --------------------------
     // The update after pair (k, k+1) is split into the 4 tile columns the NEXT pair lives in (U2a) and the rest
     // (U2b); the next pair is factored on a high-priority side stream while U2b keeps the chip busy.
+    static const int queue_t = [] { const char *e = getenv("TGP_QUEUE_T"); return e ? atoi(e) : 64; }();
+    static const int small_t_pairs = [] { const char *e = getenv("TGP_SMALL_T"); return e ? atoi(e) : 8; }();
+    int nqueue = 0;
+    TGP_HIP(hipMemsetAsync(ctx->d_queue, 0, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned), st));
     auto run_pairs = [&](int kstart, bool pairs_from_scratch) -> int {
         hipStream_t sd = ctx->side_stream;
-        auto factor_pair = [&](hipStream_t s, int k) {       // F(k), U1(k), F(k+1)
+        auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false) {       // F(k), U1(k), F(k+1)
             const int64_t mk = Np - (int64_t)TGP_PW * k;
-            factor_panel(s, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW);
+            factor_panel(s, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, exclusive);
             if (k + 1 >= nP) return;
             const int T1 = (int)((mk - TGP_PW) / TGP_TB);
             launch_syrk<1>(s, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
-            factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW);
+            factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, exclusive);
         };
         if (pairs_from_scratch) factor_pair(st, kstart);
         for (int k = kstart; k + 2 < nP; k += 2) {
@@ -373,14 +488,26 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
             }
             TGP_HIP(hipEventRecord(ctx->ev[4], st));
             TGP_HIP(hipStreamWaitEvent(sd, ctx->ev[4], 0));
-            factor_pair(sd, k + 2);
-            TGP_HIP(hipEventRecord(ctx->ev[5], sd));
+            TGP_HIP(head_start(sd));
             const int T3 = T2 - 4;
+            // chain-bound steps: the bulk runs as a persistent grid that keeps one compute unit per shader engine clear
+            // for the side stream, and the diagonal blocks insist on a compute unit of their own
+            const bool queued = T3 <= queue_t && T3 > small_t_pairs && nqueue < TGP_NQUEUE;
+            factor_pair(sd, k + 2, queued);
+            TGP_HIP(hipEventRecord(ctx->ev[5], sd));
             if (T3 > 0) {   // U2b: everything from block k+4 on
                 const double m = (double)T3 * TGP_TB;
                 const int64_t skip = (int64_t)4 * TGP_TB * TGP_PW;
-                int rc = timed([&] { launch_syrk<2>(st, d_A, Np, k + 4, T3, 0, P0 + skip, P1 + skip); },
-                               2.0 * TGP_PW * m * (m + 1.0));
+                int rc = timed([&] {
+                    if (queued) {
+                        // the grid covers every workgroup slot, so the chain finds room on the reserved units only
+                        syrk_dtv_queue_kernel<2><<<512 + 8, 256, 0, st>>>(d_A, Np, k + 4, T3, (unsigned)(tilemap_grid(T3) / 8),
+                                                                       ctx->d_queue + TGP_QUEUE_WORDS * nqueue, P0 + skip, P1 + skip);
+                        ++nqueue;
+                    } else {
+                        launch_syrk<2>(st, d_A, Np, k + 4, T3, 0, P0 + skip, P1 + skip);
+                    }
+                }, 2.0 * TGP_PW * m * (m + 1.0));
                 if (rc) return rc;
             }
             TGP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));
@@ -476,6 +603,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W) {
             }
             TGP_HIP(hipEventRecord(ctx->ev[4], st));
             TGP_HIP(hipStreamWaitEvent(sd, ctx->ev[4], 0));
+            TGP_HIP(head_start(sd));
             factor_group(sd, k + 4);
             TGP_HIP(hipEventRecord(ctx->ev[5], sd));
             const int T5 = T4 - 8;
@@ -653,8 +781,16 @@ int tgp_debug_syrk_loop(tgp_ctx *ctx, double *d_A, int64_t Np, int reps, double 
 }
 
 #ifdef TGP_POTRF_STAMPS
+extern "C" int tgp_debug_gemm_stamps(unsigned long long *out, int grid) {
+    if (grid > 0) return (int)hipMemcpyToSymbol(HIP_SYMBOL(tgp_gemm_stamp_grid), &grid, sizeof(int));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_gemm_stamps), 1024 * 4 * sizeof(unsigned long long));
+}
+extern "C" int tgp_debug_queue_stamps(unsigned long long *out, int T) {
+    if (T > 0) return (int)hipMemcpyToSymbol(HIP_SYMBOL(tgp_queue_stamp_T), &T, sizeof(int));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_queue_stamps), 1024 * 4 * sizeof(unsigned long long));
+}
 extern "C" int tgp_debug_potrf_stamps(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_potrf_stamps), 32 * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_potrf_stamps), 1024 * 20 * sizeof(unsigned long long));   // [block][stamp]
 }
 #endif
 

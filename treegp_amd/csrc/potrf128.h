@@ -20,8 +20,9 @@
 #include "tgp_internal.h"
 
 #ifdef TGP_POTRF_STAMPS
-__device__ unsigned long long tgp_potrf_stamps[32];
-#define POTRF_STAMP(i) do { if (threadIdx.x == 0) tgp_potrf_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// one row of stamps per diagonal block of the factorisation (row = base / 128), so that every call can be looked at in situ
+__device__ unsigned long long tgp_potrf_stamps[1024 * 20];
+#define POTRF_STAMP(i) do { if (threadIdx.x == 0) tgp_potrf_stamps[((base >> 7) & 1023) * 20 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define POTRF_STAMP(i) do { } while (0)
 #endif
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const d4v zero4 = {0.0, 0.0, 0.0, 0.0};
+    TGP_CHAIN_PRIO();
     POTRF_STAMP(0);
 
     {   // the block comes in with all its loads in flight at once (two columns per thread, coalesced rows);

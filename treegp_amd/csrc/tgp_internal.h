@@ -9,6 +9,16 @@
 #include <vector>
 #include "../../include/tgp.h"
 
+// Kernels of the serial panel chain (diagonal block, panel solves, strips) share compute units with the bulk trailing
+// update during the look-ahead: their waves ask the instruction arbiter for precedence over the bulk's.
+#ifdef TGP_NO_CHAIN_PRIO
+#define TGP_CHAIN_PRIO() ((void)0)
+#else
+#define TGP_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
+#define TGP_QUEUE_WORDS 48     // per launch: 8 XCD-class tile counters + 8 x 4 reserved-CU words + 8 leave counters
+#define TGP_NQUEUE 128        // persistent bulk-update launches per factorisation (one set of 8 counters each)
 #define TGP_TB 128            // tile / diagonal-block size
 #define TGP_PW 256            // panel width = trailing-update depth
 
@@ -27,6 +37,7 @@ struct tgp_ctx {
     size_t scratch_bytes = 0;
     void *scratch2 = nullptr;     // second, small scratch (partial sums) that may be live beside `scratch`
     size_t scratch2_bytes = 0;
+    unsigned *d_queue = nullptr;  // tile-queue counters of the persistent bulk update (TGP_NQUEUE launches x TGP_QUEUE_WORDS)
     int *d_info = nullptr;        // first failing pivot (1-based), 0 = ok
     int *h_info = nullptr;        // pinned mirror
     double *d_scal = nullptr;     // small device scalars (logdet, dot, ...)
