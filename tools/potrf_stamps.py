@@ -32,7 +32,9 @@ t0 = s[0, 0]
 nblk = (n + 127) // 128
 for b in range(first, min(first + count, nblk)):
     d = np.diff(s[b, :17])
-    print("%5d  %9.1f %8.1f  | " % (b, (s[b, 0] - t0) / 100.0, (s[b, 16] - s[b, 0]) / 100.0) + " ".join("%6.0f" % v for v in d))
+    where = int(s[b, 17])
+    print("%5d  %9.1f %8.1f  | " % (b, (s[b, 0] - t0) / 100.0, (s[b, 16] - s[b, 0]) / 100.0) + " ".join("%6.0f" % v for v in d) +
+          "   xcc %d se %d cu %d" % (where >> 8, (where >> 5) & 7, where & 15))
 
 # one panel GEMM of the chain (gemm_col_kernel<0> with TGP_STAMP_GRID workgroups): when and where each workgroup ran
 grid = int(os.environ.get("TGP_STAMP_GRID", "0"))

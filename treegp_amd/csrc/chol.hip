@@ -357,7 +357,7 @@ void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_inf
     double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
     const int r1 = (int)((mk - TGP_TB) / TGP_TB);
     // few row blocks: 16-row slices spread a block over 8 workgroups (latency); many: 128-row tiles (throughput)
-    static const int small_rows = [] { const char *e = getenv("TGP_SMALL_ROWS"); return e ? atoi(e) : 24; }();
+    static const int small_rows = [] { const char *e = getenv("TGP_SMALL_ROWS"); return e ? atoi(e) : 40; }();
     run_potrf128(st, Pk, TGP_PW, W0, d_info, base, exclusive);
     if (r1 <= small_rows) {
         gemm_col_small_kernel<0, TGP_TB><<<r1 * 8, 256, 0, st>>>(R1, W0, R1);

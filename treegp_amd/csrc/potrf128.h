@@ -376,5 +376,9 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
         *reinterpret_cast<double2 *>(W + i * 128 + c) = v;
     }
     POTRF_STAMP(16);
+#ifdef TGP_POTRF_STAMPS
+    if (threadIdx.x == 0)      // where it ran: XCC_ID << 8 | HW_ID[15:8]
+        tgp_potrf_stamps[((base >> 7) & 1023) * 20 + 17] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 8) | __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));
+#endif
 }
 }  // namespace potrf_v2
