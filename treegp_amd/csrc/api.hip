@@ -261,23 +261,29 @@ int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t
     rc = launch_kbuild_lower(ctx, k, d_X, n, Np, d_yerr, d_A);
     if (rc) return rc;
     TGP_HIP(hipEventRecord(ctx->ev[1], st));
-    int info = launch_potrf(ctx, d_A, Np, d_W);      // synchronises
+    // The solves are queued behind the factorisation without waiting for its verdict (one host round trip less per
+    // likelihood evaluation); if a pivot failed they run on a meaningless factor and their result is discarded below.
+    int info = launch_potrf(ctx, d_A, Np, d_W, /*defer_info=*/true);
     if (info < 0) return info;
     TGP_HIP(hipEventRecord(ctx->ev[2], st));
     if (info == 0) {
         TGP_HIP(hipMemsetAsync(d_b, 0, (size_t)Np * sizeof(double), st));
         TGP_HIP(hipMemcpyAsync(d_b, d_y, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        rc = launch_potrs(ctx, d_A, d_W, Np, d_b);
+        // without alpha only the quadratic form is wanted: y^T K^-1 y = |L^-1 y|^2, the forward sweep alone
+        static const bool both_sweeps = getenv("TGP_CHI2_BOTH_SWEEPS") != nullptr;      // A/B: y . alpha as before
+        const bool forward_only = d_alpha == nullptr && !both_sweeps;
+        rc = launch_potrs(ctx, d_A, d_W, Np, d_b, forward_only);
         if (rc) return rc;
         rc = launch_logdet(ctx, d_A, Np, n, ctx->d_scal);
         if (rc) return rc;
-        rc = launch_dot(ctx, d_y, d_b, n, ctx->d_scal + 1);
+        rc = launch_dot(ctx, forward_only ? d_b : d_y, d_b, n, ctx->d_scal + 1);
         if (rc) return rc;
         if (d_alpha) TGP_HIP(hipMemcpyAsync(d_alpha, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
         TGP_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     TGP_HIP(hipEventRecord(ctx->ev[3], st));
     TGP_HIP(hipStreamSynchronize(st));
+    if (info == 0) info = *ctx->h_info;               // the factorisation's verdict (first failing pivot, 1-based)
     float ms = 0.f;
     TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->timings[0] = ms;
@@ -318,7 +324,7 @@ int tgp_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n, 
     TGP_HIP(hipMemcpyAsync(d_X, X, 2 * n * 8, hipMemcpyHostToDevice, st));
     TGP_HIP(hipMemcpyAsync(d_y, y, n * 8, hipMemcpyHostToDevice, st));
     if (yerr) TGP_HIP(hipMemcpyAsync(d_e, yerr, n * 8, hipMemcpyHostToDevice, st));
-    rc = tgp_d_gp_solve(ctx, k, d_X, n, d_y, yerr ? d_e : nullptr, d_a, logdet, ydota, keep);
+    rc = tgp_d_gp_solve(ctx, k, d_X, n, d_y, yerr ? d_e : nullptr, alpha ? d_a : nullptr, logdet, ydota, keep);
     if (rc) return rc;
     if (alpha) {
         TGP_HIP(hipMemcpyAsync(alpha, d_a, n * 8, hipMemcpyDeviceToHost, st));

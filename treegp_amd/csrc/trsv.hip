@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void fwd_update256_kernel(const double *__rest
 // 128-block sweep (4 small launches per block): measured faster on one GPU than the fused 256-panel
 // sweep below (10.6 vs 12.2 ms at N=32768); the fused kernels serve the multi-GPU driver, where fewer
 // launches and collectives per block matter more.
-int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b) {
+int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only) {
     hipStream_t st = ctx->stream;
     const int nb = (int)(Np / TGP_TB);
     // forward: L z = b
@@ -308,8 +308,8 @@ int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np,
                                                  d_b + (int64_t)(kb + 1) * TGP_TB);
         }
     }
-    // backward: L^T a = z
-    for (int kb = nb - 1; kb >= 0; --kb) {
+    // backward: L^T a = z   (not needed for the quadratic form alone: y^T K^-1 y = z^T z)
+    for (int kb = nb - 1; kb >= 0 && !forward_only; --kb) {
         diag_gemv_t_kernel<<<1, 256, 0, st>>>(d_W + (int64_t)kb * TGP_TB * TGP_TB, d_b + (int64_t)kb * TGP_TB);
         if (kb > 0) bwd_update_kernel<<<kb, 256, 0, st>>>(d_A, Np, kb, d_b + (int64_t)kb * TGP_TB, d_b);
     }
