@@ -45,6 +45,17 @@ def get_kernel_class(A):
     raise ValueError(msg)
 
 
+
+def _inv2x2(m):
+    """Inverse of a 2x2 matrix by the adjugate (the reference calls numpy.linalg.inv here, two_pcf.py:109,139; LAPACK
+    on a 2x2 costs ~80 us per call with a many-threaded BLAS, and the chi2 of the fit makes two per evaluation)."""
+    a, b, c, d = m[0, 0], m[0, 1], m[1, 0], m[1, 1]
+    det = a * d - b * c
+    if det == 0.0:
+        raise np.linalg.LinAlgError("Singular matrix")
+    return np.array([[d, -b], [-c, a]]) / det
+
+
 class robust_2dfit(object):
     """Fit (size, g1, g2) of an anisotropic kernel to the 2-D correlation function; amplitude and
     additive constant are linear and solved in closed form inside chi2 (two_pcf.py:68-206).
@@ -65,7 +76,7 @@ class robust_2dfit(object):
         outside |g| <= 1 (two_pcf.py:96-113)."""
         if max(abs(g1), abs(g2)) > 1:
             return None
-        invLam = np.linalg.inv(get_correlation_length_matrix(corr_length, g1, g2))
+        invLam = _inv2x2(get_correlation_length_matrix(corr_length, g1, g2))
         self.kernel_fit = sigma ** 2 * self.kernel_class(invLam=invLam)
         # the reference evaluates the kernel against a whole array of zeros and keeps column 0 (two_pcf.py:111-113);
         # one origin row gives the same column at 1/npix of the work
@@ -83,7 +94,7 @@ class robust_2dfit(object):
         data = self.flat_data[self.mask]
         F = np.column_stack([m, np.ones_like(m)])
         FtW = F.T.dot(self.W)
-        self.alpha = np.linalg.inv(FtW.dot(F)).dot(FtW.dot(data.reshape(-1, 1)))
+        self.alpha = _inv2x2(FtW.dot(F)).dot(FtW.dot(data.reshape(-1, 1)))
         self.alpha[0] = abs(self.alpha[0])
         self.residuals = data - (self.alpha[0] * m + self.alpha[1])
         self.chi2_value = self.residuals.dot(self.W).dot(self.residuals.reshape(-1, 1))
