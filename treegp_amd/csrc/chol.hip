@@ -448,11 +448,11 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     };
     auto Wk = [&](int k) { return d_W + (int64_t)(2 * k) * TGP_TB * TGP_TB; };
     auto panel = [&](int k) { return d_A + panel_off(k, Np); };
-    // The side chain and the bulk update both become runnable when the strip update before them ends.  The chain's first
-    // kernel is ONE workgroup that needs half a compute unit (96 KB LDS, 260 VGPRs): if the bulk's workgroups get there
-    // first it waits for one of them to finish (measured at N = 8192: 240 us of a 660 us cycle).  So the bulk is made
-    // to wait for an event the side stream records once IT has seen the strip finish -- one more hop than the chain.
-    static const bool no_head_start = getenv("TGP_NO_HEAD_START") != nullptr;
+    // TGP_HEAD_START=1 (A/B): the bulk waits for an event the side stream records once IT has seen the strip update
+    // finish, one hop more than the chain's first kernel.  It was the first remedy for the chain waiting behind the bulk's
+    // first round of workgroups (measured at N = 8192: 240 us of a 660 us cycle); with the clear compute units of the
+    // queued bulk update it no longer pays (7.65 vs 7.79 ms at N = 8192) and it costs the bulk ~22 us per step.
+    static const bool no_head_start = getenv("TGP_HEAD_START") == nullptr;
     auto head_start = [&](hipStream_t sd) -> hipError_t {
         if (no_head_start) return hipSuccess;
         hipError_t e = hipEventRecord(ctx->ev[6], sd);
@@ -488,11 +488,11 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             }
             TGP_HIP(hipEventRecord(ctx->ev[4], st));
             TGP_HIP(hipStreamWaitEvent(sd, ctx->ev[4], 0));
-            TGP_HIP(head_start(sd));
             const int T3 = T2 - 4;
             // chain-bound steps: the bulk runs as a persistent grid that keeps one compute unit per shader engine clear
             // for the side stream, and the diagonal blocks insist on a compute unit of their own
             const bool queued = T3 <= queue_t && T3 > small_t_pairs && nqueue < TGP_NQUEUE;
+            if (queued) TGP_HIP(head_start(sd));      // off by default, see above
             factor_pair(sd, k + 2, queued);
             TGP_HIP(hipEventRecord(ctx->ev[5], sd));
             if (T3 > 0) {   // U2b: everything from block k+4 on
@@ -603,7 +603,6 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             }
             TGP_HIP(hipEventRecord(ctx->ev[4], st));
             TGP_HIP(hipStreamWaitEvent(sd, ctx->ev[4], 0));
-            TGP_HIP(head_start(sd));
             factor_group(sd, k + 4);
             TGP_HIP(hipEventRecord(ctx->ev[5], sd));
             const int T5 = T4 - 8;
