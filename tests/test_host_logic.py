@@ -174,3 +174,13 @@ def test_potrf128_register_budget():
     script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_potrf_regs.sh")
     r = subprocess.run(["bash", script], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_two_pcf_adjugate_inverse_matches_lapack():
+    from treegp_amd.two_pcf import _inv2x2
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        m = rng.standard_normal((2, 2)) * 10.0 ** rng.integers(-3, 4)
+        np.testing.assert_allclose(_inv2x2(m), np.linalg.inv(m), rtol=1e-12)
+    with pytest.raises(np.linalg.LinAlgError):
+        _inv2x2(np.array([[1.0, 2.0], [2.0, 4.0]]))

@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void syrk_distn_kernel(double *Aloc, const 
     const int64_t bi = dist_first_ge(s0, g, G) + (int64_t)(lt >> 1) * G;
     const int64_t gti = 2 * (bi - s0) + (lt & 1);
     if (gtj > gti) return;
+    if (ncol <= 8) TGP_CHAIN_PRIO();          // strips of the panel chain (2 or 2 GS tile columns), not the bulk
     const int64_t bj = s0 + (gtj >> 1);
     const int rj = (int)(bj % G);
     const int64_t hi = (lt & 1) * TGP_TB, hj = (gtj & 1) * TGP_TB;
@@ -464,7 +465,8 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     static const int queue_t = [] { const char *e = getenv("TGP_QUEUE_T"); return e ? atoi(e) : 64; }();
     static const int small_t_pairs = [] { const char *e = getenv("TGP_SMALL_T"); return e ? atoi(e) : 8; }();
     int nqueue = 0;
-    TGP_HIP(hipMemsetAsync(ctx->d_queue, 0, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned), st));
+    if (Np / TGP_TB - 8 > small_t_pairs)      // some step can take the queued form (T3 = Np/128 - 8 at the first pair)
+        TGP_HIP(hipMemsetAsync(ctx->d_queue, 0, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned), st));
     auto run_pairs = [&](int kstart, bool pairs_from_scratch) -> int {
         hipStream_t sd = ctx->side_stream;
         auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false) {       // F(k), U1(k), F(k+1)
