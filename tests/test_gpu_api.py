@@ -282,6 +282,29 @@ def test_ml_fit_concurrent_differences_follow_the_sequential_path():
     print("ML fit N=600: sequential %.1f ms, concurrent differences %.1f ms" % (walls[0] * 1e3, walls[1] * 1e3))
 
 
+def test_resident_problem_matches_host_boundary_solve():
+    """ops.ResidentProblem / gp_solve_resident (what the evaluations of one ML fit use): same numbers as gp_solve,
+    from several contexts, with and without errors, 1-D and 2-D coordinates."""
+    from treegp_amd import _lib, ops
+    rng = np.random.default_rng(21)
+    for n, ndim, with_err in ((300, 1, True), (777, 2, True), (1500, 2, False)):
+        X = rng.uniform(0, 1, (n, ndim)); y = rng.standard_normal(n); e = rng.uniform(0.05, 0.2, n) if with_err else None
+        spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.1, a=50.0, b=(5.0 if ndim == 2 else 0.0), c=(70.0 if ndim == 2 else 1.0))
+        if not with_err:
+            spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.1, a=4000.0, b=300.0, c=5000.0)   # narrow: positive definite without a noise diagonal
+        _, logdet, chi2, _ = ops.gp_solve(spec, X, y, e, want_alpha=False)
+        prob = ops.ResidentProblem(X, y, e)
+        for ctx in (None, _lib.new_ctx(0)):
+            ld, c2 = ops.gp_solve_resident(spec, prob, ctx=ctx)
+            np.testing.assert_allclose([ld, c2], [logdet, chi2], rtol=1e-13)
+        prob.close()
+    # not positive definite: same exception as the host-boundary call
+    X = np.zeros((64, 2)); prob = ops.ResidentProblem(X, np.ones(64), None)
+    with pytest.raises(np.linalg.LinAlgError):
+        ops.gp_solve_resident(ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=1.0, b=0.0, c=1.0), prob)
+    prob.close()
+
+
 def test_hyperparameter_search_two_pcf_1d():
     for ker, sig, ell, max_sep in (("RBF", 1.0, 0.5, 1.75), ("RBF", 2.0, 0.8, 1.75), ("VonKarman", 1.0, 8.0, 1.25),
                                    ("VonKarman", 2.0, 10.0, 1.25)):

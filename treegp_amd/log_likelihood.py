@@ -7,6 +7,8 @@ reference passes no ``jac``, :57, so SciPy differentiates numerically).  The dif
 ntheta + 1 evaluations one gradient needs are independent solves of a small problem, which leave
 most of the GPU idle one at a time: they are issued together, one context / stream per evaluation
 (``parallel_fd``; 2-2.5x on a fit at N = 512 ... 8192).  Same optimiser, same formula, same iterates.
+During a fit the data stay on the device (``ops.ResidentProblem``): an evaluation sends the kernel parameters and gets
+two scalars back; the quadratic form is |L^-1 y|^2, i.e. the forward triangular sweep alone.
 """
 import copy
 import os
@@ -40,12 +42,16 @@ class log_likelihood(object):
         self.ndata = len(X[:, 0])
         self.parallel_fd = os.environ.get("TGP_ML_PARALLEL", "1") != "0" and self.ndata <= _PARALLEL_MAX_N
 
-    def log_likelihood(self, kernel, ctx=None):
+    def log_likelihood(self, kernel, ctx=None, resident=None):
         """-0.5 y.K^-1.y - (n/2) log 2 pi - 0.5 log det K; any failure (e.g. K not positive
-        definite) gives -inf, as at log_likelihood.py:28-39."""
+        definite) gives -inf, as at log_likelihood.py:28-39.  `resident`: the data already on the device
+        (ops.ResidentProblem, used by optimizer() for the evaluations of one fit)."""
         try:
-            _, log_det, chi2, _ = ops.gp_solve(kernel_to_spec(kernel), self.X, self.y, self.y_err, want_alpha=False,
-                                               ctx=ctx)
+            if resident is not None:
+                log_det, chi2 = ops.gp_solve_resident(kernel_to_spec(kernel), resident, ctx=ctx)
+            else:
+                _, log_det, chi2, _ = ops.gp_solve(kernel_to_spec(kernel), self.X, self.y, self.y_err, want_alpha=False,
+                                                   ctx=ctx)
             ll = -0.5 * chi2 - (0.5 * self.ndata) * np.log(2.0 * np.pi) - 0.5 * log_det
         except (np.linalg.LinAlgError, FloatingPointError, ValueError, ops._lib.TgpError):
             ll = -np.inf
@@ -56,10 +62,23 @@ class log_likelihood(object):
     def optimizer(self, kernel):
         """L-BFGS-B on -log L over theta (log_likelihood.py:43-62)."""
         template = kernel
+        # X, y, y_err do not change during the fit: they go to the device once, every evaluation sends only theta
+        resident = ops.ResidentProblem(self.X, self.y, self.y_err) if os.environ.get("TGP_ML_RESIDENT", "1") != "0" else None
 
         def cost(theta, ctx=None):
-            return -self.log_likelihood(template.clone_with_theta(theta), ctx=ctx)
+            return -self.log_likelihood(template.clone_with_theta(theta), ctx=ctx, resident=resident)
 
+        try:
+            best = self._minimise(cost, template)
+        finally:
+            if resident is not None:
+                resident.close()
+        fitted = template.clone_with_theta(best)
+        self._kernel = copy.deepcopy(fitted)
+        self._logL = self.log_likelihood(self._kernel)
+        return fitted
+
+    def _minimise(self, cost, template):
         if self.parallel_fd:
             ntheta = len(template.theta)
             ctxs = _contexts(ntheta + 1)
@@ -82,7 +101,4 @@ class log_likelihood(object):
                 pool.shutdown()
         else:
             best = optimize.minimize(cost, template.theta, method="L-BFGS-B")["x"]
-        fitted = template.clone_with_theta(best)
-        self._kernel = copy.deepcopy(fitted)
-        self._logL = self.log_likelihood(self._kernel)
-        return fitted
+        return best
