@@ -33,6 +33,8 @@ def main():
             ops.gp_solve_resident(spec, prob)
         dtr = (time.perf_counter() - t0) / reps
         prob.close()
+        a = ops.gp_solve(spec, X, y, ye)[0]          # warm-up: first use of a size grows the library's scratch buffers
+        ops.gp_predict(spec, X, a, Xs)
         t0 = time.perf_counter()
         for _ in range(reps):
             a = ops.gp_solve(spec, X, y, ye)[0]
