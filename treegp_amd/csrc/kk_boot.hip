@@ -314,5 +314,10 @@ int kk_bootstrap_lists(tgp_ctx *ctx, const double *x, const double *y, const dou
     float ms = 0.f;
     TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->timings[4] = ms;
+    if (ctx->scratch2_bytes > ((size_t)256 << 20)) {      // a pair list of this size is not worth holding on to
+        TGP_HIP(hipFree(ctx->scratch2));
+        ctx->scratch2 = nullptr;
+        ctx->scratch2_bytes = 0;
+    }
     return 0;
 }
