@@ -133,6 +133,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void syrk_dtv_kernel(doub
     gemm_tile_dtv<NW, TGP_PW, NSEG>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
 }
 
+// Strip updates on the chain's critical path (the tile columns of the next panels) with 64-row tiles: each wave owns
+// 16 x 128 of C instead of 32 x 128, so a tile takes half as long, and while the strip fits the chip in one round either
+// way (twice the workgroups, still at most two rounds up to T = 128) the panel chain waits about half as long for it.
+template <int NSEG>
+__global__ __launch_bounds__(256, 2) void syrk_strip64_kernel(double *Abase, int64_t Np, int ob, int T, int strip, const double *P0,
+                                                              const double *P1) {
+    const int tj = (int)(blockIdx.x % strip);        // 128-column tile
+    const int th = (int)(blockIdx.x / strip);        // 64-row half tile
+    const int ti = th >> 1;
+    if (ti < tj || ti >= T) return;
+    TGP_CHAIN_PRIO();
+    const int64_t pj = ob + (tj >> 1);
+    const int64_t I = (int64_t)TGP_PW * ob + (int64_t)64 * th;
+    double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
+    const int64_t oa = (int64_t)th * 64 * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
+    gemm_tile_dtv<4, TGP_PW, NSEG, 1>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
+}
+
 // The depth-512 bulk update as a PERSISTENT grid that leaves part of the chip free, for steps where the serial panel
 // chain (side stream) is longer than the update.  A bulk workgroup lives ~126 us and a plain launch fills both
 // workgroup slots of all 256 CUs at once, so the chain's kernels -- potrf128 needs a CU with a free slot, the panel
@@ -391,6 +409,11 @@ void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int str
     if (tile == 8 && (T & 1) == 0 && !stamps) {
         const unsigned gs = strip == 0 ? (unsigned)(2 * tilemap_grid(T / 2)) : (unsigned)((int64_t)(T / 2) * strip);
         syrk_dtv_kernel<8, NSEG><<<gs, 512, 0, st>>>(d_A, Np, ob, T, strip, P0, P1);
+        return;
+    }
+    static const int strip64_t = [] { const char *e = getenv("TGP_STRIP64_T"); return e ? atoi(e) : 128; }();
+    if (strip > 0 && T <= strip64_t && tile == 4 && !stamps) {
+        syrk_strip64_kernel<NSEG><<<(unsigned)((int64_t)2 * T * strip), 256, 0, st>>>(d_A, Np, ob, T, strip, P0, P1);
         return;
     }
     const unsigned gs = strip == 0 ? (unsigned)tilemap_grid(T) : (unsigned)((int64_t)T * strip);

@@ -385,7 +385,7 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
 // k assignment: lane (r, kq) handles k = 8h + 2kq + {0, 1} in MFMA steps 2h, 2h+1, so both the direct A
 // loads and the B fragment reads are 16-byte accesses (B rows padded to 18 doubles: conflict-free b128).
 // NSEG = 0: run-time number of operand pairs, pair s at a_ptr + s * seg_stride_a / b_ptr + s * seg_stride_b.
-template <int NW, int KDEPTH, int NSEG>
+template <int NW, int KDEPTH, int NSEG, int MT = 2>
 __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double *b_ptr, double *c_ptr,
                                               const double *a1_ptr, const double *b1_ptr, int nseg_rt = 1,
                                               int64_t seg_stride_a = 0, int64_t seg_stride_b = 0) {
@@ -400,22 +400,22 @@ __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    const __amdgpu_buffer_rsrc_t ra0 = tile_rsrc(a_ptr, 32 * NW * LD * 8);
+    const __amdgpu_buffer_rsrc_t ra0 = tile_rsrc(a_ptr, 16 * MT * NW * LD * 8);
     const __amdgpu_buffer_rsrc_t rb0 = tile_rsrc(b_ptr, 128 * LD * 8);
-    const __amdgpu_buffer_rsrc_t ra1 = tile_rsrc(NSEG > 1 ? a1_ptr : a_ptr, 32 * NW * LD * 8);
+    const __amdgpu_buffer_rsrc_t ra1 = tile_rsrc(NSEG > 1 ? a1_ptr : a_ptr, 16 * MT * NW * LD * 8);
     const __amdgpu_buffer_rsrc_t rb1 = tile_rsrc(NSEG > 1 ? b1_ptr : b_ptr, 128 * LD * 8);
-    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(c_ptr, 32 * NW * LD * 8);
-    const int va = ((32 * w + l15) * LD + 2 * l4) * 8;          // A: row of m-tile 0, k-pair kq
+    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(c_ptr, 16 * MT * NW * LD * 8);
+    const int va = ((16 * MT * w + l15) * LD + 2 * l4) * 8;          // A: row of m-tile 0, k-pair kq
     const int srow = tid >> 3, kp = (tid & 7) * 2;
     const int vb = (srow * LD + kp) * 8;                        // B staging piece
-    const int vc = ((32 * w + l4) * LD + l15) * 8;              // C fragment: col = lane & 15, row = (lane >> 4) + 4r
+    const int vc = ((16 * MT * w + l4) * LD + l15) * 8;              // C fragment: col = lane & 15, row = (lane >> 4) + 4r
     const int fb = l15 * LSB + 2 * l4;                          // B fragment read
 
-    double2 areg[2][2][2];                                      // [set][m][h]
+    double2 areg[2][MT][2];                                      // [set][m][h]
     double2 rbst[BPT];
-    auto load_a = [&](double2 (&dst)[2][2], __amdgpu_buffer_rsrc_t src, int k0) {
+    auto load_a = [&](double2 (&dst)[MT][2], __amdgpu_buffer_rsrc_t src, int k0) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int h = 0; h < 2; ++h) dst[m][h] = buf_ld2(src, va, (m * 16 * LD + k0 + 8 * h) * 8);
     };
@@ -430,9 +430,9 @@ __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double 
     load_a(areg[0], ra0, 0);
     load_b(rb0, 0);
 
-    d4 acc[2][8];
+    d4 acc[MT][8];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 8; ++n)
 #pragma unroll
@@ -440,14 +440,14 @@ __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double 
     store_b(0);
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 8; ++n) acc[m][n] = -acc[m][n];
 
     constexpr int cps = KDEPTH / KB;
     static_assert(cps % 2 == 0, "chunks are processed in register-set pairs");
     const int nchunk = (NSEG > 0 ? NSEG : nseg_rt) * cps;
-    auto step = [&](const int c, double2 (&cur)[2][2], double2 (&nxt)[2][2]) {
+    auto step = [&](const int c, double2 (&cur)[MT][2], double2 (&nxt)[MT][2]) {
         const int buf = c & 1;
         const bool more = (c + 1 < nchunk);
         if (more) {
@@ -457,7 +457,7 @@ __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double 
             __amdgpu_buffer_rsrc_t sa = second ? ra1 : ra0, sb = second ? rb1 : rb0;
             if constexpr (NSEG == 0) {
                 const int seg = cn / cps;
-                sa = tile_rsrc(a_ptr + seg * seg_stride_a, 32 * NW * LD * 8);
+                sa = tile_rsrc(a_ptr + seg * seg_stride_a, 16 * MT * NW * LD * 8);
                 sb = tile_rsrc(b_ptr + seg * seg_stride_b, 128 * LD * 8);
             }
             load_a(nxt, sa, k0);
@@ -470,12 +470,12 @@ __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double 
 #pragma unroll
             for (int n = 0; n < 8; ++n) bf[n] = *reinterpret_cast<const double2 *>(&Bs[fb + n * 16 * LSB + 8 * h]);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < 8; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m][h].x, bf[n].x, acc[m][n], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < 8; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m][h].y, bf[n].y, acc[m][n], 0, 0, 0);
@@ -491,7 +491,7 @@ __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double 
     }
 
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 8; ++n)
 #pragma unroll
