@@ -267,16 +267,14 @@ int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t
     if (info < 0) return info;
     TGP_HIP(hipEventRecord(ctx->ev[2], st));
     if (info == 0) {
-        TGP_HIP(hipMemsetAsync(d_b, 0, (size_t)Np * sizeof(double), st));
-        TGP_HIP(hipMemcpyAsync(d_b, d_y, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        rc = launch_pad_copy(ctx, d_y, n, Np, d_b);
+        if (rc) return rc;
         // without alpha only the quadratic form is wanted: y^T K^-1 y = |L^-1 y|^2, the forward sweep alone
         static const bool both_sweeps = getenv("TGP_CHI2_BOTH_SWEEPS") != nullptr;      // A/B: y . alpha as before
         const bool forward_only = d_alpha == nullptr && !both_sweeps;
         rc = launch_potrs(ctx, d_A, d_W, Np, d_b, forward_only);
         if (rc) return rc;
-        rc = launch_logdet(ctx, d_A, Np, n, ctx->d_scal);
-        if (rc) return rc;
-        rc = launch_dot(ctx, forward_only ? d_b : d_y, d_b, n, ctx->d_scal + 1);
+        rc = launch_logdet_dot(ctx, d_A, Np, n, forward_only ? d_b : d_y, d_b, ctx->d_scal);
         if (rc) return rc;
         if (d_alpha) TGP_HIP(hipMemcpyAsync(d_alpha, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
         TGP_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -137,6 +137,8 @@ int launch_logdet_dist(tgp_ctx *ctx, const double *d_Aloc, const int64_t *d_loff
 int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only = false);
 int launch_logdet(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out);
 int launch_dot(tgp_ctx *ctx, const double *d_a, const double *d_b, int64_t n, double *d_out);
+int launch_logdet_dot(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, const double *d_a, const double *d_b, double *d_out);
+int launch_pad_copy(tgp_ctx *ctx, const double *d_y, int64_t n, int64_t Np, double *d_b);
 int launch_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_alpha,
                    const double *d_Xs, int64_t m, double *d_ys);
 int launch_unpack_lower(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out);

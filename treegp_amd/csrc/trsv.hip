@@ -126,6 +126,33 @@ __global__ __launch_bounds__(1024) void dot_kernel(const double *__restrict__ a,
     }
 }
 
+// both scalars of a likelihood evaluation in one launch: out[0] = log det, out[1] = a . b
+__global__ __launch_bounds__(1024) void logdet_dot_kernel(const double *__restrict__ A, int64_t Np, int64_t n,
+                                                          const double *__restrict__ a, const double *__restrict__ b, double *out) {
+    __shared__ double part[2][16];
+    double s = 0.0, d = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int64_t p = i >> 8;
+        s += 2.0 * log(A[panel_off(p, Np) + (i - p * TGP_PW) * TGP_PW + (i & 255)]);
+        d += a[i] * b[i];
+    }
+    s = wave_sum(s);
+    d = wave_sum(d);
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s; part[1][threadIdx.x >> 6] = d; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += part[threadIdx.x][k];
+        out[threadIdx.x] = t;
+    }
+}
+
+// b (Np) <- [y (n), 0 ...]: the padded right-hand side in one launch
+__global__ void pad_copy_kernel(const double *__restrict__ y, int64_t n, int64_t Np, double *__restrict__ b) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < Np) b[i] = i < n ? y[i] : 0.0;
+}
+
 // out[c] += sign * sum_r L[r][c] a[r] over `rows` rows of a 128-column block (ld 256); partial sums
 // per workgroup are combined with global fp64 atomics (out must be initialised by the caller)
 __global__ __launch_bounds__(256) void gemv_t_acc_kernel(const double *__restrict__ L, int64_t rows,
@@ -354,6 +381,18 @@ int launch_potrs_panel256(tgp_ctx *ctx, const double *d_A, const double *d_W, in
 
 int launch_logdet(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out) {
     logdet_kernel<<<1, 1024, 0, ctx->stream>>>(d_A, Np, n, d_out);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_logdet_dot(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, const double *d_a, const double *d_b, double *d_out) {
+    logdet_dot_kernel<<<1, 1024, 0, ctx->stream>>>(d_A, Np, n, d_a, d_b, d_out);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_pad_copy(tgp_ctx *ctx, const double *d_y, int64_t n, int64_t Np, double *d_b) {
+    pad_copy_kernel<<<(unsigned)((Np + 255) / 256), 256, 0, ctx->stream>>>(d_y, n, Np, d_b);
     TGP_HIP(hipGetLastError());
     return 0;
 }
