@@ -159,25 +159,30 @@ __global__ __launch_bounds__(256, 2) void syrk_strip64_kernel(double *Abase, int
 // stay free for the chain.  One counter per XCD class keeps the XCD-aware tile map (blockIdx.x & 7 = XCD of the
 // workgroup); the loop ends for every workgroup once its class has run out of slots.
 template <int NSEG>
-__global__ __launch_bounds__(256, 2) void syrk_dtv_queue_kernel(double *Abase, int64_t Np, int ob, int T, unsigned slots_per_class,
+__global__ __launch_bounds__(256, 2) void syrk_dtv_queue_kernel(double *Abase, int64_t Np, int ob, int T, unsigned slots_per_class, int nres,
                                                                 unsigned *__restrict__ queue, const double *P0, const double *P1) {
     __shared__ unsigned s_slot;
     const unsigned xcd = blockIdx.x & 7;
-    {   // One compute unit per shader engine and XCD (32 of 256) is kept clear of this kernel: the first workgroup to arrive
-        // on a shader engine names its own CU (queue[8 + 4 XCC_ID + SE_ID]) and leaves, and so does every later one that
-        // lands there.  Per shader engine, because the dispatcher deals the workgroups of a kernel to the shader engines
-        // in strict rotation and stalls on a full one: free CUs on a single engine admit one or two workgroups of the
-        // chain's kernels and the rest wait behind them (measured with in-kernel stamps, tools/potrf_stamps.py).
+    {   // `nres` compute units per shader engine and XCD (32 nres of 256) are kept clear of this kernel: the first
+        // workgroups to arrive on a shader engine name their own CUs (queue[8 + 3 (4 XCC_ID + SE_ID) + r]) and leave, and
+        // so does every later one that lands there.  Per shader engine, because the dispatcher deals the workgroups of a
+        // kernel to the shader engines in strict rotation and stalls on a full one: free CUs on a single engine admit one
+        // or two workgroups of the chain's kernels and the rest wait behind them (measured with in-kernel stamps,
+        // tools/potrf_stamps.py).
         if (threadIdx.x == 0) {
             const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));      // HW_ID[15:8]: CU_ID[3:0], SH_ID, SE_ID[2:0]
             const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;  // XCC_ID[3:0]
             const unsigned key = hw + 1;
-            const unsigned prev = atomicCAS(&queue[8 + 4 * xcc + ((hw >> 5) & 3)], 0u, key);
-            unsigned leave = (prev == 0u || prev == key) ? 1u : 0u;
-            // Progress does not depend on where the dispatcher puts workgroups: at most 16 of the 65 of a tile class
-            // may leave.  (With other contexts' kernels on the chip the only free room can be the units those kernels
+            unsigned *claims = queue + 8 + 3 * (4 * xcc + ((hw >> 5) & 3));
+            unsigned leave = 0;
+            for (int r = 0; r < nres && !leave; ++r) {
+                const unsigned prev = atomicCAS(&claims[r], 0u, key);
+                leave = (prev == 0u || prev == key) ? 1u : 0u;
+            }
+            // Progress does not depend on where the dispatcher puts workgroups: at most 8 nres + 8 of the 65 of a tile
+            // class may leave.  (With other contexts' kernels on the chip the only free room can be the units those kernels
             // keep clear; without the cap every workgroup of this one could land there and leave, and no tile be done.)
-            if (leave && atomicAdd(&queue[40 + xcd], 1u) >= 16u) leave = 0u;
+            if (leave && atomicAdd(&queue[104 + xcd], 1u) >= 8u * (unsigned)nres + 8u) leave = 0u;
             s_slot = leave;
         }
         __syncthreads();
@@ -486,6 +491,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     // The update after pair (k, k+1) is split into the 4 tile columns the NEXT pair lives in (U2a) and the rest
     // (U2b); the next pair is factored on a high-priority side stream while U2b keeps the chip busy.
     static const int queue_t = [] { const char *e = getenv("TGP_QUEUE_T"); return e ? atoi(e) : 64; }();
+    static const int queue_res = [] { const char *e = getenv("TGP_QUEUE_RES"); return e ? atoi(e) : 0; }();
     static const int small_t_pairs = [] { const char *e = getenv("TGP_SMALL_T"); return e ? atoi(e) : 8; }();
     int nqueue = 0;
     if (Np / TGP_TB - 8 > small_t_pairs)      // some step can take the queued form (T3 = Np/128 - 8 at the first pair)
@@ -525,8 +531,21 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
                 const int64_t skip = (int64_t)4 * TGP_TB * TGP_PW;
                 int rc = timed([&] {
                     if (queued) {
-                        // the grid covers every workgroup slot, so the chain finds room on the reserved units only
-                        syrk_dtv_queue_kernel<2><<<512 + 8, 256, 0, st>>>(d_A, Np, k + 4, T3, (unsigned)(tilemap_grid(T3) / 8),
+                        // The grid covers every workgroup slot, so the chain finds room on the clear units only.  How many
+                        // of them (1 .. 3 per shader engine = 32 .. 96 CUs): as many as leave the bulk -- tiles x ~130 us
+                        // over the remaining slots -- shorter than the chain (~400 us per pair of panels): with 64 CUs
+                        // the panel GEMMs run one workgroup per CU (22 instead of 40 us) and the strips in one round
+                        int nres = 1;
+                        if (queue_res > 0) {
+                            nres = queue_res > 3 ? 3 : queue_res;
+                        } else {
+                            const int64_t tiles = (int64_t)T3 * (T3 + 1) / 2;
+                            for (int r = 3; r > 1; --r) {
+                                const int64_t slots = 512 - 64 * r;
+                                if ((tiles + slots - 1) / slots * 130 <= 400) { nres = r; break; }
+                            }
+                        }
+                        syrk_dtv_queue_kernel<2><<<512 + 8, 256, 0, st>>>(d_A, Np, k + 4, T3, (unsigned)(tilemap_grid(T3) / 8), nres,
                                                                        ctx->d_queue + TGP_QUEUE_WORDS * nqueue, P0 + skip, P1 + skip);
                         ++nqueue;
                     } else {

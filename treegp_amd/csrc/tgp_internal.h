@@ -17,7 +17,7 @@
 #define TGP_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
 #endif
 
-#define TGP_QUEUE_WORDS 48     // per launch: 8 XCD-class tile counters + 8 x 4 reserved-CU words + 8 leave counters
+#define TGP_QUEUE_WORDS 112    // per launch: 8 XCD-class tile counters + 8 x 4 x 3 clear-CU words + 8 leave counters
 #define TGP_NQUEUE 128        // persistent bulk-update launches per factorisation (one set of 8 counters each)
 #define TGP_TB 128            // tile / diagonal-block size
 #define TGP_PW 256            // panel width = trailing-update depth
