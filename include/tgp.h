@@ -70,6 +70,10 @@ int tgp_device_count(void);
 int tgp_last_timings(tgp_ctx *ctx, double *ms, int n);
 /* when on (default off) the Cholesky brackets every trailing-update launch with events */
 int tgp_set_profiling(tgp_ctx *ctx, int on);
+/* 0: the factorisation of this context stays on its one stream (no look-ahead on the side stream).  For contexts
+ * that run side by side -- e.g. the independent likelihood evaluations of one finite-difference gradient
+ * (treegp/log_likelihood.py:57 lets SciPy take them one after the other): hardware queues are few.          */
+int tgp_set_lookahead(tgp_ctx *ctx, int on);
 
 /* ---- S1: kernel matrix (host buffers) --------------------------------------------------
  * out (n, m) row-major = amp * k(X_i, Y_j).  Y == NULL: self kernel, out is (n, n) and the

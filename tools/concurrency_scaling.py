@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Throughput of K concurrent likelihood evaluations (one context / thread each, data resident) vs K.
+usage: concurrency_scaling.py [N=1024] [single]   (single: tgp_set_lookahead(ctx, 0) on every context)"""
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+from treegp_amd import _lib, ops  # noqa: E402
+from treegp_amd.synthetic import star_field, headline_invlam  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+iL = headline_invlam()
+spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=iL[0, 0], b=iL[0, 1], c=iL[1, 1])
+X, y, ye, _ = star_field(n, 16)
+prob = ops.ResidentProblem(X, y - y.mean(), ye)
+ctxs = [_lib.new_ctx(0) for _ in range(8)]
+if len(sys.argv) > 2 and sys.argv[2] == "single":
+    for c in ctxs:
+        _lib.load_library().tgp_set_lookahead(c, 0)
+reps = 40
+
+
+def loop(i):
+    for _ in range(reps):
+        ops.gp_solve_resident(spec, prob, ctx=ctxs[i])
+
+
+for K in (1, 2, 3, 4, 6, 8):
+    with ThreadPoolExecutor(K) as pool:
+        list(pool.map(loop, range(K)))
+        t0 = time.perf_counter()
+        list(pool.map(loop, range(K)))
+        dt = time.perf_counter() - t0
+    print("N=%d  K=%d concurrent contexts: %.3f ms per evaluation overall (%.0f evaluations/s)" % (n, K, dt / (K * reps) * 1e3, K * reps / dt), flush=True)

@@ -34,6 +34,7 @@ SIGNATURES = {
     "tgp_device_count": (C.c_int, []),
     "tgp_last_timings": (C.c_int, [_vp, _dp, C.c_int]),
     "tgp_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "tgp_set_lookahead": (C.c_int, [_vp, C.c_int]),
     "tgp_kernel_matrix": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _i64, _vp]),
     "tgp_gp_solve": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp, _vp, _dp, _dp, C.POINTER(_vp)]),
     "tgp_factor_free": (None, [_vp, _vp]),

@@ -146,6 +146,12 @@ int tgp_last_timings(tgp_ctx *ctx, double *ms, int n) {
     return 0;
 }
 
+int tgp_set_lookahead(tgp_ctx *ctx, int on) {
+    if (!ctx) return -1;
+    ctx->lookahead = on ? 1 : 0;
+    return 0;
+}
+
 int tgp_set_profiling(tgp_ctx *ctx, int on) {
     if (!ctx) return -1;
     ctx->profiling = on;

@@ -31,6 +31,7 @@ struct tgp_ctx {
     std::string err;
     double timings[TGP_NTIMINGS] = {0};
     int profiling = 0;
+    int lookahead = 1;                 // 0: factorise on the one stream (tgp_set_lookahead; for contexts that run side by side)
     hipEvent_t ev[8] = {nullptr};
     // grow-only scratch
     void *scratch = nullptr;

@@ -30,7 +30,9 @@ _ctx_pool = []                   # extra contexts (one stream each) for concurre
 def _contexts(count):
     with _pool_lock:
         while len(_ctx_pool) < count:
-            _ctx_pool.append(_lib.new_ctx(int(os.environ.get("TGP_DEVICE", os.environ.get("LOCAL_RANK", "0")))))
+            ctx = _lib.new_ctx(int(os.environ.get("TGP_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+            _lib.load_library().tgp_set_lookahead(ctx, 0)     # side by side: one stream each (hardware queues are few)
+            _ctx_pool.append(ctx)
         return _ctx_pool[:count]
 
 
