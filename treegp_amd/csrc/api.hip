@@ -44,6 +44,17 @@ int tgp_ensure_scratch(tgp_ctx *ctx, size_t bytes) {
     return 0;
 }
 
+// the look-ahead stream is created on first use: contexts that never factorise with look-ahead (small problems,
+// tgp_set_lookahead(ctx, 0), contexts whose stream is set by the caller and only carry kernels) do not take a slot in
+// the runtime's rotation of streams over its few hardware queues
+int tgp_ensure_side_stream(tgp_ctx *ctx) {
+    if (ctx->side_stream) return 0;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    TGP_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
+    return 0;
+}
+
 int tgp_ensure_scratch2(tgp_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->scratch2_bytes) return 0;
     if (ctx->scratch2) TGP_HIP(hipFree(ctx->scratch2));
@@ -98,11 +109,6 @@ int tgp_init(const int *devices, int ndev, tgp_ctx **out) {
     if (hipSetDevice(ctx->device) != hipSuccess) { delete ctx; return -2; }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return -2; }
     ctx->stream = ctx->own_stream;
-    {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi) != hipSuccess) { delete ctx; return -2; }
-    }
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_info, 256) != hipSuccess) { delete ctx; return -2; }

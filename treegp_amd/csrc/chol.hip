@@ -461,6 +461,10 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     // one stream each: the runtime has 4 hardware queues, and with two streams per context three contexts already share
     // queues and serialise (6 contexts at N = 1024: 0.60 ms per evaluation with look-ahead, 0.22 ms without).
     const int mode = mode_env >= 0 ? mode_env : (!ctx->lookahead ? 1 : (Np >= 28672 ? 3 : (Np <= 2048 ? 1 : 2)));
+    if (mode >= 2) {
+        int rc = tgp_ensure_side_stream(ctx);
+        if (rc) return rc;
+    }
     static const bool want_stamps = getenv("TGP_SYRK_STAMPS") != nullptr;      // development diagnostics
     double flops = 0.0;
     int nlaunch = 0;

@@ -116,6 +116,7 @@ __host__ __device__ inline void tilemap(int64_t b, int64_t T, int &ti, int &tj) 
 }
 
 // implemented across the .hip files
+int tgp_ensure_side_stream(tgp_ctx *ctx);
 int tgp_ensure_scratch(tgp_ctx *ctx, size_t bytes);
 int tgp_ensure_scratch2(tgp_ctx *ctx, size_t bytes);
 int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,
