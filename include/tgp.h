@@ -84,8 +84,8 @@ int tgp_kernel_matrix(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_
 /* ---- S2: alpha = (K + diag(yerr^2))^-1 y, logdet = sum 2 log diag(chol) ------------------
  * K never leaves the device.  keep != NULL receives a handle on the device-resident factor
  * (free with tgp_factor_free).  alpha may be NULL (log-likelihood only needs y.alpha, which
- * is returned in *ydota when ydota != NULL; it is then computed as |L^-1 y|^2 from the
- * forward sweep alone).                                                                    */
+ * is returned in *ydota when ydota != NULL; it is then computed as |L^-1 y|^2, with y carried
+ * through the factorisation as an extra row of the matrix, or from the forward sweep alone).  */
 int tgp_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n,
                  const double *y, const double *yerr, double *alpha, double *logdet,
                  double *ydota, tgp_factor **keep);

@@ -145,7 +145,7 @@ def test_golden_config1_and_aniso2d(tg, golden):
                                  {"TGP_CHOL_MODE": "0"}, {"TGP_CHOL_MODE": "1"}, {"TGP_CHOL_MODE": "2"},
                                  {"TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "0"}, {"TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "8"},
                                  {"TGP_CHOL_MODE": "3", "TGP_SMALL_T": "0", "TGP_SMALL_ROWS": "0"}, {"TGP_PREDICT_GENERIC": "1"},
-                                 {"TGP_QUEUE_T": "0"}, {"TGP_STRIP64_T": "0"}, {"TGP_QUEUE_T": "200", "TGP_HEAD_START": "1"}])
+                                 {"TGP_QUEUE_T": "0"}, {"TGP_STRIP64_T": "0"}, {"TGP_NO_AUGMENT": "1"}, {"TGP_QUEUE_T": "200", "TGP_HEAD_START": "1"}])
 def test_alternative_kernel_paths_agree(env):
     """The A/B switches kept in the library (older tiles, schedules and diagonal-block kernels) must stay correct:
     each one solves and predicts the same problem in a fresh process (the switches are read once per process)."""
@@ -197,3 +197,20 @@ def test_concurrent_contexts_agree_with_single_solves():
             got = list(pool.map(lambda i: ops.gp_solve(specs[i], X, y, ye, want_alpha=False, ctx=ctxs[i])[1:3], range(K)))
             for g, r in zip(got, ref):
                 np.testing.assert_allclose(g, r, rtol=1e-11)
+
+
+@pytest.mark.parametrize("n", [100, 255, 257, 700, 2049, 3000])
+def test_likelihood_only_solve_matches_full_solve(tg, n):
+    """Without alpha (and n not a multiple of 256) y rides through the factorisation as an extra matrix row and the
+    quadratic form is read off that row -- no triangular sweep.  Same numbers as the full solve and as the oracle."""
+    from treegp_amd import _lib, ops
+    rng = np.random.default_rng(n)
+    X = rng.uniform(0, 1, (n, 2)); y = rng.standard_normal(n) * 3.0 + 0.5; e = rng.uniform(0.05, 0.15, n)
+    spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.7, a=80.0, b=10.0, c=60.0)
+    alpha, logdet, ydota, _ = ops.gp_solve(spec, X, y, e)
+    _, logdet2, chi2, _ = ops.gp_solve(spec, X, y, e, want_alpha=False)
+    np.testing.assert_allclose(chi2, ydota, rtol=1e-11)
+    np.testing.assert_allclose(logdet2, logdet, rtol=1e-13)
+    a_ref, ld_ref = O.gp_solve(O.kernel_matrix("gauss", X, amp=1.7, a=80.0, b=10.0, c=60.0), y, e)
+    np.testing.assert_allclose(chi2, float(y @ a_ref), rtol=1e-10)
+    np.testing.assert_allclose(logdet2, ld_ref, rtol=1e-11)

@@ -272,13 +272,25 @@ int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t
     TGP_HIP(hipEventRecord(ctx->ev[0], st));
     rc = launch_kbuild_lower(ctx, k, d_X, n, Np, d_yerr, d_A);
     if (rc) return rc;
+    // Likelihood only (no alpha, factor not kept) and a padding row to spare: y rides along as row Np-1 of the matrix and
+    // comes out of the factorisation as L^-1 y -- no triangular sweep (trsv.hip: augment_rhs_kernel)
+    static const bool no_augment = getenv("TGP_NO_AUGMENT") != nullptr || getenv("TGP_CHI2_BOTH_SWEEPS") != nullptr;
+    const bool augmented = !no_augment && d_alpha == nullptr && keep == nullptr && n < Np;
+    if (augmented) {
+        rc = launch_augment_rhs(ctx, d_A, Np, n, d_y);
+        if (rc) return rc;
+    }
     TGP_HIP(hipEventRecord(ctx->ev[1], st));
     // The solves are queued behind the factorisation without waiting for its verdict (one host round trip less per
     // likelihood evaluation); if a pivot failed they run on a meaningless factor and their result is discarded below.
     int info = launch_potrf(ctx, d_A, Np, d_W, /*defer_info=*/true);
     if (info < 0) return info;
     TGP_HIP(hipEventRecord(ctx->ev[2], st));
-    if (info == 0) {
+    if (info == 0 && augmented) {
+        rc = launch_logdet_rowsq(ctx, d_A, Np, n, ctx->d_scal);
+        if (rc) return rc;
+        TGP_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    } else if (info == 0) {
         rc = launch_pad_copy(ctx, d_y, n, Np, d_b);
         if (rc) return rc;
         // without alpha only the quadratic form is wanted: y^T K^-1 y = |L^-1 y|^2, the forward sweep alone

@@ -147,6 +147,38 @@ __global__ __launch_bounds__(1024) void logdet_dot_kernel(const double *__restri
     }
 }
 
+// The right-hand side as one more row of the matrix: row Np-1 (a padding row, n < Np) <- [y (n), 0 ..., 1e300].  The
+// factorisation then leaves L^-1 y in that row -- the panel solves and updates treat it like any other row below the
+// diagonal -- and a likelihood evaluation needs no triangular sweep at all.  The huge diagonal keeps the row's own pivot
+// positive whatever |L^-1 y|^2 is; nothing lies below or to the right of it, and the log-determinant stops at row n.
+__global__ void augment_rhs_kernel(double *__restrict__ A, int64_t Np, int64_t n, const double *__restrict__ y) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= Np) return;
+    const int64_t p = c >> 8, r = Np - 1;
+    A[panel_off(p, Np) + (r - p * TGP_PW) * TGP_PW + (c & 255)] = c < n ? y[c] : (c == r ? 1e300 : 0.0);
+}
+// out[0] = log det (rows < n), out[1] = |L[Np-1, 0:n]|^2
+__global__ __launch_bounds__(1024) void logdet_rowsq_kernel(const double *__restrict__ A, int64_t Np, int64_t n, double *out) {
+    __shared__ double part[2][16];
+    double s = 0.0, d = 0.0;
+    const int64_t r = Np - 1;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int64_t p = i >> 8;
+        s += 2.0 * log(A[panel_off(p, Np) + (i - p * TGP_PW) * TGP_PW + (i & 255)]);
+        const double z = A[panel_off(p, Np) + (r - p * TGP_PW) * TGP_PW + (i & 255)];
+        d += z * z;
+    }
+    s = wave_sum(s);
+    d = wave_sum(d);
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s; part[1][threadIdx.x >> 6] = d; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += part[threadIdx.x][k];
+        out[threadIdx.x] = t;
+    }
+}
+
 // b (Np) <- [y (n), 0 ...]: the padded right-hand side in one launch
 __global__ void pad_copy_kernel(const double *__restrict__ y, int64_t n, int64_t Np, double *__restrict__ b) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -387,6 +419,17 @@ int launch_logdet(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double
 
 int launch_logdet_dot(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, const double *d_a, const double *d_b, double *d_out) {
     logdet_dot_kernel<<<1, 1024, 0, ctx->stream>>>(d_A, Np, n, d_a, d_b, d_out);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_augment_rhs(tgp_ctx *ctx, double *d_A, int64_t Np, int64_t n, const double *d_y) {
+    augment_rhs_kernel<<<(unsigned)((Np + 255) / 256), 256, 0, ctx->stream>>>(d_A, Np, n, d_y);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+int launch_logdet_rowsq(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out) {
+    logdet_rowsq_kernel<<<1, 1024, 0, ctx->stream>>>(d_A, Np, n, d_out);
     TGP_HIP(hipGetLastError());
     return 0;
 }

@@ -8,7 +8,8 @@ ntheta + 1 evaluations one gradient needs are independent solves of a small prob
 most of the GPU idle one at a time: they are issued together, one context / stream per evaluation
 (``parallel_fd``; 2-2.5x on a fit at N = 512 ... 8192).  Same optimiser, same formula, same iterates.
 During a fit the data stay on the device (``ops.ResidentProblem``): an evaluation sends the kernel parameters and gets
-two scalars back; the quadratic form is |L^-1 y|^2, i.e. the forward triangular sweep alone.
+two scalars back; the quadratic form is |L^-1 y|^2, with y carried through the factorisation as an extra matrix row
+(no triangular sweep; the forward sweep alone when n is a multiple of 256).
 """
 import copy
 import os
