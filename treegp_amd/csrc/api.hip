@@ -283,7 +283,7 @@ int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t
     TGP_HIP(hipEventRecord(ctx->ev[1], st));
     // The solves are queued behind the factorisation without waiting for its verdict (one host round trip less per
     // likelihood evaluation); if a pivot failed they run on a meaningless factor and their result is discarded below.
-    int info = launch_potrf(ctx, d_A, Np, d_W, /*defer_info=*/true);
+    int info = launch_potrf(ctx, d_A, Np, d_W, /*defer_info=*/true, /*n_data=*/n);
     if (info < 0) return info;
     TGP_HIP(hipEventRecord(ctx->ev[2], st));
     if (info == 0 && augmented) {

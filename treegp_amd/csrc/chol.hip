@@ -376,13 +376,26 @@ inline void run_potrf128(hipStream_t st, double *A, int lda, double *W, int *inf
 
 namespace {
 // factor one 256-wide panel: the two 128x128 diagonal blocks (L + inverse) and the rows below them
-void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_info, int base, bool exclusive = false) {
+__global__ void set_identity128_kernel(double *__restrict__ W) {
+    const int t = blockIdx.x * 256 + threadIdx.x;          // 64 x 256 threads: one element each
+    W[t] = (t >> 7) == (t & 127) ? 1.0 : 0.0;
+}
+
+// `n_data` (>= 0): order of the matrix before padding.  When the second 128-block of a panel lies entirely in the padding
+// (possible for the last panel only) it is the identity and its own factor: no potrf128, no update of it, W1 = I.
+void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_info, int base, bool exclusive = false,
+                  int64_t n_data = -1) {
     double *W1 = W0 + TGP_TB * TGP_TB;
     double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
     const int r1 = (int)((mk - TGP_TB) / TGP_TB);
     // few row blocks: 16-row slices spread a block over 8 workgroups (latency); many: 128-row tiles (throughput)
     static const int small_rows = [] { const char *e = getenv("TGP_SMALL_ROWS"); return e ? atoi(e) : 40; }();
     run_potrf128(st, Pk, TGP_PW, W0, d_info, base, exclusive);
+    if (n_data >= 0 && (int64_t)base + TGP_TB >= n_data && mk == TGP_PW) {
+        gemm_col_small_kernel<0, TGP_TB><<<8, 256, 0, st>>>(R1, W0, R1);      // rows 128..255: zero, or the right-hand side row
+        set_identity128_kernel<<<64, 256, 0, st>>>(W1);
+        return;
+    }
     if (r1 <= small_rows) {
         gemm_col_small_kernel<0, TGP_TB><<<r1 * 8, 256, 0, st>>>(R1, W0, R1);
         gemm_col_small_kernel<1, TGP_PW><<<r1 * 8, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
@@ -440,7 +453,7 @@ void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int str
 // and the next group is factored on a high-priority side stream under the rest.
 // History at N=65536 (same tile): 1694 ms one panel at a time, 1571 pairs, 1551 pairs + look-ahead; with the DTV tile
 // 1423 ms pairs + look-ahead, 1362 ms fours + look-ahead (68.9 TF, 87.6 % of the fp64 MFMA peak).
-int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_info) {
+int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_info, int64_t n_data) {
     TGP_ARG(Np > 0 && Np % TGP_PW == 0);
     hipStream_t st = ctx->stream;
     TGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), st));
@@ -508,11 +521,11 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
         hipStream_t sd = ctx->side_stream;
         auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false) {       // F(k), U1(k), F(k+1)
             const int64_t mk = Np - (int64_t)TGP_PW * k;
-            factor_panel(s, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, exclusive);
+            factor_panel(s, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, exclusive, n_data);
             if (k + 1 >= nP) return;
             const int T1 = (int)((mk - TGP_PW) / TGP_TB);
             launch_syrk<1>(s, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
-            factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, exclusive);
+            factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, exclusive, n_data);
         };
         if (pairs_from_scratch) factor_pair(st, kstart);
         for (int k = kstart; k + 2 < nP; k += 2) {
@@ -569,7 +582,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     if (mode == 0) {
         for (int k = 0; k < nP; ++k) {
             const int64_t mk = Np - (int64_t)TGP_PW * k;
-            factor_panel(st, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW);
+            factor_panel(st, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, false, n_data);
             const int T = (int)((mk - TGP_PW) / TGP_TB);
             if (T > 0) {
                 const double m = (double)T * TGP_TB;
@@ -614,7 +627,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
         auto factor_group = [&](hipStream_t s, int k0) {
             for (int j = 0; j < 4 && k0 + j < nP; ++j) {
                 if (j > 0) strip_update(s, k0, j);
-                factor_panel(s, panel(k0 + j), Np - (int64_t)TGP_PW * (k0 + j), Wk(k0 + j), ctx->d_info, (k0 + j) * TGP_PW);
+                factor_panel(s, panel(k0 + j), Np - (int64_t)TGP_PW * (k0 + j), Wk(k0 + j), ctx->d_info, (k0 + j) * TGP_PW, false, n_data);
             }
         };
         auto bulk = [&](int k0, int ob, int T, int strip) {      // depth-1024 update from block `ob` on, T tile rows
@@ -671,12 +684,12 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     } else {
         for (int k = 0; k < nP; k += 2) {
             const int64_t mk = Np - (int64_t)TGP_PW * k;
-            factor_panel(st, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW);
+            factor_panel(st, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, false, n_data);
             if (k + 1 >= nP) break;
             const int T1 = (int)((mk - TGP_PW) / TGP_TB);
             // U1: only the two tile columns of panel k+1, depth 256 (short; not part of the timed set)
             launch_syrk<1>(st, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
-            factor_panel(st, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW);
+            factor_panel(st, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, false, n_data);
             const int T2 = T1 - 2;
             if (T2 > 0) {
                 const double m = (double)T2 * TGP_TB;
