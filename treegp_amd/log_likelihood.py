@@ -68,8 +68,14 @@ class log_likelihood(object):
         # X, y, y_err do not change during the fit: they go to the device once, every evaluation sends only theta
         resident = ops.ResidentProblem(self.X, self.y, self.y_err) if os.environ.get("TGP_ML_RESIDENT", "1") != "0" else None
 
-        def cost(theta, ctx=None):
-            return -self.log_likelihood(template.clone_with_theta(theta), ctx=ctx, resident=resident)
+        def cost(theta, ctx=None, work=None):
+            # `work`: a kernel object owned by this evaluation slot whose theta is set in place -- what clone_with_theta
+            # does after its (much slower) clone; the host side of an evaluation is otherwise mostly that clone
+            if work is None:
+                work = template.clone_with_theta(theta)
+            else:
+                work.theta = theta
+            return -self.log_likelihood(work, ctx=ctx, resident=resident)
 
         try:
             best = self._minimise(cost, template)
@@ -85,6 +91,7 @@ class log_likelihood(object):
         if self.parallel_fd:
             ntheta = len(template.theta)
             ctxs = _contexts(ntheta + 1)
+            works = [template.clone_with_theta(template.theta) for _ in range(ntheta + 1)]
             pool = ThreadPoolExecutor(max_workers=ntheta + 1)
 
             def cost_and_gradient(theta):
@@ -94,7 +101,7 @@ class log_likelihood(object):
                     shifted = points[0].copy()
                     shifted[i] = points[0][i] + _FD_STEP
                     points.append(shifted)
-                values = list(pool.map(cost, points, ctxs))
+                values = list(pool.map(cost, points, ctxs, works))
                 grad = np.array([(values[i + 1] - values[0]) / (points[i + 1][i] - points[0][i]) for i in range(ntheta)])
                 return values[0], grad
 
@@ -103,5 +110,6 @@ class log_likelihood(object):
             finally:
                 pool.shutdown()
         else:
-            best = optimize.minimize(cost, template.theta, method="L-BFGS-B")["x"]
+            work = template.clone_with_theta(template.theta)
+            best = optimize.minimize(lambda theta: cost(theta, None, work), template.theta, method="L-BFGS-B")["x"]
         return best
