@@ -283,8 +283,12 @@ class two_pcf(object):
         xi, xi_weight, distance, coord, mask = self.return_2pcf()
         origin = np.zeros((1, coord.shape[1]))      # the reference passes zeros_like(coord) and keeps column 0: same values
 
-        def model(theta, template=kernel):
-            return template.clone_with_theta(theta)(coord, Y=origin)[:, 0]
+        work = kernel.clone_with_theta(kernel.theta)     # one working copy: theta is set in place per evaluation, which is
+                                                          # what clone_with_theta does after its (much slower) clone
+
+        def model(theta):
+            work.theta = theta
+            return work(coord, Y=origin)[:, 0]
 
         def chi2(theta):
             r = xi[mask] - model(theta)[mask]
