@@ -194,7 +194,7 @@ def main():
                 traffic = json.load(open(pmc))["_derived"]["syrk_hbm_bytes_per_launch"]
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                               "kernel": ("syrk_segs_kernel<4>" if n >= 28672 else "syrk_dtv_kernel<4, 2>") if world == 1 else "syrk_distn_kernel (rank 0)",
+                               "kernel": ("syrk_segs_kernel<4>" if n >= 22528 else "syrk_dtv_kernel<4, 2>") if world == 1 else "syrk_distn_kernel (rank 0)",
                                "launches": int(acc["syrk_launches"]),
                                "avg_launch_ms": acc["syrk_ms"] / max(acc["syrk_launches"], 1)}
         if "chol_ms" in acc:
