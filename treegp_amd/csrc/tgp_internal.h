@@ -89,28 +89,38 @@ __host__ __device__ inline int64_t dist_panel_blocks(int64_t p, int64_t nB, int 
     return (fb < nB) ? (nB - 1 - fb) / G + 1 : 0;
 }
 
-// trailing-update tile enumeration (XCD-aware): see chol.hip
+// trailing-update tile enumeration (XCD-aware): see chol.hip.  Blocks b, b+8, ... share an XCD; an XCD works through
+// whole super-tiles of sup x sup tiles (shared operand rows stay in its L2).  Super-tiles are dealt to the XCDs in turn, so
+// the XCDs' shares differ by up to a super-tile or two: with 8 x 8 that is 0.3 % of a launch at T = 496 but 7 % at T = 100
+// and 25 % at T = 40 (measured by enumeration); below TGP_SUP4_BELOW tile rows the super-tiles are 4 x 4 (1 % at T = 100,
+// 3 % at T = 40), below 32 tile rows 2 x 2.
+#ifndef TGP_SUP4_BELOW
+#define TGP_SUP4_BELOW 192
+#endif
+__host__ __device__ inline int tilemap_sup_shift(int64_t T) { return T < 32 ? 1 : (T < TGP_SUP4_BELOW ? 2 : 3); }
 __host__ __device__ inline int64_t tilemap_grid(int64_t T) {
-    int64_t S = (T + 7) / 8;                 // super-tiles per side
+    const int sh = tilemap_sup_shift(T);
+    int64_t S = (T + (1 << sh) - 1) >> sh;   // super-tiles per side
     int64_t ns = S * (S + 1) / 2;            // lower-triangular super-tiles
-    return ((ns + 7) / 8) * 8 * 64;
+    return ((ns + 7) / 8) * 8 * ((int64_t)1 << (2 * sh));
 }
 // block id -> (ti, tj), or ti = -1 when the slot is empty
 __host__ __device__ inline void tilemap(int64_t b, int64_t T, int &ti, int &tj) {
-    int64_t S = (T + 7) / 8;
+    const int sh = tilemap_sup_shift(T);
+    int64_t S = (T + (1 << sh) - 1) >> sh;
     int64_t ns = S * (S + 1) / 2;
     int xcd = (int)(b & 7);                  // blocks b, b+8, ... share an XCD (speed only)
     int64_t slot = b >> 3;
-    int64_t st = (slot >> 6) * 8 + xcd;      // super-tile handled by this XCD group
-    int within = (int)(slot & 63);
+    int64_t st = (slot >> (2 * sh)) * 8 + xcd;      // super-tile handled by this XCD group
+    int within = (int)(slot & ((1 << (2 * sh)) - 1));
     if (st >= ns) { ti = -1; tj = -1; return; }
     // st -> (Si, Sj), Sj <= Si, row-major triangular enumeration
     int64_t Si = (int64_t)((sqrt(8.0 * (double)st + 1.0) - 1.0) * 0.5);
     while (Si * (Si + 1) / 2 > st) --Si;
     while ((Si + 1) * (Si + 2) / 2 <= st) ++Si;
     int64_t Sj = st - Si * (Si + 1) / 2;
-    int i = (int)(Si * 8 + (within >> 3));
-    int j = (int)(Sj * 8 + (within & 7));
+    int i = (int)((Si << sh) + (within >> sh));
+    int j = (int)((Sj << sh) + (within & ((1 << sh) - 1)));
     if (j > i || i >= T) { ti = -1; tj = -1; return; }
     ti = i; tj = j;
 }
