@@ -90,7 +90,17 @@ class NumpyLocalOps(object):
     def keep_diag(self, k):
         self.Lfull[k * BLK:(k + 1) * BLK, k * BLK:(k + 1) * BLK] = np.tril(self.bcast[:BLK * BLK].numpy().reshape(BLK, BLK))
 
-    def keep_rows(self, k, gathered, cmax):
+    def keeps_done(self):
+        return None
+
+    def side_wait_keeps(self, ev):
+        pass
+
+    def main_wait_keeps(self):
+        pass
+
+    def keep_rows(self, k, gathered, cmax, handle):
+        handle.wait()
         P = gathered.numpy()
         for b in range(k + 1, self.nB):
             r = b % self.G

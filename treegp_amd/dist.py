@@ -151,6 +151,11 @@ class HipLocalOps(object):
         self.side_stream = torch.cuda.Stream(device=device, priority=-1)
         self.ctx_side = _lib.new_ctx(device.index if device.index is not None else 0)
         self.lib.tgp_set_stream(self.ctx_side, C.c_void_p(self.side_stream.cuda_stream))
+        # a third stream (own context) for the copies that build the replicated factor: they only need a gather to have
+        # landed and its buffer not to be reused yet -- off the panel chain, where they cost up to 0.3 ms per panel
+        self.keep_stream = torch.cuda.Stream(device=device)
+        self.ctx_keep = _lib.new_ctx(device.index if device.index is not None else 0)
+        self.lib.tgp_set_stream(self.ctx_keep, C.c_void_p(self.keep_stream.cuda_stream))
         # replicated factor for the solves: every panel is seen by every rank anyway (broadcast + all-gather); kept
         # in the single-GPU packed layout it lets the triangular sweeps run locally, without their 2 N/256 collectives
         self.Afull = None
@@ -239,9 +244,23 @@ class HipLocalOps(object):
         self._chk(self.lib.tgp_dd_keep_panel(self.ctx_side, self._p(self.Afull), self.Np, k, self.G, self._p(self.bcast),
                                              None, 0), "tgp_dd_keep_panel", self.ctx_side)
 
-    def keep_rows(self, k, gathered, cmax):   # side stream, after the all-gather of panel k
-        self._chk(self.lib.tgp_dd_keep_panel(self.ctx_side, self._p(self.Afull), self.Np, k, self.G, None,
-                                             self._p(gathered), cmax), "tgp_dd_keep_panel", self.ctx_side)
+    def keep_rows(self, k, gathered, cmax, handle):   # keep stream, once the all-gather of panel k (`handle`) has landed
+        with self.torch.cuda.stream(self.keep_stream):
+            handle.wait()
+            self._chk(self.lib.tgp_dd_keep_panel(self.ctx_keep, self._p(self.Afull), self.Np, k, self.G, None,
+                                                 self._p(gathered), cmax), "tgp_dd_keep_panel", self.ctx_keep)
+
+    def keeps_done(self):                  # an event after everything queued on the keep stream so far
+        ev = self.torch.cuda.Event()
+        ev.record(self.keep_stream)
+        return ev
+
+    def side_wait_keeps(self, ev):         # the side stream may reuse a gather buffer only after its keeps
+        if ev is not None:
+            self.side_stream.wait_event(ev)
+
+    def main_wait_keeps(self):
+        self.main_stream.wait_stream(self.keep_stream)
 
     def potrs_full(self, rhs):             # main stream: rhs (Np) <- L^-T L^-1 rhs with the replicated factor
         self._chk(self.lib.tgp_d_potrs(self.ctx, self._p(self.Afull), self._p(self.W), self.Np, self._p(rhs)), "tgp_d_potrs")
@@ -335,17 +354,12 @@ class DistributedCholesky(object):
             send = ops.panel_send_view(k, cmax)
             return comm.all_gather_start(buf[:G * cmax * BLK * BLK], send), cmax
 
-        pending = []                                             # gathered panels not yet copied into the replicated factor
-
-        def flush_keeps():
-            while pending:
-                w, kk, buf, cc = pending.pop(0)
-                w.wait()                                         # side stream: that gather has landed
-                ops.keep_rows(kk, buf, cc)
+        keep_events = {}                                         # id(first buffer of a set) -> event after that set's keeps
 
         def side_group(k, bufs):
             """panels k .. k+GS-1 (those that exist) on the side stream; returns [(gather handle, cmax)] per panel"""
-            flush_keeps()
+            if keep:
+                ops.side_wait_keeps(keep_events.pop(id(bufs[0]), None))     # these buffers were last read two groups ago
             out = []
             for j in range(GS):
                 if k + j >= nB:
@@ -353,13 +367,13 @@ class DistributedCholesky(object):
                 if j > 0:
                     w, c = out[j - 1]
                     w.wait()                                     # side stream: panel k+j-1 is on every rank
-                    if keep:
-                        ops.keep_rows(k + j - 1, bufs[j - 1], c)
                     # panel k+j's two tile columns against the j panels before it, one launch of depth 256 j
                     ops.update_group(k, bufs[:j], [oc for _, oc in out], 0, 2, side=True)
                 out.append(factor_and_gather(k + j, bufs[j]))
-            if keep and out and out[-1][0] is not None:
-                pending.append((out[-1][0], k + len(out) - 1, bufs[len(out) - 1], out[-1][1]))   # copied by the next chain
+                if keep and out[-1][0] is not None:
+                    ops.keep_rows(k + j, bufs[j], out[-1][1], out[-1][0])   # copied on the keep stream, off this chain
+            if keep:
+                keep_events[id(bufs[0])] = ops.keeps_done()
             return out
 
         def timed(fn):
@@ -390,10 +404,9 @@ class DistributedCholesky(object):
             self.update_flops += GS * self._local_update_flops(k + GS - 1)
             self.update_launches += 2
             cur_w, k, flip = nxt_w, k + GS, 1 - flip
-        if pending:
-            with ops.on_side():
-                flush_keeps()
         ops.main_wait_side()                                     # the last chain has no gather to wait on
+        if keep:
+            ops.main_wait_keeps()                                # the replicated factor is complete before the solves
         # any rank's failure is everybody's failure; report the smallest failing index
         big = 1e18
         mine = ops.info()                                        # synchronises the stream
