@@ -51,6 +51,21 @@ __global__ __launch_bounds__(256) void gemm_col_small_kernel(const double *A, co
     TGP_CHAIN_PRIO();
     nt_small_tile<MODE, TGP_TB, 1>(A + o, TGP_PW, B, LDB, C + o, TGP_PW, nullptr, nullptr);
 }
+// Rows below a factored 256 x 256 diagonal block, all three steps of their solve in one launch: X0 = R0 W0^T,
+// R1 -= X0 L10^T, X1 = R1 W1^T (R0 | R1 = the two 128-column halves of the rows, L10 = rows 128..255 of the block's first
+// half, W0 / W1 the inverted 128-blocks).  A row tile depends on nothing but itself and the diagonal block.  Used by the
+// multi-GPU panel chain (tgp_dd_trsm), where every launch beside the bulk update waits for workgroup slots: one wait
+// instead of three.  (On one GPU the same fusion did not pay: same number of launches on the chain, see DESIGN.)
+__global__ __launch_bounds__(256, 2) void panel_tall_kernel(double *rows0, const double *W0, const double *L10, const double *W1) {
+    double *rows = rows0 + (int64_t)blockIdx.x * 128 * TGP_PW;
+    TGP_CHAIN_PRIO();
+    gemm_tile_128<0, TGP_TB, TGP_TB>(rows, W0, rows);
+    __syncthreads();
+    gemm_tile_128<1, TGP_PW, TGP_TB>(rows, L10, rows + TGP_TB);
+    __syncthreads();
+    gemm_tile_128<0, TGP_TB, TGP_TB>(rows + TGP_TB, W1, rows + TGP_TB);
+}
+
 template <int NSEG>
 __global__ __launch_bounds__(256) void syrk_small_kernel(double *Abase, int64_t Np, int ob, int T, const double *P0,
                                                          const double *P1) {
@@ -751,9 +766,14 @@ int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int
 int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, const double *W0, const double *W1) {
     if (ntiles <= 0) return 0;
     hipStream_t st = ctx->stream;
-    gemm_col_kernel<0, TGP_TB><<<ntiles, 256, 0, st>>>(rows, W0, rows);
-    gemm_col_kernel<1, TGP_PW><<<ntiles, 256, 0, st>>>(rows, Lkk + (int64_t)TGP_TB * TGP_PW, rows + TGP_TB);
-    gemm_col_kernel<0, TGP_TB><<<ntiles, 256, 0, st>>>(rows + TGP_TB, W1, rows + TGP_TB);
+    static const bool unfused = getenv("TGP_DIST_TRSM_UNFUSED") != nullptr;      // A/B: three launches
+    if (!unfused) {
+        panel_tall_kernel<<<ntiles, 256, 0, st>>>(rows, W0, Lkk + (int64_t)TGP_TB * TGP_PW, W1);
+    } else {
+        gemm_col_kernel<0, TGP_TB><<<ntiles, 256, 0, st>>>(rows, W0, rows);
+        gemm_col_kernel<1, TGP_PW><<<ntiles, 256, 0, st>>>(rows, Lkk + (int64_t)TGP_TB * TGP_PW, rows + TGP_TB);
+        gemm_col_kernel<0, TGP_TB><<<ntiles, 256, 0, st>>>(rows + TGP_TB, W1, rows + TGP_TB);
+    }
     TGP_HIP(hipGetLastError());
     return 0;
 }

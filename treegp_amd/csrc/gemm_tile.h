@@ -219,6 +219,12 @@ __device__ __forceinline__ void gemm_tile_128_dma(const double *a_ptr, const dou
 // depth-512 trailing update after two factored panels), one chunk pipeline across both.
 // NSEG = 0: run-time number of segments `nseg_rt`, segment s at a_ptr + s * seg_stride_a (and likewise
 // for B) -- the posterior-covariance product over all panels of the factor.
+template <int LS>
+__device__ __forceinline__ double *tile128_lds_storage() {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * 128 * LS];
+    return lds;
+}
+
 template <int MODE, int LDB, int KDEPTH, typename CFG = TileDefault, int NSEG = 1>
 __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double *b_ptr, double *c_ptr,
                                               unsigned long long *stamps = nullptr, const double *a1_ptr = nullptr,
@@ -233,7 +239,8 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
     constexpr int LDA = TGP_PW, LDC = TGP_PW;
     constexpr int LS = CFG::LS;
     constexpr bool PRELOAD = CFG::PRELOAD && MODE == 1;
-    __shared__ __attribute__((aligned(16))) double lds[2][2][CFG::DMA ? 2 : 128 * LS];   // [buf][A|B][row*LS + k]
+    // [buf][A|B][row*LS + k]; one array per LS, shared by every MODE / LDB instantiation a kernel calls in sequence
+    double (*lds)[2][128 * LS] = reinterpret_cast<double (*)[2][128 * LS]>(tile128_lds_storage<LS>());
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
