@@ -66,6 +66,15 @@ __global__ __launch_bounds__(256, 2) void panel_tall_kernel(double *rows0, const
     gemm_tile_128<0, TGP_TB, TGP_TB>(rows + TGP_TB, W1, rows + TGP_TB);
 }
 
+// rows 128..255 of a 256 x 256 diagonal block between its two potrf128 calls, one workgroup, one launch:
+// L10 = A10 W0^T, then A11 -= L10 L10^T
+__global__ __launch_bounds__(256, 2) void diag_mid_kernel(double *R1, const double *W0) {
+    TGP_CHAIN_PRIO();
+    gemm_tile_128<0, TGP_TB, TGP_TB>(R1, W0, R1);
+    __syncthreads();
+    gemm_tile_128<1, TGP_PW, TGP_TB>(R1, R1, R1 + TGP_TB);
+}
+
 template <int NSEG>
 __global__ __launch_bounds__(256) void syrk_small_kernel(double *Abase, int64_t Np, int ob, int T, const double *P0,
                                                          const double *P1) {
@@ -754,9 +763,14 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
 int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base) {
     hipStream_t st = ctx->stream;
     double *R1 = blk + (int64_t)TGP_TB * TGP_PW;
+    static const bool unfused = getenv("TGP_DIST_TRSM_UNFUSED") != nullptr;
     run_potrf128(st, blk, TGP_PW, W0, ctx->d_info, base);
-    gemm_col_kernel<0, TGP_TB><<<1, 256, 0, st>>>(R1, W0, R1);
-    gemm_col_kernel<1, TGP_PW><<<1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
+    if (!unfused) {
+        diag_mid_kernel<<<1, 256, 0, st>>>(R1, W0);
+    } else {
+        gemm_col_kernel<0, TGP_TB><<<1, 256, 0, st>>>(R1, W0, R1);
+        gemm_col_kernel<1, TGP_PW><<<1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
+    }
     run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, ctx->d_info, base + TGP_TB);
     TGP_HIP(hipGetLastError());
     return 0;
