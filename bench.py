@@ -30,42 +30,101 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix peak
 
 
-def cpu_baseline(n_s, m_s):
-    """The reference's own SciPy call sequence on the host cores, on a bounded sample."""
+def cpu_baseline(n_s, m_s, n_headline):
+    """The reference's own SciPy call sequence (oracle/cpu_reference_path.py) on the host cores, protocol of
+    BASELINE.md section 3: BLAS threads = the fastest of {cgroup quota, physical cores, half, quarter, 16, 32}
+    on a dpotrf probe, 1 warm-up + 5 timed passes (3 if the time budget is spent), median per phase; sample =
+    configs[1] in full (N=8192 / M=32768).  `extrapolated_n65536` scales the measured phases to the headline size
+    (dpotrf by N^3, pair loops by N^2 and M N) and is labelled as such."""
     from oracle import cpu_reference_path as R
     from treegp_amd.synthetic import star_field, headline_invlam
     X, y, y_err, Xs = star_field(n_s, m_s)
     iL = headline_invlam()
-    tm = {}
-    R.solve_predict(X, y - y.mean(), y_err, Xs, iL, 1.0, timings=tm)       # single pass, first touch included
-    threads = os.cpu_count()
+    host = R.host_cpus()
+    phys = host["physical"] or host["logical"]
+    cand = {phys, max(phys // 2, 1), max(phys // 4, 1), 16, 32}
+    if host["cgroup_quota"]:
+        cand.add(max(int(round(host["cgroup_quota"])), 1))
+    cand = sorted(c for c in cand if 1 <= c <= host["logical"])
+    threads, probe = R.pick_blas_threads(cand)
+    med, npass = R.timed_passes(X, y - y.mean(), y_err, Xs, iL, 1.0, threads)
     blas = "unknown BLAS"
     try:
         from threadpoolctl import threadpool_info
-        pools = threadpool_info()
-        threads = max([p.get("num_threads", 1) for p in pools] + [1])
-        blas = ", ".join(sorted({"%s %s" % (p.get("internal_api", "?"), p.get("version", "")) for p in pools
+        blas = ", ".join(sorted({"%s %s" % (p.get("internal_api", "?"), p.get("version", "")) for p in threadpool_info()
                                  if p.get("user_api") == "blas"})) or blas
     except Exception:
         pass
-    cpu = "unknown CPU"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu = line.split(":", 1)[1].strip()
-                break
-    except Exception:
-        pass
+    gf = n_s ** 3 / 3 / med["cholesky"] / 1e9
+    r3, r2 = (n_headline / n_s) ** 3, (n_headline / n_s) ** 2
+    m_h = 4 * n_headline
+    ext = {"kbuild": med["kbuild"] * r2, "cholesky": med["cholesky"] * r3, "cho_solve": med["cho_solve"] * r2,
+           "cross_kernel": med["cross_kernel"] * (m_h * n_headline) / (m_s * n_s),
+           "matvec": med["matvec"] * (m_h * n_headline) / (m_s * n_s)}
+    ext_total = sum(ext.values())
     return {
-        "value": (n_s + m_s) / tm["total"], "unit": "points/s", "cores": threads, "kind": "port",
-        "sample": "same star field at N=%d train / M=%d predict, one pass of the reference's SciPy calls "
-                  "(pdist+exp+squareform %.2fs, dpotrf %.2fs = %.1f GFLOP/s on %d BLAS threads, cho_solve %.3fs, "
-                  "cdist+exp %.2fs single-thread); host: %s, %d logical CPUs, %s; the O(N^3) factorisation makes "
-                  "points/s size-dependent"
-                  % (n_s, m_s, tm["kbuild"], tm["cholesky"], n_s ** 3 / 3 / tm["cholesky"] / 1e9, threads,
-                     tm["cho_solve"], tm["cross_kernel"], cpu, os.cpu_count() or 0, blas),
-        "phases_s": {k: round(v, 4) for k, v in tm.items()},
+        "value": (n_s + m_s) / med["total"], "unit": "points/s", "cores": int(threads), "kind": "port",
+        "sample": "configs[1] in full: same star-field recipe at N=%d train / M=%d predict; the reference's SciPy calls "
+                  "(oracle/cpu_reference_path.py), 1 warm-up + %d timed passes, median per phase: pdist+exp+squareform "
+                  "%.2fs (single-thread), dpotrf %.3fs = %.0f GFLOP/s on %d BLAS threads, cho_solve %.3fs, cdist+exp "
+                  "%.2fs (single-thread); host: %s, %d logical / %s physical CPUs, cgroup quota %s, %s; the O(N^3) "
+                  "factorisation makes points/s size-dependent -- compare with the GPU at the same N, not with `value`"
+                  % (n_s, m_s, npass, med["kbuild"], med["cholesky"], gf, threads, med["cho_solve"], med["cross_kernel"],
+                     host["model"], host["logical"], host["physical"], host["cgroup_quota"], blas),
+        "passes": npass, "blas_threads_probe_gflops": {str(k): round(v, 1) for k, v in probe.items()},
+        "dpotrf_gflops": gf,
+        "phases_s": {k: round(v, 4) for k, v in med.items()},
+        "extrapolated_n%d" % n_headline: {
+            "label": "EXTRAPOLATED, not measured: dpotrf time x (N/%d)^3, pair loops x N^2 resp. M N, M = 4 N" % n_s,
+            "phases_s": {k: round(v, 2) for k, v in ext.items()}, "total_s": round(ext_total, 1),
+            "value": (n_headline + m_h) / ext_total, "unit": "points/s"},
     }
+
+
+def _csrc_digest():
+    """sha256 over the HIP sources: a PMC file is only quoted for the code it was collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "treegp_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(n, kernel_key):
+    """HBM-side bytes per launch of a kernel from the newest profiles/r*_pmc_bench_n<N>.json (separate rocprofv3
+    --pmc passes of this very command, tools/pmc_bench.sh, corrected as the microarchitecture guide's HBM section
+    prescribes).  Returns (bytes or None, provenance string): None when no file was collected on the shipped
+    sources -- a stale number is not quoted."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_n%d.json" % n)))
+    if not files:
+        return None, "no PMC file for this workload"
+    rec = json.load(open(files[-1]))
+    der = rec.get("_derived", {})
+    name = os.path.relpath(files[-1], ROOT)
+    if der.get("csrc_digest") != _csrc_digest():
+        return None, "%s was collected on other sources (digest %s, now %s): not quoted" % (name, der.get("csrc_digest"), _csrc_digest())
+    return der.get(kernel_key), "%s (csrc digest %s)" % (name, der["csrc_digest"])
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a child
+    torch.distributed.run (fresh processes; this parent has not touched the GPU and never will), pass their single
+    JSON line through and exit with their code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -84,9 +143,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("TGP_ONE_DEVICE") == "1":
         local_rank = 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))                   # before anything below initialises HIP in this process
     if args.gpus != world:
-        if args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     from treegp_amd import _lib, ops
     from treegp_amd.synthetic import star_field, headline_invlam
@@ -166,9 +226,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        seen = torch.ones(1, dtype=torch.float64, device=t.device)
+        dist.all_reduce(seen)
+        ranks_seen = int(seen.item())
+    else:
+        ranks_seen = 1
 
     if rank == 0:
         K = args.steps
@@ -177,7 +242,7 @@ def main():
             "metric": "GP solve+predict throughput, 2-D AnisotropicRBF N=%d" % n,
             "value": (n + m) * K / dt, "unit": "points/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "ranks_seen": ranks_seen,
             "config": {"workload": "configs[3] problem (2-D AnisotropicRBF star field, N=%d training points, "
                                    "y_err noise diagonal) solved end to end + fused predict of M=%d points; "
                                    "%s" % (n, m, "one GPU" if world == 1 else "row-block-cyclic over %d GPUs" % world),
@@ -186,26 +251,44 @@ def main():
         }
         if acc.get("syrk_ms", 0) > 0:
             ach = acc["syrk_flops"] / (acc["syrk_ms"] * 1e-3) / 1e12          # per GPU (rank 0's share when N > 1)
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_v6_pmc_bench_n65536.json")
-            if world == 1 and n == 65536 and os.path.exists(pmc):
-                # HBM bytes per launch of this kernel for this exact workload, from separate rocprofv3 --pmc
-                # passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_bench.sh), calibration notes inside the file
-                traffic = json.load(open(pmc))["_derived"]["syrk_hbm_bytes_per_launch"]
+            launches = max(acc["syrk_launches"], 1)
+            traffic, src = (None, "not collected for this configuration")
+            alg_bytes = None
+            if world == 1:
+                # HBM-side bytes per launch of this kernel for this exact workload, from separate rocprofv3 --pmc
+                # passes on the shipped sources (FETCH_SIZE x2 for the 16-B/lane operand loads, WRITE_SIZE exact;
+                # tools/pmc_bench.sh); algorithmic bytes per launch = C read + written once (16 B per updated element)
+                traffic, src = measured_traffic(n, "syrk_hbm_bytes_per_launch")
+                alg_bytes = 16.0 * (acc["syrk_flops"] / (2.0 * 1024.0)) / launches if n >= 22528 else None
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                               "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": src,
+                               "algorithmic_bytes": alg_bytes,
+                               "traffic_over_algorithmic": (traffic / alg_bytes) if (traffic and alg_bytes) else None,
                                "kernel": ("syrk_segs_kernel<4>" if n >= 22528 else "syrk_dtv_kernel<4, 2>") if world == 1 else "syrk_distn_kernel (rank 0)",
                                "launches": int(acc["syrk_launches"]),
-                               "avg_launch_ms": acc["syrk_ms"] / max(acc["syrk_launches"], 1)}
+                               "avg_launch_ms": acc["syrk_ms"] / launches}
         if "chol_ms" in acc:
             out["cholesky_tflops_fp64"] = (n ** 3 / 3.0) * K / (acc["chol_ms"] * 1e-3) / 1e12
             out["gp_solves_per_sec"] = K / ((acc["kbuild_ms"] + acc["chol_ms"] + acc["trsv_ms"]) * 1e-3)
             out["predict_points_per_sec"] = m * K / (acc["predict_ms"] * 1e-3)
             if "kbuild_bytes" in acc:
                 out["kbuild_GBps"] = acc["kbuild_bytes"] / (acc["kbuild_ms"] * 1e-3) / 1e9
+                # K build is HBM-write bound, 8 Np(Np+1)/2 + 16 Np algorithmic bytes per launch
+                kb_t, kb_src = measured_traffic(n, "kbuild_write_bytes") if world == 1 else (None, "")
+                out["roofline_kbuild"] = {"bound": "hbm", "achieved": out["kbuild_GBps"], "peak": 8000.0, "unit": "GB/s",
+                                          "frac": out["kbuild_GBps"] / 8000.0, "traffic": kb_t, "traffic_source": kb_src,
+                                          "algorithmic_bytes": acc["kbuild_bytes"] / K,
+                                          "kernel": "kbuild_lower_kernel<GAUSS>", "avg_launch_ms": acc["kbuild_ms"] / K}
+            # both triangular sweeps read the packed factor once each, ~8 Np^2 bytes per solve
+            npad = (n + 255) // 256 * 256
+            tr_bytes = 2 * 8.0 * (npad * (npad + 1) / 2.0)
+            tr_rate = tr_bytes * K / (acc["trsv_ms"] * 1e-3) / 1e9
+            out["roofline_trsv"] = {"bound": "hbm", "achieved": tr_rate, "peak": 8000.0, "unit": "GB/s", "frac": tr_rate / 8000.0,
+                                    "traffic": None, "algorithmic_bytes": tr_bytes, "kernel": "potrs: forward + backward sweep",
+                                    "avg_ms": acc["trsv_ms"] / K}
             out["phases_ms_per_step"] = {k: acc[k] / K for k in ("kbuild_ms", "chol_ms", "trsv_ms", "predict_ms", "syrk_ms")}
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, max(args.cpu_sample // 4, 1))
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 4 * args.cpu_sample, n)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -8,12 +8,20 @@ Parity status
 * kernel matrices, GP solve / predict / posterior covariance / log-likelihood:
   PINNED against the imported reference (``tests/golden/make_golden.py`` ->
   ``tests/golden/*.npz``; checked by ``tests/test_oracle_golden.py``).
-* binned 2-point correlation (``kk_twod`` / ``kk_log``): **parity unpinned**.  The
-  arithmetic lives in the third-party TreeCorr library (PyPI ``treecorr``,
-  ``requirements.txt:6`` pins ``>=5.0``), which is neither vendored in the reference
-  nor installed in this image; no reference test pins a bin value.  The restatement
-  below follows the reference's call sites (``treegp/two_pcf.py:283-340``) and
-  TreeCorr's published binning rules (exact binning, i.e. ``bin_slop=0``).
+* Log-binned pair sums (``kk_log`` with unit weights, ``vcorr``): PINNED against the
+  reference's own exact O(N^2) pair binner ``treegp/utils.py:5-74`` (``vcorr``), run
+  unmodified by ``tests/golden/make_golden.py`` -> ``g9_vcorr.npz`` (vector fields; a
+  scalar field with ``dy = 0`` on a grid that coincides with a KK log-bin grid, where
+  ``xi+`` / ``logr`` are KK's ``xi`` / ``meanlogr``).  Per-point weights enter ``kk_log`` as the
+  factor ``w_i w_j`` on the same sums; that factor itself has no reference-held value.
+* TwoD-pixel pair sums (``kk_twod``) and what TreeCorr does beyond exact binning:
+  **parity unpinned**.  The arithmetic lives in the third-party TreeCorr library (PyPI
+  ``treecorr``, ``requirements.txt:6`` pins ``>=5.0``), which is neither vendored in the
+  reference nor installed in this image; no reference test pins a bin value.  The
+  restatement follows the reference's call sites (``treegp/two_pcf.py:283-340``) and
+  TreeCorr's published binning rules (exact binning, i.e. ``bin_slop=0``); the reference's
+  isotropic path runs TreeCorr with its default ``bin_slop`` (approximate binning), which
+  exact binning does not reproduce bit for bit.
 
 All kernels are described by plain numbers, never by the product's classes:
 ``kind`` in {"gauss", "vk", "avk"}:
@@ -166,7 +174,7 @@ def twod_pixel_centres(nbins, max_sep):
 
 
 # --------------------------------------------------------------------------------------
-# binned scalar-scalar (KK) pair correlation, exact binning  [parity unpinned, see header]
+# binned scalar-scalar (KK) pair correlation, exact binning  [Log bins pinned, TwoD unpinned: see header]
 # --------------------------------------------------------------------------------------
 def kk_twod(x, y, k, w, min_sep, max_sep, nbins, chunk=1024):
     """Restates treecorr.KKCorrelation(bin_type="TwoD", bin_slop=0).process(cat) as used
@@ -320,8 +328,7 @@ def vcorr(x, y, dx, dy, rmin=5.0 / 3600.0, rmax=1.5, dlogr=0.05, chunk=512):
     """utils.py:36-74 restated without the index arrays: every pair i < j, complex separation
     d = (x_j - x_i) + i (y_j - y_i), log|d| histogrammed with np.histogram on (bins, range)
     exactly as there, weights 1, log|d|, dx_i dx_j + dy_i dy_j, v_i v_j and v_i v_j conj(d)^2/|d|^2
-    (v = dx + i dy).  Parity unpinned: no reference test checks a value (tests/test_hyp_search.py:133-139
-    only runs it) and treegp/utils.py imports treecorr at module level, so it cannot be imported here.
+    (v = dx + i dy).  Pinned by tests/golden/g9_vcorr.npz (the reference's vcorr run unmodified).
     Returns logr, xiplus, ximinus, xicross, xiz2 and the pair counts."""
     x = np.asarray(x, float); y = np.asarray(y, float)
     v = np.asarray(dx, float) + 1j * np.asarray(dy, float)

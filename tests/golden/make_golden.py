@@ -21,6 +21,15 @@ Outputs (inputs + the reference's outputs, nothing else):
   g6_meanify.npz        mean-function case, X0/y0 decoded from the reference's FITS fixture
   g7_host_scalars.npz   n_bootstrap / mask sizes, bootstrap index rows, kernel theta maps
   g8_reftests.npz       the reference's own test problems (tests/test_gp_interp.py) end to end
+  g9_vcorr.npz          treegp/utils.py vcorr / xiB / comp_eb -- the reference's own exact O(N^2)
+                        log-binned pair binner -- on vector fields and, with dy = 0, on a scalar
+                        field whose bins coincide with a KK log-bin grid (pins kk_log / vcorr)
+
+``treegp/utils.py`` starts with ``import treecorr`` (utils.py:2) although ``vcorr``, ``xiB`` and
+``comp_eb`` (utils.py:5-107) never touch it.  For G9 only, an EMPTY module object named
+``treecorr`` is registered so that this one import statement resolves; it has no attributes,
+so any code path that really needed TreeCorr would stop with AttributeError (the route
+SURVEY.md 8(c) prescribes).
 """
 import importlib
 import os
@@ -48,6 +57,13 @@ def load_reference():
     pkg.VonKarman = k.VonKarman
     pkg.AnisotropicVonKarman = k.AnisotropicVonKarman
     return pkg
+
+
+def load_reference_utils():
+    """treegp/utils.py unmodified; its module-level ``import treecorr`` resolves to an empty
+    module object (see the header)."""
+    sys.modules.setdefault("treecorr", types.ModuleType("treecorr"))
+    return importlib.import_module("treegp.utils")
 
 
 def corr_len_matrix(size, e1, e2):
@@ -284,6 +300,54 @@ def main():
                     tag + "_new_x": new_x, tag + "_y_far": ypb, tag + "_cov_far": covb})
     out["x"] = x
     np.savez(os.path.join(OUT, "g8_reftests.npz"), **out)
+    # ---------------- G9: the reference's own exact pair binner (treegp/utils.py:5-107) ----
+    ut = load_reference_utils()
+    out = {}
+    # (a) vector field, default-like log bins scaled to a unit field
+    rng = np.random.default_rng(99)
+    n = 1500
+    x, y = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    dx = np.sin(3 * x) + 0.1 * rng.standard_normal(n)
+    dy = np.cos(2 * y) * np.sin(x) + 0.1 * rng.standard_normal(n)
+    kw = dict(rmin=0.01, rmax=0.8, dlogr=0.2)
+    logr, xip, xim, xix, xiz2 = ut.vcorr(x, y, dx, dy, **kw)
+    xie, xib, logr_eb = ut.comp_eb(x, y, dx, dy, **kw)
+    out.update(a_x=x, a_y=y, a_dx=dx, a_dy=dy, a_rmin=kw["rmin"], a_rmax=kw["rmax"], a_dlogr=kw["dlogr"],
+               a_logr=logr, a_xiplus=xip, a_ximinus=xim, a_xicross=xix, a_xiz2=xiz2, a_xie=xie, a_xib=xib)
+    # (b) the reference's default arguments (rmin 5/3600, rmax 1.5, dlogr 0.05: 140 bins, some empty -> nan)
+    n = 700
+    x, y = rng.uniform(0, 2, n), rng.uniform(0, 2, n)
+    dx, dy = rng.standard_normal(n), rng.standard_normal(n)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        logr, xip, xim, xix, xiz2 = ut.vcorr(x, y, dx, dy)
+    out.update(b_x=x, b_y=y, b_dx=dx, b_dy=dy, b_logr=logr, b_xiplus=xip, b_ximinus=xim, b_xicross=xix, b_xiz2=xiz2)
+    # (c) scalar field through the same binner: dy = 0 makes xi+ = <k_i k_j> and logr = <log r> per bin,
+    #     i.e. what KKCorrelation(min_sep, max_sep, nbins) with exact binning and unit weights returns as
+    #     xi / meanlogr.  dlogr is chosen so that vcorr's bins ARE that log grid (checked).
+    n = 2000
+    x, y = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    kf = sine_field(rng, np.array([x, y]).T)
+    kf = kf - kf.mean()
+    min_sep, max_sep, nbins = 0.02, 0.5, 20
+    dlogr = np.log(max_sep / min_sep) / nbins
+    assert int(np.ceil(np.log(max_sep / min_sep) / dlogr)) == nbins
+    logr, xip, xim, xix, xiz2 = ut.vcorr(x, y, kf, np.zeros(n), rmin=min_sep, rmax=max_sep, dlogr=dlogr)
+    assert len(logr) == nbins
+    out.update(c_x=x, c_y=y, c_k=kf, c_min_sep=min_sep, c_max_sep=max_sep, c_nbins=nbins, c_dlogr=dlogr,
+               c_logr=logr, c_xiplus=xip, c_ximinus=xim, c_xicross=xix, c_xiz2=xiz2)
+    # (d) the subsampling branch (utils.py:28-35): legacy global RandomState, seeded here
+    n = 900
+    x, y = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    dx, dy = rng.standard_normal(n), rng.standard_normal(n)
+    np.random.seed(1234)
+    logr, xip, xim, xix, xiz2 = ut.vcorr(x, y, dx, dy, rmin=0.02, rmax=0.7, dlogr=0.3, maxpts=400)
+    out.update(d_x=x, d_y=y, d_dx=dx, d_dy=dy, d_seed=1234, d_maxpts=400, d_rmin=0.02, d_rmax=0.7, d_dlogr=0.3,
+               d_logr=logr, d_xiplus=xip, d_ximinus=xim, d_xicross=xix, d_xiz2=xiz2)
+    # (e) xiB on its own (utils.py:77-86)
+    lr = np.sort(rng.uniform(-5, 0, 30))
+    p_, m_ = rng.standard_normal(30), rng.standard_normal(30)
+    out.update(e_logr=lr, e_xiplus=p_, e_ximinus=m_, e_xib=ut.xiB(lr, p_, m_))
+    np.savez(os.path.join(OUT, "g9_vcorr.npz"), **out)
     print("golden vectors written to", OUT)
 
 

@@ -44,6 +44,16 @@ def _worker(rank, world, port, n, out_dir):
             logdet = float(ch.logdet()[0])
             np.testing.assert_allclose(alpha, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
             np.testing.assert_allclose(logdet, np.linalg.slogdet(K)[1], rtol=1e-11)
+        # the replicate decision is a collective one: rank 0's environment setting wins over the others',
+        # and one rank without room for the copy makes every rank fall back to the distributed sweeps
+        from treegp_amd.dist import agree_replicate
+        assert agree_replicate(comm, lambda env: True, env_rank0="1" if rank == 0 else "0") is True
+        assert agree_replicate(comm, lambda env: env != "0", env_rank0="0" if rank == 0 else "1") is False
+        assert agree_replicate(comm, lambda env: rank != world - 1) is False
+        assert agree_replicate(comm, lambda env: True) is True
+        # ranks that disagree anyway are stopped before the first solve can pair a collective with nothing
+        with pytest.raises(RuntimeError, match="disagree"):
+            DistributedCholesky(NumpyLocalOps(K, n, world, rank, replicated=(rank == 0)), comm)
         # a matrix that is not positive definite is reported on every rank
         Kbad = K.copy()
         Kbad[300, 300] = -1.0

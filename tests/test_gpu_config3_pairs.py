@@ -1,0 +1,140 @@
+"""configs[2] at its full size (N = 32 768) for the pair-binning half of the hot path: kk_log / kk_twod pair counts
+against independent exact counts (kd-tree enumeration, no oracle loop), the 444-resample bootstrap (pair lists vs
+per-resample kernels), and the isotropic two-pcf fit of a von Karman field through the public API."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 32768
+
+
+def _vk_field(n, ell, sigma, seed, nfeat=4096):
+    """Gaussian random field with the reference's von Karman covariance sigma^2 (r/ell)^(5/6) K_{5/6}(2 pi r/ell)/lim0
+    (treegp/kernels.py:249-262 -- a Matern of order 5/6 and inverse scale kappa = 2 pi/ell) on n uniform points of the
+    unit square, synthesised from random Fourier modes drawn from its 2-D spectral density ~ (kappa^2 + q^2)^(-11/6):
+    |q| = kappa sqrt((1-u)^(-6/5) - 1).  Inputs only; a Cholesky draw at this n is the very solve under test."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, (n, 2))
+    kappa = 2 * np.pi / ell
+    q = kappa * np.sqrt((1 - rng.uniform(0, 1, nfeat)) ** (-1.2) - 1.0)
+    th = rng.uniform(0, 2 * np.pi, nfeat)
+    ph = rng.uniform(0, 2 * np.pi, nfeat)
+    Q = np.array([q * np.cos(th), q * np.sin(th)])
+    y = np.zeros(n)
+    for s in range(0, n, 4096):
+        y[s:s + 4096] = np.cos(X[s:s + 4096] @ Q + ph).sum(axis=1)
+    y *= sigma * np.sqrt(2.0 / nfeat)
+    return X, y
+
+
+def test_kk_log_pair_counts_vs_kdtree():
+    """Log bins at N = 32 768 (5.4e8 pairs): per-bin pair counts equal cumulative kd-tree counts differenced at the bin
+    edges (scipy.spatial.cKDTree.count_neighbors); sum of weights consistent; xi of a constant field is that constant
+    squared."""
+    from scipy.spatial import cKDTree
+    from treegp_amd import ops
+    from treegp_amd.synthetic import star_field
+    X, y, y_err, _ = star_field(N, 1)
+    k = y - y.mean()
+    mn, mx, nb = np.sqrt(1.0 / N), 0.5, 20
+    xi, wt, meanr, meanlogr, npairs = ops.kk_log(X[:, 0], X[:, 1], k, None, mn, mx, nb)
+    edges = mn * np.exp(np.arange(nb + 1) * np.log(mx / mn) / nb)
+    tree = cKDTree(X)
+    cum = tree.count_neighbors(tree, edges)                   # ordered pairs incl. self, r <= edge
+    ref = np.diff((cum - N) // 2)
+    # a pair lying within rounding of an edge could legitimately differ; uniform random points have none
+    np.testing.assert_array_equal(npairs, ref)
+    np.testing.assert_array_equal(wt, npairs)
+    assert np.all((meanr > edges[:-1]) & (meanr < edges[1:]))
+    assert np.all(np.exp(meanlogr) <= meanr)
+    w = 1.0 / y_err ** 2
+    xi_c, wt_c = ops.kk_log(X[:, 0], X[:, 1], np.full(N, 1.5), w, mn, mx, nb)[:2]
+    np.testing.assert_allclose(xi_c, 2.25, rtol=1e-12)
+    assert np.all(wt_c > 0)
+
+
+def test_kk_twod_pair_counts_vs_kdtree_enumeration():
+    """TwoD pixels at N = 32 768, 21 x 21 pixels, max_sep 0.15: the pairs are enumerated independently (kd-tree, Chebyshev
+    ball) and binned with NumPy -- pair counts exact, weights and xi to 1e-12."""
+    from scipy.spatial import cKDTree
+    from treegp_amd import ops
+    from treegp_amd.synthetic import star_field
+    X, y, y_err, _ = star_field(N, 1)
+    k = y - y.mean()
+    w = 1.0 / y_err ** 2
+    mx, nb = 0.15, 21
+    xi, wt, npairs = ops.kk_twod(X[:, 0], X[:, 1], k, w, 0.0, mx, nb)
+    pairs = cKDTree(X).query_pairs(mx, p=np.inf, output_type="ndarray")
+    i, j = pairs[:, 0], pairs[:, 1]
+    dx, dy = X[j, 0] - X[i, 0], X[j, 1] - X[i, 1]
+    ok = (np.maximum(np.abs(dx), np.abs(dy)) < mx) & ((dx != 0) | (dy != 0))
+    i, j, dx, dy = i[ok], j[ok], dx[ok], dy[ok]
+    bs = 2.0 * mx / nb
+    s_n = np.zeros(nb * nb); s_w = np.zeros(nb * nb); s_k = np.zeros(nb * nb)
+    ww = w[i] * w[j]
+    kk = ww * k[i] * k[j]
+    for sgn in (1.0, -1.0):
+        ix = ((sgn * dx + mx) / bs).astype(np.int64)
+        iy = ((sgn * dy + mx) / bs).astype(np.int64)
+        good = (ix >= 0) & (ix < nb) & (iy >= 0) & (iy < nb)
+        b = iy[good] * nb + ix[good]
+        s_n += np.bincount(b, minlength=nb * nb)
+        s_w += np.bincount(b, weights=ww[good], minlength=nb * nb)
+        s_k += np.bincount(b, weights=kk[good], minlength=nb * nb)
+    np.testing.assert_array_equal(npairs, s_n)
+    np.testing.assert_allclose(wt, s_w, rtol=1e-12)
+    np.testing.assert_allclose(xi, s_k / s_w, rtol=0, atol=1e-12 * np.abs(xi).max())
+    np.testing.assert_allclose(xi.reshape(nb, nb), xi.reshape(nb, nb)[::-1, ::-1], rtol=0, atol=1e-13)   # two_pcf.py:306-310
+
+
+def test_bootstrap_444_lists_vs_per_resample(monkeypatch):
+    """The anisotropic fit's 444 resamples (two_pcf.py:342-362, nbins = 21) at N = 32 768: the pair-list kernels (geometry
+    once, lanes = resamples) against the per-resample pair kernels, and one resample against a direct binning of the
+    materialised resample."""
+    from treegp_amd import ops
+    from treegp_amd.synthetic import star_field
+    from oracle import gp_oracle as O
+    X, y, y_err, _ = star_field(N, 1)
+    idx = O.bootstrap_indices(N, 444)
+    assert idx.max() == N - 2                                    # the last point is never drawn
+    mx, nb = 0.15, 21
+    got = ops.kk_twod_bootstrap(X[:, 0], X[:, 1], y, y_err, idx, 0.0, mx, nb)
+    assert got.shape == (444, nb * nb)
+    monkeypatch.setenv("TGP_BOOT_LISTS", "0")
+    old = ops.kk_twod_bootstrap(X[:, 0], X[:, 1], y, y_err, idx[:24], 0.0, mx, nb)
+    monkeypatch.delenv("TGP_BOOT_LISTS")
+    np.testing.assert_allclose(got[:24], old, rtol=0, atol=1e-12 * np.abs(old).max())
+    r = 443
+    u, v, yb, eb = X[idx[r], 0], X[idx[r], 1], y[idx[r]], y_err[idx[r]]
+    direct = ops.kk_twod(u, v, yb - yb.mean(), 1.0 / eb ** 2, 0.0, mx, nb)[0]
+    np.testing.assert_allclose(got[r], direct, rtol=0, atol=1e-12 * np.abs(direct).max())
+
+
+def test_config3_two_pcf_fit_recovers_vonkarman_scale():
+    """configs[2] through the public API: N = 32 768 von Karman field, optimizer="two-pcf", nbins = 20, automatic
+    separations (two_pcf.py:409-421); recovered theta within the reference's own tolerance 0.7
+    (tests/test_hyp_search.py:43), return_2pcf() reproducible (:46-47), then solve + predict at that size."""
+    import treegp_amd as treegp
+    ell, sigma = 0.1, 1.0
+    X, y = _vk_field(N, ell, sigma, seed=5)
+    rng = np.random.default_rng(6)
+    noise = 0.03
+    y_err = noise * rng.uniform(0.8, 1.2, N)
+    y = y + y_err * rng.standard_normal(N)
+    truth = treegp.eval_kernel("%r**2 * VonKarman(length_scale=%r)" % (sigma, ell))
+    gp = treegp.GPInterpolation(kernel="0.7**2 * VonKarman(length_scale=0.2)", optimizer="two-pcf", nbins=20,
+                                normalize=True)
+    gp.initialize(X, y, y_err=y_err)
+    gp.solve()
+    np.testing.assert_allclose(gp.kernel.theta, truth.theta, atol=7e-1)
+    xi, xi_weight, distance, coord, mask = gp.return_2pcf()
+    np.testing.assert_allclose(xi, gp._optimizer._2pcf, atol=1e-10)
+    assert len(xi) == 20 and mask.all()
+    Xs = rng.uniform(0, 1, (4096, 2))
+    yp = gp.predict(Xs)
+    assert np.isfinite(yp).all()
+    # held-out check: the fitted GP predicts the noiseless field better than the mean does
+    Xh, yh = _vk_field(N, ell, sigma, seed=5)                  # same modes, same points: the noiseless training field
+    resid = gp.predict(X[:2048]) - yh[:2048]
+    assert np.std(resid) < 0.5 * np.std(yh)

@@ -186,3 +186,26 @@ def test_driver_on_rccl_backend_world_of_one():
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_nccl_world1.py")
     r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "nccl world-of-one ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_bench_self_launch_rehearsal(G):
+    """`python bench.py --gpus G` as the driver types it, with no launcher around it: the parent starts G ranks
+    (torch.distributed.run child, rendezvous on 127.0.0.1) before touching the GPU, rank 0 prints ONE JSON line and the
+    exit code is 0.  Rehearsed here with gloo and all ranks on this box's one GPU; on a multi-GPU node the same
+    command runs over nccl = RCCL, one rank per device."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TGP_DIST_BACKEND="gloo", TGP_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(G), "--steps", "2", "--warmup", "1",
+                        "--ntrain", "6144", "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == G and out["ranks_seen"] == G and out["steps"] == 2
+    assert out["value"] > 0 and out["unit"] == "points/s" and out["scaling"] == "strong"

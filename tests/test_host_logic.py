@@ -184,3 +184,98 @@ def test_two_pcf_adjugate_inverse_matches_lapack():
         np.testing.assert_allclose(_inv2x2(m), np.linalg.inv(m), rtol=1e-12)
     with pytest.raises(np.linalg.LinAlgError):
         _inv2x2(np.array([[1.0, 2.0], [2.0, 4.0]]))
+
+
+def test_bench_self_launches_its_ranks_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` with no launcher around it starts its two ranks itself (before anything initialises
+    HIP in the parent); without a HIP device every rank stops with the library's own error and the parent returns a
+    non-zero exit code -- no silent CPU path."""
+    import subprocess
+    import sys
+    if _lib.load_library().tgp_device_count() > 0:
+        pytest.skip("a GPU is present (the rehearsal with real kernels is in tests/test_gpu_dist.py)")
+    env = dict(os.environ, TGP_DIST_BACKEND="gloo", TGP_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--ntrain", "512", "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "no CPU path" in r.stderr or "no HIP device" in r.stderr, r.stderr[-2000:]
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())
+
+
+class _FakeMinuit2(object):
+    """The slice of iminuit 2.x's API that two_pcf.py:157-168 of the reference (and robust_2dfit._run_migrad here) uses:
+    Minuit(fcn, start), .migrad(), .parameters, .params[name].value, .accurate.  The minimiser behind it is SciPy's."""
+    __version__ = "2.30.1"
+
+    class Minuit(object):
+        def __init__(self, fcn, start):
+            self.fcn, self.start = fcn, np.asarray(start, float)
+            self.parameters = tuple("x%d" % i for i in range(len(self.start)))
+
+        def migrad(self):
+            from scipy import optimize
+            from types import SimpleNamespace
+            res = optimize.minimize(self.fcn, self.start, method="Nelder-Mead", options=dict(xatol=1e-7, fatol=1e-10, maxiter=4000))
+            self.params = {n: SimpleNamespace(value=v) for n, v in zip(self.parameters, res.x)}
+            self.accurate = bool(res.success)
+
+
+class _FakeMinuit1(object):
+    """iminuit 1.x: Minuit.from_array_func(fcn, start, print_level=0), .values (ordered mapping), .migrad_ok()."""
+    __version__ = "1.5.4"
+
+    class Minuit(object):
+        @classmethod
+        def from_array_func(cls, fcn, start, print_level=0):
+            m = cls()
+            m.fcn, m.start = fcn, np.asarray(start, float)
+            return m
+
+        def migrad(self):
+            from scipy import optimize
+            res = optimize.minimize(self.fcn, self.start, method="Nelder-Mead", options=dict(xatol=1e-7, fatol=1e-10, maxiter=4000))
+            self.values = {"x%d" % i: v for i, v in enumerate(res.x)}
+            self._ok = bool(res.success)
+
+        def migrad_ok(self):
+            return self._ok
+
+
+@pytest.mark.parametrize("fake", [_FakeMinuit2, _FakeMinuit1])
+def test_robust_2dfit_minuit_plumbing(fake, monkeypatch):
+    """robust_2dfit through the MIGRAD branch (both iminuit API generations the reference supports,
+    treegp/two_pcf.py:157-168) on a noiseless model correlation function: (size, g1, g2), amplitude and constant come
+    back.  The pixel model is a closed-form Gaussian so that no GPU is needed."""
+    import sys
+    T = sys.modules["treegp_amd.two_pcf"]            # the package attribute of that name is the class, as in the reference
+
+    class HostGauss(object):
+        def __init__(self, invLam=None):
+            self.invLam = invLam
+
+        def __rmul__(self, c):
+            self.amp = c
+            return self
+
+        def __call__(self, X, Y=None):
+            d = X - Y
+            q = np.einsum("ni,ij,nj->n", d, self.invLam, d)
+            return (self.amp * np.exp(-0.5 * q))[:, None]
+
+    monkeypatch.setattr(T, "iminuit", fake)
+    monkeypatch.setattr(T, "get_kernel_class", lambda k: HostGauss)
+    nb, mx = 15, 1.0
+    c = (np.arange(nb) + 0.5) * 2 * mx / nb - mx
+    xx, yy = np.meshgrid(c, c)
+    x, y = xx.ravel(), yy.ravel()
+    truth = (0.35, 0.15, -0.1)
+    model = HostGauss(invLam=np.linalg.inv(T.get_correlation_length_matrix(*truth)))
+    model.amp = 1.7 ** 2
+    data = model(np.column_stack([x, y]), Y=np.zeros((1, 2)))[:, 0] + 0.02
+    fit = T.robust_2dfit(None, data, x, y, np.eye(len(x)))
+    fit.minimize_minuit(p0=[0.3, 0.0, 0.0])
+    assert fit._fit_ok and hasattr(fit, "m")
+    np.testing.assert_allclose(fit.result[1:4], truth, atol=2e-3)
+    np.testing.assert_allclose(fit.result[0], 1.7, atol=2e-3)
+    np.testing.assert_allclose(fit.result[4], 0.02, atol=1e-4)

@@ -106,6 +106,8 @@ def _share_hip_runtime_with_torch():
         cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
         if os.path.exists(cand):
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            if os.environ.get("TGP_VERBOSE"):
+                print("treegp_amd: using torch's HIP runtime %s (one HIP runtime per process)" % cand, file=sys.stderr)
     except Exception:
         pass
 
@@ -122,7 +124,9 @@ def load_library():
         # runtime's hardware queues: 4 by default, streams beyond that share queues and serialise (4 contexts at
         # N = 1024: 0.32 ms per evaluation overall with 4 queues, 0.18 ms with 8).  Only effective if HIP has not been
         # initialised in this process yet; an explicit setting wins.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        # Process-wide side effect (documented in INTEGRATION.md); TGP_SET_HW_QUEUES=0 leaves the environment alone.
+        if os.environ.get("TGP_SET_HW_QUEUES", "1") != "0":
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

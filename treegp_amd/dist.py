@@ -125,10 +125,41 @@ class SelfComm(object):
         out[:inp.numel()].copy_(inp)
 
 
+def local_replicate_vote(lib, Np, G, device, env=None):
+    """This rank's own view: is a replicated factor wanted (TGP_DIST_REPLICATE; default yes with more than one rank)
+    and does it fit in half of the free device memory?"""
+    import torch
+    env = os.environ.get("TGP_DIST_REPLICATE") if env is None else env
+    if not (G > 1 or env == "1") or env == "0":
+        return False
+    full_bytes = int(lib.tgp_panel_elems(Np)) * 8
+    return full_bytes < 0.5 * torch.cuda.mem_get_info(device)[0]
+
+
+def agree_replicate(comm, vote, env_rank0=None):
+    """One decision for all ranks: rank 0's TGP_DIST_REPLICATE setting is broadcast (per-rank environments may
+    differ), and the factor is replicated only if EVERY rank has room for it (all-reduce MIN of the local votes,
+    done as MAX of the negation).  ``vote(env)`` -> this rank's bool under that setting."""
+    import torch
+    dev = getattr(comm, "device", None) or "cpu"
+    t = torch.zeros(1, dtype=torch.float64, device=dev)
+    if comm.rank == 0:
+        e = os.environ.get("TGP_DIST_REPLICATE") if env_rank0 is None else env_rank0
+        t[0] = {"0": 0.0, "1": 1.0}.get(e, 2.0)                 # 2 = unset
+    comm.broadcast(t, 0)
+    env = {0: "0", 1: "1"}.get(int(t.item()), "")
+    t[0] = 0.0 if vote(env) else 1.0
+    comm.all_reduce_max(t)
+    return t.item() == 0.0
+
+
 class HipLocalOps(object):
     """Local arithmetic of one rank on its GPU through the tgp_dd_* entry points."""
 
-    def __init__(self, ctx, spec, n, G, g, device):
+    def __init__(self, ctx, spec, n, G, g, device, replicate=None):
+        """``replicate``: keep a full copy of the factor on this rank for communication-free solves.  With more than
+        one rank it MUST be the value ``agree_replicate`` returned (the same on every rank: the solve branches on it and
+        a mixed decision would pair collectives with no partner); None = decide locally (world of one)."""
         import torch
         from . import _lib
         self.torch, self._lib, self.lib = torch, _lib, _lib.load_library()
@@ -159,11 +190,10 @@ class HipLocalOps(object):
         # replicated factor for the solves: every panel is seen by every rank anyway (broadcast + all-gather); kept
         # in the single-GPU packed layout it lets the triangular sweeps run locally, without their 2 N/256 collectives
         self.Afull = None
-        full_bytes = int(self.lib.tgp_panel_elems(self.Np)) * 8
-        if G > 1 or os.environ.get("TGP_DIST_REPLICATE") == "1":
-            free_bytes = torch.cuda.mem_get_info(device)[0]
-            if os.environ.get("TGP_DIST_REPLICATE", "1") != "0" and full_bytes < 0.5 * free_bytes:
-                self.Afull = torch.empty(full_bytes // 8, dtype=torch.float64, device=device)
+        if replicate is None:
+            replicate = local_replicate_vote(self.lib, self.Np, G, device)
+        if replicate:
+            self.Afull = torch.empty(int(self.lib.tgp_panel_elems(self.Np)), dtype=torch.float64, device=device)
 
     def _chk(self, rc, what, ctx=None):
         self._lib.check(ctx or self.ctx, rc, what)
@@ -304,6 +334,15 @@ class DistributedCholesky(object):
         self.G, self.g = comm.size, comm.rank
         assert (ops.G, ops.g) == (self.G, self.g)
         self.nB, self.Np = ops.nB, ops.Np
+        # solve() branches on ops.replicated between a communication-free path and one full of collectives: every rank
+        # must have taken the same decision (agree_replicate); checked once here, by a collective all ranks reach
+        if self.G > 1 and hasattr(ops, "zeros"):
+            flag = ops.zeros(2)
+            r = 1.0 if getattr(ops, "replicated", False) else 0.0
+            flag[0], flag[1] = r, -r
+            comm.all_reduce_max(flag)
+            if float(flag[0]) != -float(flag[1]):
+                raise RuntimeError("ranks disagree on the replicated factor (use dist.agree_replicate)")
         # panels are taken in groups of `group` (4 from N = 28672 on, else 2: the single-GPU crossover); all-gathered
         # panels: two groups of buffers (the group the bulk update reads, the group being produced underneath it)
         self.group = int(os.environ.get("TGP_DIST_GROUP", "4" if self.Np >= 28672 else "2"))
@@ -484,7 +523,11 @@ class DistributedGP(object):
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.n, self.m = len(y), len(Xs)
-        self.ops = HipLocalOps(ctx, spec, self.n, G, g, device)
+        from . import _lib
+        lib = _lib.load_library()
+        Np = int(lib.tgp_padded_n(self.n))
+        replicate = agree_replicate(comm, lambda env: local_replicate_vote(lib, Np, G, device, env)) if G > 1 else None
+        self.ops = HipLocalOps(ctx, spec, self.n, G, g, device, replicate=replicate)
         timer = (lambda: torch.cuda.Event(enable_timing=True)) if profile else None
         self.chol = DistributedCholesky(self.ops, comm, timer=timer)
         o = self.ops

@@ -54,7 +54,7 @@ class GPInterpolation(object):
             table = read_bintable_row(average_fits)
             self._X0, self._y0 = table["COORDS0"], table["PARAMS0"]
         self._alpha = None
-        self._factor = None
+        self._factor = self._factor_key = None
 
     # -- hyper-parameter fit ---------------------------------------------------------------------
     def _fit(self, kernel, X, y, y_err):
@@ -75,9 +75,23 @@ class GPInterpolation(object):
 
     def _drop_solution(self):
         self._alpha = None
+        self._set_factor(None, None)
+
+    def _set_factor(self, factor, key):
         if getattr(self, "_factor", None) is not None:
             self._factor.free()
-        self._factor = None
+        self._factor, self._factor_key = factor, key
+
+    @staticmethod
+    def _factor_fingerprint(spec, X1, y_err):
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+        h.update(np.asarray([spec.kind, spec.amp, spec.a, spec.b, spec.c, spec.ell], dtype=np.float64).tobytes())
+        for arr in (X1, y_err):
+            arr = np.ascontiguousarray(arr, dtype=np.float64)
+            h.update(str(arr.shape).encode())
+            h.update(arr.tobytes())
+        return h.digest()
 
     # -- prediction ------------------------------------------------------------------------------
     def predict(self, X, return_cov=False):
@@ -94,14 +108,16 @@ class GPInterpolation(object):
         cross-kernel mat-vec (tgp_gp_predict) and, for return_cov, Kss - HT K^-1 HT^T from the
         factor kept on the device (tgp_gp_predict_cov) instead of a second factorisation."""
         spec = kernel_to_spec(kernel)
-        need_factor = return_cov and self._factor is None
-        if self._alpha is None or need_factor:
-            alpha, _, _, factor = ops.gp_solve(spec, X1, y, y_err, keep=return_cov)
-            self._alpha = alpha
-            if factor is not None:
-                if self._factor is not None:
-                    self._factor.free()
-                self._factor = factor
+        # The reference caches only alpha (computed when it is None, whatever the arguments: gp_interp.py:179) and
+        # rebuilds K + diag(y_err^2) from its ARGUMENTS for every covariance request (:186-187).  The factor kept on the
+        # device therefore carries the fingerprint of what it was built from and is rebuilt when that differs.
+        key = self._factor_fingerprint(spec, X1, y_err) if return_cov else None
+        if self._alpha is None:
+            self._alpha, _, _, factor = ops.gp_solve(spec, X1, y, y_err, keep=return_cov)
+            self._set_factor(factor, key)
+        elif return_cov and (self._factor is None or self._factor_key != key):
+            factor = ops.gp_solve(spec, X1, y, y_err, keep=True)[3]          # alpha stays the cached one, as in the reference
+            self._set_factor(factor, key)
         y_predict = ops.gp_predict(spec, X1, self._alpha, X2)
         if return_cov:
             y_cov = ops.gp_predict_cov(spec, self._factor, X1, X2)

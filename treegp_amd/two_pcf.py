@@ -64,6 +64,8 @@ class robust_2dfit(object):
     :param x, y: pixel coordinates  :param W: inverse covariance of xi  :param mask: pixels to use
     """
 
+    _warned_no_minuit = False
+
     def __init__(self, kernel, flat_data, x, y, W, mask=None):
         self.kernel_class = get_kernel_class(kernel)
         self.mask = np.ones(len(x), dtype=bool) if mask is None else mask
@@ -103,6 +105,11 @@ class robust_2dfit(object):
     def _minimize_minuit(self, p0=[3000.0, 0.2, 0.2]):
         """One minimisation from p0: MIGRAD when iminuit is installed (what the reference uses,
         two_pcf.py:150-176), otherwise Nelder-Mead polished by BFGS on the same 3-parameter chi2."""
+        if iminuit is None and not robust_2dfit._warned_no_minuit:
+            robust_2dfit._warned_no_minuit = True
+            warnings.warn("iminuit is not installed: the anisotropic 2-pcf fit uses Nelder-Mead + BFGS on the same chi2 "
+                          "instead of the reference's MIGRAD (treegp/two_pcf.py:150-176); fitted hyper-parameters can "
+                          "differ from the reference's within the fit's own tolerance", RuntimeWarning, stacklevel=3)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             if iminuit is None:
