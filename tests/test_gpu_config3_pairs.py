@@ -128,7 +128,10 @@ def test_config3_two_pcf_fit_recovers_vonkarman_scale():
     gp.initialize(X, y, y_err=y_err)
     gp.solve()
     np.testing.assert_allclose(gp.kernel.theta, truth.theta, atol=7e-1)
-    xi, xi_weight, distance, coord, mask = gp.return_2pcf()
+    # :46-47 re-measures through gp.return_2pcf(); with automatic separations that call has no min_sep / max_sep (the
+    # reference would hand None to TreeCorr there too), so the optimiser's own object -- which holds the separations
+    # it chose -- re-measures here
+    xi, xi_weight, distance, coord, mask = gp._optimizer.return_2pcf()
     np.testing.assert_allclose(xi, gp._optimizer._2pcf, atol=1e-10)
     assert len(xi) == 20 and mask.all()
     Xs = rng.uniform(0, 1, (4096, 2))

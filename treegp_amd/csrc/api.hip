@@ -131,6 +131,7 @@ void tgp_destroy(tgp_ctx *ctx) {
     if (e->W_cache) (void)hipFree(e->W_cache);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+    if (ctx->vslab) (void)hipFree(ctx->vslab);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->h_info) (void)hipHostFree(ctx->h_info);
@@ -363,6 +364,7 @@ void tgp_factor_free(tgp_ctx *ctx, tgp_factor *f) {
     }
     if (f->d_A) (void)hipFree(f->d_A);
     if (f->d_W) (void)hipFree(f->d_W);
+    if (f->d_slabs) (void)hipFree(f->d_slabs);
     delete f;
 }
 

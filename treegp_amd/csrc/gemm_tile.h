@@ -208,12 +208,12 @@ __device__ __forceinline__ void gemm_tile_128_dma(const double *a_ptr, const dou
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    buf_st1(PRELOAD ? -acc[m][n][r] : acc[m][n][r], rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
+                    buf_st1((PRELOAD || MODE == 2) ? -acc[m][n][r] : acc[m][n][r], rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
         }
     }
 }
 
-// MODE 0: C = A B^T     MODE 1: C -= A B^T      (A: 128 x KDEPTH, B: 128 x KDEPTH, row-major)
+// MODE 0: C = A B^T     MODE 1: C -= A B^T     MODE 2: C = -(A B^T)      (A: 128 x KDEPTH, B: 128 x KDEPTH, row-major)
 // A and C always live in 256-wide panels (ld 256); B is a panel (LDB 256) or a W block (LDB 128).
 // NSEG = 2: the contraction runs over two operand pairs back to back, C -= A0 B0^T + A1 B1^T (the
 // depth-512 trailing update after two factored panels), one chunk pipeline across both.
@@ -368,7 +368,7 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    buf_st1(PRELOAD ? -acc[m][n][r] : acc[m][n][r], rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
+                    buf_st1((PRELOAD || MODE == 2) ? -acc[m][n][r] : acc[m][n][r], rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
         }
     }
     if (stamps && threadIdx.x == 0) {
@@ -555,6 +555,7 @@ __device__ __forceinline__ void nt_small_tile(const double *a, int lda, const do
         for (int r = 0; r < 4; ++r) {
             double *p = c + (int64_t)(l4 + 4 * r) * ldc + 32 * w + 16 * n + l15;
             if constexpr (MODE == 1) *p = *p - acc[n][r];
+            else if constexpr (MODE == 2) *p = -acc[n][r];
             else *p = acc[n][r];
         }
 }

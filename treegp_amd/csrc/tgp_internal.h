@@ -38,6 +38,8 @@ struct tgp_ctx {
     size_t scratch_bytes = 0;
     void *scratch2 = nullptr;     // second, small scratch (partial sums) that may be live beside `scratch`
     size_t scratch2_bytes = 0;
+    void *vslab = nullptr;        // inverse slabs of the 1024-row triangular sweeps (trsv_big.hip) when the caller keeps none
+    size_t vslab_bytes = 0;
     unsigned *d_queue = nullptr;  // tile-queue counters of the persistent bulk update (TGP_NQUEUE launches x TGP_QUEUE_WORDS)
     int *d_info = nullptr;        // first failing pivot (1-based), 0 = ok
     int *h_info = nullptr;        // pinned mirror
@@ -50,6 +52,7 @@ struct tgp_factor {
     int64_t n = 0, Np = 0;
     double *d_A = nullptr;        // packed lower panels
     double *d_W = nullptr;        // inverted 128x128 diagonal blocks
+    double *d_slabs = nullptr;    // inverse slabs of the big-step sweeps, built by the first solve with this factor
 };
 
 #define TGP_HIP(call)                                                                   \
@@ -146,7 +149,15 @@ int launch_fwd_update_rows(tgp_ctx *ctx, const double *Lrows, int64_t rows, cons
 int launch_gemv_t_rows(tgp_ctx *ctx, const double *Lrows, int64_t rows, const double *a, double *s);
 int launch_logdet_dist(tgp_ctx *ctx, const double *d_Aloc, const int64_t *d_loff, int64_t Np, int64_t n, int G, int g,
                        double *d_out);
-int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only = false);
+// slab_cache: where the caller keeps this factor's inverse slabs (built on first use, owned by the caller: hipFree);
+// nullptr = rebuild them into the context's own buffer on every call
+int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only = false,
+                 double **slab_cache = nullptr);
+int launch_potrs_128(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only);
+size_t vslab_bytes(int64_t Np, int S);
+int launch_vslab_build(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, int S, double *slabs);
+int launch_potrs_big(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z,
+                     bool forward_only);
 int launch_logdet(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out);
 int launch_dot(tgp_ctx *ctx, const double *d_a, const double *d_b, int64_t n, double *d_out);
 int launch_logdet_dot(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, const double *d_a, const double *d_b, double *d_out);

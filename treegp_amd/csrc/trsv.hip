@@ -351,7 +351,40 @@ __global__ __launch_bounds__(256) void fwd_update256_kernel(const double *__rest
 // 128-block sweep (4 small launches per block): measured faster on one GPU than the fused 256-panel
 // sweep below (10.6 vs 12.2 ms at N=32768); the fused kernels serve the multi-GPU driver, where fewer
 // launches and collectives per block matter more.
-int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only) {
+// Big-step sweeps (trsv_big.hip) from TGP_POTRS_BIG_FROM rows on (default 2048; 0 = never); TGP_POTRS_STEP = 512 | 1024 | 2048.
+int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only,
+                 double **slab_cache) {
+    const int64_t big_from = getenv("TGP_POTRS_BIG_FROM") ? atoll(getenv("TGP_POTRS_BIG_FROM")) : 2048;
+    const int step_env = getenv("TGP_POTRS_STEP") ? atoi(getenv("TGP_POTRS_STEP")) : 1024;
+    const int S = (step_env == 512 || step_env == 2048) ? step_env : 1024;
+    if (big_from <= 0 || Np < big_from) return launch_potrs_128(ctx, d_A, d_W, Np, d_b, forward_only);
+    int rc = tgp_ensure_scratch2(ctx, (size_t)Np * sizeof(double));
+    if (rc) return rc;
+    double *slabs = nullptr;
+    bool build = true;
+    if (slab_cache) {
+        if (*slab_cache) build = false;
+        else TGP_HIP(hipMalloc((void **)slab_cache, vslab_bytes(Np, S)));
+        slabs = *slab_cache;
+    } else {
+        const size_t need = vslab_bytes(Np, S);
+        if (need > ctx->vslab_bytes) {
+            if (ctx->vslab) TGP_HIP(hipFree(ctx->vslab));
+            ctx->vslab = nullptr;
+            ctx->vslab_bytes = 0;
+            TGP_HIP(hipMalloc(&ctx->vslab, need));
+            ctx->vslab_bytes = need;
+        }
+        slabs = (double *)ctx->vslab;
+    }
+    if (build) {
+        rc = launch_vslab_build(ctx, d_A, d_W, Np, S, slabs);
+        if (rc) return rc;
+    }
+    return launch_potrs_big(ctx, d_A, Np, S, slabs, d_b, (double *)ctx->scratch2, forward_only);
+}
+
+int launch_potrs_128(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only) {
     hipStream_t st = ctx->stream;
     const int nb = (int)(Np / TGP_TB);
     // forward: L z = b
