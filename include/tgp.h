@@ -91,6 +91,21 @@ int tgp_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n,
                  double *ydota, tgp_factor **keep);
 void tgp_factor_free(tgp_ctx *ctx, tgp_factor *f);
 
+/* ---- S2b: the same for a kernel matrix the CALLER evaluated ---------------------------------
+ * For scikit-learn kernel trees tgp_kernel cannot describe (Sum, WhiteKernel, Matern, ...): the
+ * reference evals any of them (treegp/kernels.py:17-59) and factorises what kernel(X1) returns
+ * (treegp/gp_interp.py:180-182).  K: (n, n) row-major, its lower triangle is read; yerr^2 (may be
+ * NULL) is added to the diagonal on the device.  Everything else as tgp_gp_solve.              */
+int tgp_gp_solve_dense(tgp_ctx *ctx, const double *K, int64_t n, const double *y, const double *yerr,
+                       double *alpha, double *logdet, double *ydota, tgp_factor **keep);
+
+/* ---- S2c: more right-hand sides against a kept factor ("multi-field") -----------------------
+ * One GP per field, all fields sharing the coordinates and the kernel (the Piff pattern the
+ * reference names at README.rst:28; with the reference each field is its own GPInterpolation and
+ * its own cholesky + cho_solve, gp_interp.py:180-182).  B and Xout: (nrhs, n) row-major;
+ * Xout[v] = (K + diag(yerr^2))^-1 B[v].  The factor is read once per sweep for up to 4 fields.  */
+int tgp_factor_solve(tgp_ctx *ctx, tgp_factor *f, const double *B, int nrhs, double *Xout);
+
 /* ---- S3: ys[j] = sum_i amp k(Xs_j, X_i) alpha_i, HT never materialised -------------------*/
 int tgp_gp_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n,
                    const double *alpha, const double *Xs, int64_t m, double *ys);
@@ -98,6 +113,10 @@ int tgp_gp_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n
 /* ---- S3b: cov (m, m) = k(Xs,Xs) - HT K^-1 HT^T using a kept factor ------------------------*/
 int tgp_gp_predict_cov(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel *k, const double *X,
                        int64_t n, const double *Xs, int64_t m, double *cov);
+/* the same with HT = kernel(X2, Y=X1) (m, n) and Kss = kernel(X2) (m, m) evaluated by the caller
+ * (treegp/gp_interp.py:177,191 for kernel trees that go through tgp_gp_solve_dense)              */
+int tgp_gp_predict_cov_dense(tgp_ctx *ctx, tgp_factor *f, const double *HT, const double *Kss,
+                             int64_t m, double *cov);
 
 /* ---- S4: binned scalar pair correlation, exact binning -----------------------------------
  * w == NULL: unit weights.  TwoD: nbins x nbins pixels over [-max_sep, max_sep]^2, outputs
@@ -167,6 +186,10 @@ int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t
                    double *ydota, tgp_factor **keep);
 int tgp_d_gp_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,
                      const double *d_alpha, const double *d_Xs, int64_t m, double *d_ys);
+/* d_K: dense (n, n) row-major on the device (lower triangle read) */
+int tgp_d_gp_solve_dense(tgp_ctx *ctx, const double *d_K, int64_t n, const double *d_y,
+                         const double *d_yerr, double *d_alpha, double *logdet, double *ydota,
+                         tgp_factor **keep);
 
 /* ---- factor storage: packed lower panels ("panel-major") -----------------------------------
  * Np = n rounded up to 256.  Panel p (p = 0 .. Np/256-1) holds rows 256p .. Np-1 of columns
@@ -185,6 +208,8 @@ int tgp_d_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int
 int tgp_d_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W);
 /* d_b (Np) <- L^-T L^-1 d_b */
 int tgp_d_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b);
+/* d_B (nrhs, Np) row-major: every row <- L^-T L^-1 row */
+int tgp_d_potrs_multi(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_B, int nrhs);
 /* unpack the lower triangle into a dense (n, n) row-major host matrix (upper part zero) */
 int tgp_d_unpack_lower(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *out);
 /* ---- multi-GPU tier (one process per GPU; driver: treegp_amd/dist.py) ------------------------

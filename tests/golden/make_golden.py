@@ -25,6 +25,9 @@ Outputs (inputs + the reference's outputs, nothing else):
                         log-binned pair binner -- on vector fields and, with dy = 0, on a scalar
                         field whose bins coincide with a KK log-bin grid (pins kk_log / vcorr)
 
+  g10_sklearn_kernels.npz  kernel trees only scikit-learn can evaluate (Sum + WhiteKernel, Matern, RationalQuadratic):
+                        the reference's predict / covariance / log-likelihood for them (dense-K entry point)
+
 ``treegp/utils.py`` starts with ``import treecorr`` (utils.py:2) although ``vcorr``, ``xiB`` and
 ``comp_eb`` (utils.py:5-107) never touch it.  For G9 only, an EMPTY module object named
 ``treecorr`` is registered so that this one import statement resolves; it has no attributes,
@@ -348,6 +351,24 @@ def main():
     p_, m_ = rng.standard_normal(30), rng.standard_normal(30)
     out.update(e_logr=lr, e_xiplus=p_, e_ximinus=m_, e_xib=ut.xiB(lr, p_, m_))
     np.savez(os.path.join(OUT, "g9_vcorr.npz"), **out)
+    # ---------------- G10: kernel trees outside the parametrised device kernels -------------------
+    rng = np.random.default_rng(31)
+    N, M = 700, 300
+    X = rng.uniform(0, 1, (N, 2))
+    y = 0.2 + sine_field(rng, X) + 0.05 * rng.standard_normal(N)
+    y_err = 0.05 * rng.uniform(0.8, 1.2, N)
+    Xs = rng.uniform(0, 1, (M, 2))
+    out = dict(X=X, y=y, y_err=y_err, Xs=Xs)
+    for tag, kern in (("sumwhite", "1.0**2 * RBF(0.15) + WhiteKernel(1e-3)"),
+                      ("matern", "0.9**2 * Matern(length_scale=0.2, nu=1.5)"),
+                      ("rq", "1.1**2 * RationalQuadratic(length_scale=0.2, alpha=0.7)"),
+                      ("sum2", "0.7**2 * RBF(0.1) + 0.5**2 * AnisotropicRBF(scale_length=[0.4, 0.25])")):
+        gp = GP(kernel=kern, optimizer="none", normalize=True, white_noise=0.0)
+        gp.initialize(X, y, y_err=y_err)
+        yp, cov = gp.predict(Xs[:128], return_cov=True)
+        out.update({tag + "_kernel": kern, tag + "_y_pred": gp.predict(Xs), tag + "_alpha": gp._alpha, tag + "_cov128": cov,
+                    tag + "_logL": gp.return_log_likelihood()})
+    np.savez(os.path.join(OUT, "g10_sklearn_kernels.npz"), **out)
     print("golden vectors written to", OUT)
 
 

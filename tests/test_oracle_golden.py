@@ -163,6 +163,26 @@ def test_kk_log_against_reference_binner(golden):
     np.testing.assert_allclose(xi2, xi, rtol=1e-13, atol=1e-16)
 
 
+def test_sklearn_kernel_trees_host_side(golden):
+    """g10: for kernel trees outside the parametrised device kernels the product evaluates ``kernel.__call__`` on the host and
+    hands K to the device; here the same host evaluation + the oracle's Cholesky reproduce the reference's alpha,
+    predictions, covariance and log-likelihood (pins the host half of the dense path without a GPU)."""
+    import treegp_amd as treegp
+    g = golden("g10_sklearn_kernels.npz")
+    X, y, y_err, Xs = g["X"], g["y"], g["y_err"], g["Xs"]
+    mean = np.mean(y)
+    for tag in ("sumwhite", "matern", "rq"):         # "sum2" holds an AnisotropicRBF leaf, whose __call__ is the GPU's (S1)
+        k = treegp.eval_kernel(str(g[tag + "_kernel"]))
+        K = k(X)
+        alpha, _ = O.gp_solve(K, y - mean, y_err)
+        np.testing.assert_allclose(alpha, g[tag + "_alpha"], rtol=0, atol=1e-9 * np.abs(g[tag + "_alpha"]).max())
+        HT = k(Xs, Y=X)
+        np.testing.assert_allclose(O.gp_predict(HT, alpha) + mean, g[tag + "_y_pred"], rtol=1e-10, atol=1e-10)
+        cov = O.gp_predict_cov(K, y_err, HT[:128], k(Xs[:128]))
+        np.testing.assert_allclose(cov, g[tag + "_cov128"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(O.log_likelihood(K, y - mean, y_err), g[tag + "_logL"], rtol=1e-12)
+
+
 def meanify_fixture_coords(nfields=300, ndata=500):
     """The star positions behind the reference's tests/inputs/mean_gp_stat_mean.fits: legacy
     np.random.seed(42) stream of its tests/test_meanify.py:43-55 -- per field 500 uniform x, 500 uniform

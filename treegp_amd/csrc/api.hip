@@ -256,32 +256,16 @@ int tgp_d_unpack_lower(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, d
 }
 
 // ---- S2 -------------------------------------------------------------------------------------
-int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_y,
-                   const double *d_yerr, double *d_alpha, double *logdet, double *ydota, tgp_factor **keep) {
-    TGP_ARG(k && d_X && d_y && n > 0);
-    TGP_HIP(hipSetDevice(ctx->device));
+// What follows the K build, shared by the parametrised kernels (tgp_d_gp_solve) and the caller-built matrix
+// (tgp_d_gp_solve_dense): factorise the packed matrix in the context's cache, solve, log-determinant, y . alpha.
+// ev[0] / ev[1] bracket the build (recorded by the caller).
+static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d_y, double *d_alpha, double *logdet,
+                            double *ydota, tgp_factor **keep, bool augmented) {
     hipStream_t st = ctx->stream;
-    const int64_t Np = padded_n(n);
-    int rc = ensure_factor_cache(ctx, Np);
-    if (rc) return rc;
     tgp_ctx_ext *e = ext_of(ctx);
     double *d_A = e->A_cache, *d_W = e->W_cache;
-    rc = tgp_ensure_scratch(ctx, (size_t)Np * sizeof(double));
-    if (rc) return rc;
     double *d_b = (double *)ctx->scratch;
-
-    TGP_HIP(hipEventRecord(ctx->ev[0], st));
-    rc = launch_kbuild_lower(ctx, k, d_X, n, Np, d_yerr, d_A);
-    if (rc) return rc;
-    // Likelihood only (no alpha, factor not kept) and a padding row to spare: y rides along as row Np-1 of the matrix and
-    // comes out of the factorisation as L^-1 y -- no triangular sweep (trsv.hip: augment_rhs_kernel)
-    static const bool no_augment = getenv("TGP_NO_AUGMENT") != nullptr || getenv("TGP_CHI2_BOTH_SWEEPS") != nullptr;
-    const bool augmented = !no_augment && d_alpha == nullptr && keep == nullptr && n < Np;
-    if (augmented) {
-        rc = launch_augment_rhs(ctx, d_A, Np, n, d_y);
-        if (rc) return rc;
-    }
-    TGP_HIP(hipEventRecord(ctx->ev[1], st));
+    int rc = 0;
     // The solves are queued behind the factorisation without waiting for its verdict (one host round trip less per
     // likelihood evaluation); if a pivot failed they run on a meaningless factor and their result is discarded below.
     int info = launch_potrf(ctx, d_A, Np, d_W, /*defer_info=*/true, /*n_data=*/n);
@@ -331,6 +315,113 @@ int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t
         e->cache_Np = 0;
         *keep = f;
     }
+    return 0;
+}
+
+int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_y,
+                   const double *d_yerr, double *d_alpha, double *logdet, double *ydota, tgp_factor **keep) {
+    TGP_ARG(k && d_X && d_y && n > 0);
+    TGP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t Np = padded_n(n);
+    int rc = ensure_factor_cache(ctx, Np);
+    if (rc) return rc;
+    double *d_A = ext_of(ctx)->A_cache;
+    rc = tgp_ensure_scratch(ctx, (size_t)Np * sizeof(double));
+    if (rc) return rc;
+    TGP_HIP(hipEventRecord(ctx->ev[0], st));
+    rc = launch_kbuild_lower(ctx, k, d_X, n, Np, d_yerr, d_A);
+    if (rc) return rc;
+    // Likelihood only (no alpha, factor not kept) and a padding row to spare: y rides along as row Np-1 of the matrix and
+    // comes out of the factorisation as L^-1 y -- no triangular sweep (trsv.hip: augment_rhs_kernel)
+    static const bool no_augment = getenv("TGP_NO_AUGMENT") != nullptr || getenv("TGP_CHI2_BOTH_SWEEPS") != nullptr;
+    const bool augmented = !no_augment && d_alpha == nullptr && keep == nullptr && n < Np;
+    if (augmented) {
+        rc = launch_augment_rhs(ctx, d_A, Np, n, d_y);
+        if (rc) return rc;
+    }
+    TGP_HIP(hipEventRecord(ctx->ev[1], st));
+    return factor_and_solve(ctx, n, Np, d_y, d_alpha, logdet, ydota, keep, augmented);
+}
+
+// The same for a matrix the CALLER evaluated: any scikit-learn kernel tree that tgp_kernel cannot describe (Sum,
+// WhiteKernel, Matern, ...; treegp/kernels.py:17-59 evals any of them and gp_interp.py:177-183 works with what comes back).
+// d_K: dense (n, n) row-major on the device, lower triangle read; d_yerr^2 (may be NULL) is added to the diagonal.
+int tgp_d_gp_solve_dense(tgp_ctx *ctx, const double *d_K, int64_t n, const double *d_y, const double *d_yerr,
+                         double *d_alpha, double *logdet, double *ydota, tgp_factor **keep) {
+    TGP_ARG(d_K && d_y && n > 0);
+    TGP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t Np = padded_n(n);
+    int rc = ensure_factor_cache(ctx, Np);
+    if (rc) return rc;
+    rc = tgp_ensure_scratch(ctx, (size_t)Np * sizeof(double));
+    if (rc) return rc;
+    TGP_HIP(hipEventRecord(ctx->ev[0], st));
+    rc = launch_pack_lower(ctx, d_K, n, Np, d_yerr, ext_of(ctx)->A_cache);
+    if (rc) return rc;
+    TGP_HIP(hipEventRecord(ctx->ev[1], st));
+    return factor_and_solve(ctx, n, Np, d_y, d_alpha, logdet, ydota, keep, false);
+}
+
+int tgp_gp_solve_dense(tgp_ctx *ctx, const double *K, int64_t n, const double *y, const double *yerr, double *alpha,
+                       double *logdet, double *ydota, tgp_factor **keep) {
+    TGP_ARG(K && y && n > 0);
+    TGP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc = ensure_io(ctx, rup((size_t)n * n * 8) + 3 * rup(n * 8));
+    if (rc) return rc;
+    Arena ar{(char *)ext_of(ctx)->io.buf};
+    double *d_K = ar.take<double>((size_t)n * n), *d_y = ar.take<double>(n), *d_e = ar.take<double>(n), *d_a = ar.take<double>(n);
+    TGP_HIP(hipMemcpyAsync(d_K, K, (size_t)n * n * 8, hipMemcpyHostToDevice, st));
+    TGP_HIP(hipMemcpyAsync(d_y, y, n * 8, hipMemcpyHostToDevice, st));
+    if (yerr) TGP_HIP(hipMemcpyAsync(d_e, yerr, n * 8, hipMemcpyHostToDevice, st));
+    rc = tgp_d_gp_solve_dense(ctx, d_K, n, d_y, yerr ? d_e : nullptr, alpha ? d_a : nullptr, logdet, ydota, keep);
+    if (rc) return rc;
+    if (alpha) {
+        TGP_HIP(hipMemcpyAsync(alpha, d_a, n * 8, hipMemcpyDeviceToHost, st));
+        TGP_HIP(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+// ---- several right-hand sides against one kept factor (the Piff pattern, treegp/README.rst:28: one GP per PSF parameter,
+// all sharing the star positions) -------------------------------------------------------------------------------------
+// d_B: (nrhs, Np) row-major on the device, each row one padded right-hand side, solved in place
+int tgp_d_potrs_multi(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_B, int nrhs) {
+    TGP_ARG(d_A && d_W && d_B && nrhs > 0 && Np % TGP_PW == 0);
+    TGP_HIP(hipSetDevice(ctx->device));
+    TGP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    int rc = launch_potrs_multi(ctx, d_A, d_W, Np, d_B, nrhs, nullptr);
+    if (rc) return rc;
+    TGP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    TGP_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timings[2] = ms;
+    return 0;
+}
+
+// B, Xout: (nrhs, n) row-major host; Xout[v] = (K + D)^-1 B[v] with the factor kept by tgp_gp_solve / tgp_gp_solve_dense
+int tgp_factor_solve(tgp_ctx *ctx, tgp_factor *f, const double *B, int nrhs, double *Xout) {
+    TGP_ARG(f && B && Xout && nrhs > 0);
+    TGP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t n = f->n, Np = f->Np;
+    int rc = ensure_io(ctx, rup((size_t)nrhs * Np * 8));
+    if (rc) return rc;
+    double *d_B = (double *)ext_of(ctx)->io.buf;
+    TGP_HIP(hipMemsetAsync(d_B, 0, (size_t)nrhs * Np * 8, st));
+    TGP_HIP(hipMemcpy2DAsync(d_B, (size_t)Np * 8, B, (size_t)n * 8, (size_t)n * 8, (size_t)nrhs, hipMemcpyHostToDevice, st));
+    TGP_HIP(hipEventRecord(ctx->ev[0], st));
+    rc = launch_potrs_multi(ctx, f->d_A, f->d_W, Np, d_B, nrhs, &f->d_slabs);
+    if (rc) return rc;
+    TGP_HIP(hipEventRecord(ctx->ev[1], st));
+    TGP_HIP(hipMemcpy2DAsync(Xout, (size_t)n * 8, d_B, (size_t)Np * 8, (size_t)n * 8, (size_t)nrhs, hipMemcpyDeviceToHost, st));
+    TGP_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timings[2] = ms;
     return 0;
 }
 

@@ -71,49 +71,51 @@ __global__ __launch_bounds__(256, 2) void cov_syrk_kernel(double *Cpm, const dou
 }
 }  // namespace
 
-extern "C" int tgp_gp_predict_cov(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel *k, const double *X, int64_t n,
-                                  const double *Xs, int64_t m, double *cov) {
-    TGP_ARG(f && k && X && Xs && cov && m > 0 && n == f->n);
-    TGP_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    const int64_t Np = f->Np;
-    const int nP = (int)(Np / TGP_PW);
-    const int64_t Mp = (m + TGP_PW - 1) / TGP_PW * TGP_PW;        // 256: the covariance uses the panel layout too
-    const int nPm = (int)(Mp / TGP_PW);
-    TGP_ARG(Mp <= 65535);
+namespace {
+// geometry + scratch shared by the two entry points
+struct CovPlan {
+    int64_t n, m, Np, Mp;
+    int nP, nPm;
+    double *d_X, *d_Xs, *d_Bt, *d_C;
+};
+int cov_plan(tgp_ctx *ctx, const tgp_factor *f, int64_t m, bool coords, CovPlan *pl) {
+    pl->n = f->n; pl->m = m; pl->Np = f->Np;
+    pl->nP = (int)(pl->Np / TGP_PW);
+    pl->Mp = (m + TGP_PW - 1) / TGP_PW * TGP_PW;                  // 256: the covariance uses the panel layout too
+    pl->nPm = (int)(pl->Mp / TGP_PW);
+    TGP_ARG(pl->Mp <= 65535);
     auto rup = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t need = rup(2 * n * 8) + rup(2 * m * 8) + rup((size_t)Mp * Np * 8) + rup((size_t)Mp * Mp * 8);
+    const size_t need = (coords ? rup(2 * pl->n * 8) + rup(2 * m * 8) : 0) + rup((size_t)pl->Mp * pl->Np * 8) + rup((size_t)pl->Mp * pl->Mp * 8);
     int rc = tgp_ensure_scratch(ctx, need);
     if (rc) return rc;
     char *base = (char *)ctx->scratch;
     size_t off = 0;
     auto take = [&](size_t b) { char *p = base + off; off += rup(b); return (double *)p; };
-    double *d_X = take(2 * n * 8), *d_Xs = take(2 * m * 8), *d_Bt = take((size_t)Mp * Np * 8),
-           *d_C = take((size_t)Mp * Mp * 8);
-    TGP_HIP(hipEventRecord(ctx->ev[0], st));
-    TGP_HIP(hipMemcpyAsync(d_X, X, 2 * n * 8, hipMemcpyHostToDevice, st));
-    TGP_HIP(hipMemcpyAsync(d_Xs, Xs, 2 * m * 8, hipMemcpyHostToDevice, st));
-    // HT (gp_interp.py:177) and k(X2) (gp_interp.py:191), zero padded, in panels
-    rc = launch_cross_panels(ctx, k, d_Xs, m, d_X, n, 0, d_Bt, Mp, Np);
-    if (rc) return rc;
-    rc = launch_cross_panels(ctx, k, d_Xs, m, d_Xs, m, 1, d_C, Mp, Mp);
-    if (rc) return rc;
-    const int nb = 2 * nP;
-    const unsigned mt = (unsigned)(Mp / TGP_TB);
+    pl->d_X = coords ? take(2 * pl->n * 8) : nullptr;
+    pl->d_Xs = coords ? take(2 * m * 8) : nullptr;
+    pl->d_Bt = take((size_t)pl->Mp * pl->Np * 8);
+    pl->d_C = take((size_t)pl->Mp * pl->Mp * 8);
+    return 0;
+}
+// d_Bt holds HT, d_C holds k(X2, X2), both in zero-padded panels: substitution, Kss - Bt Bt^T, result to the host
+int cov_finish(tgp_ctx *ctx, const tgp_factor *f, const CovPlan &pl, double *cov) {
+    hipStream_t st = ctx->stream;
+    const int nb = 2 * pl.nP;
+    const unsigned mt = (unsigned)(pl.Mp / TGP_TB);
     for (int kb = 0; kb < nb; ++kb) {
-        double *Bk = d_Bt + (int64_t)(kb >> 1) * Mp * TGP_PW + (kb & 1) * TGP_TB;
+        double *Bk = pl.d_Bt + (int64_t)(kb >> 1) * pl.Mp * TGP_PW + (kb & 1) * TGP_TB;
         cov_trsm_kernel<<<mt, 256, 0, st>>>(Bk, f->d_W + (int64_t)kb * TGP_TB * TGP_TB);
         const int nc = nb - kb - 1;
-        if (nc > 0) cov_update_kernel<<<dim3(mt, (unsigned)nc), 256, 0, st>>>(d_Bt, Mp, f->d_A, Np, kb);
+        if (nc > 0) cov_update_kernel<<<dim3(mt, (unsigned)nc), 256, 0, st>>>(pl.d_Bt, pl.Mp, f->d_A, pl.Np, kb);
     }
-    cov_syrk_kernel<<<dim3(mt, mt), 256, 0, st>>>(d_C, d_Bt, Mp, nP);
+    cov_syrk_kernel<<<dim3(mt, mt), 256, 0, st>>>(pl.d_C, pl.d_Bt, pl.Mp, pl.nP);
     TGP_HIP(hipGetLastError());
     TGP_HIP(hipEventRecord(ctx->ev[1], st));
-    for (int p = 0; p < nPm; ++p) {
-        const int64_t w = (m - (int64_t)p * TGP_PW < TGP_PW) ? m - (int64_t)p * TGP_PW : TGP_PW;
+    for (int p = 0; p < pl.nPm; ++p) {
+        const int64_t w = (pl.m - (int64_t)p * TGP_PW < TGP_PW) ? pl.m - (int64_t)p * TGP_PW : TGP_PW;
         if (w <= 0) break;
-        TGP_HIP(hipMemcpy2DAsync(cov + (int64_t)p * TGP_PW, (size_t)m * 8, d_C + (int64_t)p * Mp * TGP_PW, (size_t)TGP_PW * 8,
-                                 (size_t)w * 8, (size_t)m, hipMemcpyDeviceToHost, st));
+        TGP_HIP(hipMemcpy2DAsync(cov + (int64_t)p * TGP_PW, (size_t)pl.m * 8, pl.d_C + (int64_t)p * pl.Mp * TGP_PW, (size_t)TGP_PW * 8,
+                                 (size_t)w * 8, (size_t)pl.m, hipMemcpyDeviceToHost, st));
     }
     TGP_HIP(hipEventRecord(ctx->ev[2], st));
     TGP_HIP(hipStreamSynchronize(st));
@@ -123,4 +125,52 @@ extern "C" int tgp_gp_predict_cov(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel 
     TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
     ctx->timings[9] = ms;                       // (m, m) result to the caller's buffer
     return 0;
+}
+}  // namespace
+
+extern "C" int tgp_gp_predict_cov(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel *k, const double *X, int64_t n,
+                                  const double *Xs, int64_t m, double *cov) {
+    TGP_ARG(f && k && X && Xs && cov && m > 0 && n == f->n);
+    TGP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    CovPlan pl;
+    int rc = cov_plan(ctx, f, m, true, &pl);
+    if (rc) return rc;
+    TGP_HIP(hipEventRecord(ctx->ev[0], st));
+    TGP_HIP(hipMemcpyAsync(pl.d_X, X, 2 * n * 8, hipMemcpyHostToDevice, st));
+    TGP_HIP(hipMemcpyAsync(pl.d_Xs, Xs, 2 * m * 8, hipMemcpyHostToDevice, st));
+    // HT (gp_interp.py:177) and k(X2) (gp_interp.py:191), zero padded, in panels
+    rc = launch_cross_panels(ctx, k, pl.d_Xs, m, pl.d_X, n, 0, pl.d_Bt, pl.Mp, pl.Np);
+    if (rc) return rc;
+    rc = launch_cross_panels(ctx, k, pl.d_Xs, m, pl.d_Xs, m, 1, pl.d_C, pl.Mp, pl.Mp);
+    if (rc) return rc;
+    return cov_finish(ctx, f, pl, cov);
+}
+
+// The same with HT = kernel(X2, Y=X1) (m, n) and Kss = kernel(X2) (m, m) evaluated by the caller (row-major host arrays):
+// any scikit-learn kernel tree (gp_interp.py:184-192 with the factor kept by tgp_gp_solve_dense).
+extern "C" int tgp_gp_predict_cov_dense(tgp_ctx *ctx, tgp_factor *f, const double *HT, const double *Kss, int64_t m, double *cov) {
+    TGP_ARG(f && HT && Kss && cov && m > 0);
+    TGP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    CovPlan pl;
+    int rc = cov_plan(ctx, f, m, false, &pl);
+    if (rc) return rc;
+    const int64_t n = f->n;
+    TGP_HIP(hipEventRecord(ctx->ev[0], st));
+    TGP_HIP(hipMemsetAsync(pl.d_Bt, 0, (size_t)pl.Mp * pl.Np * 8, st));
+    TGP_HIP(hipMemsetAsync(pl.d_C, 0, (size_t)pl.Mp * pl.Mp * 8, st));
+    for (int p = 0; p < pl.nP; ++p) {
+        const int64_t w = (n - (int64_t)p * TGP_PW < TGP_PW) ? n - (int64_t)p * TGP_PW : TGP_PW;
+        if (w <= 0) break;
+        TGP_HIP(hipMemcpy2DAsync(pl.d_Bt + (int64_t)p * pl.Mp * TGP_PW, (size_t)TGP_PW * 8, HT + (int64_t)p * TGP_PW, (size_t)n * 8,
+                                 (size_t)w * 8, (size_t)m, hipMemcpyHostToDevice, st));
+    }
+    for (int p = 0; p < pl.nPm; ++p) {
+        const int64_t w = (m - (int64_t)p * TGP_PW < TGP_PW) ? m - (int64_t)p * TGP_PW : TGP_PW;
+        if (w <= 0) break;
+        TGP_HIP(hipMemcpy2DAsync(pl.d_C + (int64_t)p * pl.Mp * TGP_PW, (size_t)TGP_PW * 8, Kss + (int64_t)p * TGP_PW, (size_t)m * 8,
+                                 (size_t)w * 8, (size_t)m, hipMemcpyHostToDevice, st));
+    }
+    return cov_finish(ctx, f, pl, cov);
 }

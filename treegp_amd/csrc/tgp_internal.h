@@ -158,6 +158,7 @@ size_t vslab_bytes(int64_t Np, int S);
 int launch_vslab_build(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, int S, double *slabs);
 int launch_potrs_big(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z,
                      bool forward_only);
+int launch_potrs_big_multi(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_B, double *d_Z, int nrhs);
 int launch_logdet(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out);
 int launch_dot(tgp_ctx *ctx, const double *d_a, const double *d_b, int64_t n, double *d_out);
 int launch_logdet_dot(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, const double *d_a, const double *d_b, double *d_out);
@@ -167,3 +168,6 @@ int launch_logdet_rowsq(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, 
 int launch_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_alpha,
                    const double *d_Xs, int64_t m, double *d_ys);
 int launch_unpack_lower(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out);
+int launch_pack_lower(tgp_ctx *ctx, const double *d_K, int64_t n, int64_t Np, const double *d_yerr, double *d_A);
+// d_B: (nrhs, Np) right-hand sides, solved in place, the factor read once per sweep for groups of up to 8 of them
+int launch_potrs_multi(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_B, int nrhs, double **slab_cache);

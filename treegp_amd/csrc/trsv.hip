@@ -352,20 +352,20 @@ __global__ __launch_bounds__(256) void fwd_update256_kernel(const double *__rest
 // sweep below (10.6 vs 12.2 ms at N=32768); the fused kernels serve the multi-GPU driver, where fewer
 // launches and collectives per block matter more.
 // Big-step sweeps (trsv_big.hip) from TGP_POTRS_BIG_FROM rows on (default 2048; 0 = never); TGP_POTRS_STEP = 512 | 1024 | 2048.
-int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only,
-                 double **slab_cache) {
+static bool potrs_big_config(int64_t Np, int *S) {
     const int64_t big_from = getenv("TGP_POTRS_BIG_FROM") ? atoll(getenv("TGP_POTRS_BIG_FROM")) : 2048;
     const int step_env = getenv("TGP_POTRS_STEP") ? atoi(getenv("TGP_POTRS_STEP")) : 1024;
-    const int S = (step_env == 512 || step_env == 2048) ? step_env : 1024;
-    if (big_from <= 0 || Np < big_from) return launch_potrs_128(ctx, d_A, d_W, Np, d_b, forward_only);
-    int rc = tgp_ensure_scratch2(ctx, (size_t)Np * sizeof(double));
-    if (rc) return rc;
-    double *slabs = nullptr;
+    *S = (step_env == 512 || step_env == 2048) ? step_env : 1024;
+    return big_from > 0 && Np >= big_from;
+}
+
+// the inverse slabs of this factor: the caller's cache (built on first use) or the context's buffer (rebuilt every call)
+static int acquire_slabs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, int S, double **slab_cache, double **out) {
     bool build = true;
     if (slab_cache) {
         if (*slab_cache) build = false;
         else TGP_HIP(hipMalloc((void **)slab_cache, vslab_bytes(Np, S)));
-        slabs = *slab_cache;
+        *out = *slab_cache;
     } else {
         const size_t need = vslab_bytes(Np, S);
         if (need > ctx->vslab_bytes) {
@@ -375,13 +375,38 @@ int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np,
             TGP_HIP(hipMalloc(&ctx->vslab, need));
             ctx->vslab_bytes = need;
         }
-        slabs = (double *)ctx->vslab;
+        *out = (double *)ctx->vslab;
     }
-    if (build) {
-        rc = launch_vslab_build(ctx, d_A, d_W, Np, S, slabs);
-        if (rc) return rc;
-    }
+    return build ? launch_vslab_build(ctx, d_A, d_W, Np, S, *out) : 0;
+}
+
+int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only,
+                 double **slab_cache) {
+    int S;
+    if (!potrs_big_config(Np, &S)) return launch_potrs_128(ctx, d_A, d_W, Np, d_b, forward_only);
+    int rc = tgp_ensure_scratch2(ctx, (size_t)Np * sizeof(double));
+    if (rc) return rc;
+    double *slabs = nullptr;
+    rc = acquire_slabs(ctx, d_A, d_W, Np, S, slab_cache, &slabs);
+    if (rc) return rc;
     return launch_potrs_big(ctx, d_A, Np, S, slabs, d_b, (double *)ctx->scratch2, forward_only);
+}
+
+int launch_potrs_multi(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_B, int nrhs, double **slab_cache) {
+    int S;
+    if (!potrs_big_config(Np, &S)) {
+        for (int v = 0; v < nrhs; ++v) {
+            int rc = launch_potrs_128(ctx, d_A, d_W, Np, d_B + (int64_t)v * Np, false);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    int rc = tgp_ensure_scratch2(ctx, (size_t)nrhs * Np * sizeof(double));
+    if (rc) return rc;
+    double *slabs = nullptr;
+    rc = acquire_slabs(ctx, d_A, d_W, Np, S, slab_cache, &slabs);
+    if (rc) return rc;
+    return launch_potrs_big_multi(ctx, d_A, Np, S, slabs, d_B, (double *)ctx->scratch2, nrhs);
 }
 
 int launch_potrs_128(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only) {

@@ -154,59 +154,74 @@ __global__ __launch_bounds__(256) void vtrans_kernel(const double *__restrict__ 
     }
 }
 
+// All sweep kernels take NR right-hand sides at once (vector v at in / out + v * vs): the factor and the slabs are read once
+// for all of them.
+
 // out[r0 + i] = sum_lc M(r0 + i, lc) in[r0 + lc]:  M = V (lower: panels 0 .. i/256) or Vt (upper: panels i/256 .. last); one
 // wave per row, whatever lies on the other side of the diagonal inside those panels is zero.  All loads of a row are
 // issued together (panels outside the row's range are redirected to its diagonal panel and weighted with 0): the
 // kernel is one memory latency long, and there is one of it on the critical path of every step.
-template <bool UPPER, int NP>
+template <bool UPPER, int NP, int NR>
 __global__ __launch_bounds__(256) void diag_gemv_big_kernel(const double *__restrict__ M, int64_t Np, int64_t r0, int rows,
-                                                            const double *__restrict__ in, double *__restrict__ out) {
+                                                            const double *__restrict__ in, double *__restrict__ out, int64_t vs) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= rows) return;
     const int pd = i >> 8, plast = (rows - 1) >> 8;
-    double2 m[NP][2], x[NP][2];
+    double2 m[NP][2];
     double wgt[NP];
+    int cpq[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const bool on = UPPER ? (q >= pd && q <= plast) : (q <= pd);
-        const int cp = on ? q : pd;
+        cpq[q] = on ? q : pd;
         wgt[q] = on ? 1.0 : 0.0;
-        const double *mp = M + (int64_t)cp * Np * 256 + (r0 + i) * 256 + 2 * lane;
-        const double *xp = in + r0 + cp * 256 + 2 * lane;
+        const double *mp = M + (int64_t)cpq[q] * Np * 256 + (r0 + i) * 256 + 2 * lane;
         m[q][0] = *reinterpret_cast<const double2 *>(mp);
         m[q][1] = *reinterpret_cast<const double2 *>(mp + 128);
-        x[q][0] = *reinterpret_cast<const double2 *>(xp);
-        x[q][1] = *reinterpret_cast<const double2 *>(xp + 128);
     }
-    double s = 0.0;
 #pragma unroll
-    for (int q = 0; q < NP; ++q)
-        s += wgt[q] * ((m[q][0].x * x[q][0].x + m[q][0].y * x[q][0].y) + (m[q][1].x * x[q][1].x + m[q][1].y * x[q][1].y));
-    s = wsum(s);
-    if (lane == 0) out[r0 + i] = s;
+    for (int v = 0; v < NR; ++v) {
+        double2 x[NP][2];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const double *xp = in + v * vs + r0 + cpq[q] * 256 + 2 * lane;
+            x[q][0] = *reinterpret_cast<const double2 *>(xp);
+            x[q][1] = *reinterpret_cast<const double2 *>(xp + 128);
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            s += wgt[q] * ((m[q][0].x * x[q][0].x + m[q][0].y * x[q][0].y) + (m[q][1].x * x[q][1].x + m[q][1].y * x[q][1].y));
+        s = wsum(s);
+        if (lane == 0) out[v * vs + r0 + i] = s;
+    }
 }
 
-// forward bulk: b[r] -= L[r, columns of super-block K] . z_K   for nrows rows from row0.  One wave per row, RPW = 16/NP rows
-// per wave with every load (the rows, z, the old b) in flight before the first use: a workgroup lives for one memory latency
-template <int NP>
+// forward bulk: b[r] -= L[r, columns of super-block K] . z_K   for nrows rows from row0.  One wave per row, RPW rows per
+// wave with every load (the rows, z, the old b) in flight before the first use: a workgroup lives for one memory latency
+template <int NP, int NR>
 __global__ __launch_bounds__(256) void bulk_fwd_kernel(const double *__restrict__ A, int64_t Np, int p0, int npan, int64_t row0,
-                                                       int64_t nrows, const double *__restrict__ z, double *b) {
-    constexpr int RPW = 16 / NP;
+                                                       int64_t nrows, const double *__restrict__ z, double *b, int64_t vs) {
+    constexpr int RPW = (16 / NP) / (NR > 1 ? 2 : 1) > 0 ? (16 / NP) / (NR > 1 ? 2 : 1) : 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t first = (int64_t)blockIdx.x * (4 * RPW) + wave * RPW;
     if (first >= nrows) return;
-    double2 zr[NP][2], av[RPW][NP][2];
-    const int64_t mine = first + (lane < RPW ? lane : 0);
-    const double bold = b[row0 + (mine < nrows ? mine : nrows - 1)];
+    double2 zr[NR][NP][2], av[RPW][NP][2];
+    const int64_t mine = first + (lane % RPW);                              // lane -> (row lane % RPW, vector lane / RPW)
+    const int myv = (lane / RPW) < NR ? (lane / RPW) : 0;
+    const double bold = b[myv * vs + row0 + (mine < nrows ? mine : nrows - 1)];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int qq = q < npan ? q : 0;                                   // panels beyond the (short, last) super-block: weight 0 below
         const int64_t p = p0 + qq;
         const double *base = A + panel_off(p, Np) - p * TGP_PW * TGP_PW + 2 * lane;
-        zr[q][0] = *reinterpret_cast<const double2 *>(z + qq * 256 + 2 * lane);
-        zr[q][1] = *reinterpret_cast<const double2 *>(z + qq * 256 + 128 + 2 * lane);
-        if (q >= npan) zr[q][0] = zr[q][1] = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int v = 0; v < NR; ++v) {
+            zr[v][q][0] = *reinterpret_cast<const double2 *>(z + v * vs + qq * 256 + 2 * lane);
+            zr[v][q][1] = *reinterpret_cast<const double2 *>(z + v * vs + qq * 256 + 128 + 2 * lane);
+            if (q >= npan) zr[v][q][0] = zr[v][q][1] = make_double2(0.0, 0.0);
+        }
 #pragma unroll
         for (int t = 0; t < RPW; ++t) {
             const int64_t r = first + t;
@@ -217,16 +232,19 @@ __global__ __launch_bounds__(256) void bulk_fwd_kernel(const double *__restrict_
     }
     double mysum = 0.0;
 #pragma unroll
-    for (int t = 0; t < RPW; ++t) {
-        double acc = 0.0;
+    for (int v = 0; v < NR; ++v)
 #pragma unroll
-        for (int q = 0; q < NP; ++q)
-            acc += (av[t][q][0].x * zr[q][0].x + av[t][q][0].y * zr[q][0].y) + (av[t][q][1].x * zr[q][1].x + av[t][q][1].y * zr[q][1].y);
+        for (int t = 0; t < RPW; ++t) {
+            double acc = 0.0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);     // every lane ends up with the row's sum
-        if (lane == t) mysum = acc;
-    }
-    if (lane < RPW && mine < nrows) b[row0 + mine] = bold - mysum;
+            for (int q = 0; q < NP; ++q)
+                acc += (av[t][q][0].x * zr[v][q][0].x + av[t][q][0].y * zr[v][q][0].y) +
+                       (av[t][q][1].x * zr[v][q][1].x + av[t][q][1].y * zr[v][q][1].y);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);     // every lane ends up with the row's sum
+            if (lane == v * RPW + t) mysum = acc;
+        }
+    if (lane < NR * RPW && mine < nrows) b[myv * vs + row0 + mine] = bold - mysum;
 }
 
 // backward bulk: z[c] -= sum_i L[r0 + i, c] a[r0 + i]  (i < rows) for the CW columns c0 = CW blockIdx.x .. : no reduction across
@@ -234,13 +252,14 @@ __global__ __launch_bounds__(256) void bulk_fwd_kernel(const double *__restrict_
 // through ONE compute unit (~50 GB/s), so its width sets the latency of the launch: CW = 128 (1 KiB per row and wave load, 1 MiB
 // per workgroup at S = 1024) when there are enough columns to fill the chip anyway, CW = 32 (four rows of 256 B per wave load,
 // 256 KiB per workgroup) for the short steps, where the launch is otherwise 20 us long whatever its size.
-template <int CW>
+template <int CW, int NR>
 __global__ __launch_bounds__(512) void bulk_bwd_kernel(const double *__restrict__ A, int64_t Np, int64_t r0, int rows,
-                                                       const double *__restrict__ a, double *z) {
+                                                       const double *__restrict__ a, double *z, int64_t vs) {
     constexpr int LPR = CW / 2;                     // lanes per row (a double2 each)
     constexpr int RPI = 64 / LPR;                   // rows per wave load instruction
-    __shared__ double as[2048];
-    __shared__ double2 part[8][LPR];
+    extern __shared__ double dyn_lds[];
+    double *as = dyn_lds;                           // [NR][rows]
+    double2 *part = reinterpret_cast<double2 *>(dyn_lds);                   // [NR][8][LPR], reuses the space once `as` is done with
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane / LPR, cl = lane % LPR;
     const int64_t c0 = (int64_t)blockIdx.x * CW, p = c0 >> 8;
@@ -249,11 +268,12 @@ __global__ __launch_bounds__(512) void bulk_bwd_kernel(const double *__restrict_
     const int loff = 16 * cl;
     const int per = rows >> 3;                      // rows is a multiple of 256: per is a multiple of 32
     const int i0 = wave * per + sub;
-    double2 zold = make_double2(0.0, 0.0);
-    if (tid < LPR) zold = *reinterpret_cast<const double2 *>(z + c0 + 2 * tid);
-    // two register sets of 16 wave loads each, the next set in flight while one is consumed; a set covers STEP rows, which
+    double2 zold[NR];
+#pragma unroll
+    for (int v = 0; v < NR; ++v) zold[v] = tid < LPR ? *reinterpret_cast<const double2 *>(z + v * vs + c0 + 2 * tid) : make_double2(0.0, 0.0);
+    // two register sets of wave loads, the next set in flight while one is consumed; a set covers STEP rows, which
     // can exceed a wave's share (per = 32 with CW = 32): rows past the share are clamped for the load and weighted with 0
-    constexpr int U = CW == 128 ? 16 : 8, STEP = U * RPI;
+    constexpr int U = (CW == 128 && NR == 1) ? 16 : 8, STEP = U * RPI;
     const int end = wave * per + per;
     auto ld = [&](int i, int u) {
         const int r = i + u * RPI;
@@ -262,13 +282,17 @@ __global__ __launch_bounds__(512) void bulk_bwd_kernel(const double *__restrict_
     double2 v0[U], v1[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) v0[u] = ld(i0, u);
-    for (int i = tid; i < rows; i += 512) as[i] = a[r0 + i];
+#pragma unroll
+    for (int v = 0; v < NR; ++v)
+        for (int i = tid; i < rows; i += 512) as[v * rows + i] = a[v * vs + r0 + i];
     __syncthreads();
-    auto wt = [&](int i, int u) {
+    auto wt = [&](int v, int i, int u) {
         const int r = i + u * RPI;
-        return r < end ? as[r] : 0.0;
+        return r < end ? as[v * rows + r] : 0.0;
     };
-    double sx = 0.0, sy = 0.0;
+    double sx[NR], sy[NR];
+#pragma unroll
+    for (int v = 0; v < NR; ++v) sx[v] = sy[v] = 0.0;
 #pragma unroll 1
     for (int i = i0; i < end; i += 2 * STEP) {
         const bool second = i - sub + STEP < end;   // wave-uniform
@@ -277,38 +301,49 @@ __global__ __launch_bounds__(512) void bulk_bwd_kernel(const double *__restrict_
             for (int u = 0; u < U; ++u) v1[u] = ld(i + STEP, u);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const double w = wt(i, u);
-            sx += v0[u].x * w;
-            sy += v0[u].y * w;
-        }
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int v = 0; v < NR; ++v) {
+                const double w = wt(v, i, u);
+                sx[v] += v0[u].x * w;
+                sy[v] += v0[u].y * w;
+            }
         if (i - sub + 2 * STEP < end) {
 #pragma unroll
             for (int u = 0; u < U; ++u) v0[u] = ld(i + 2 * STEP, u);
         }
         if (second) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const double w = wt(i + STEP, u);
-                sx += v1[u].x * w;
-                sy += v1[u].y * w;
-            }
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int v = 0; v < NR; ++v) {
+                    const double w = wt(v, i + STEP, u);
+                    sx[v] += v1[u].x * w;
+                    sy[v] += v1[u].y * w;
+                }
         }
     }
+    __syncthreads();                                // every wave is done with `as`
 #pragma unroll
-    for (int o = 32; o >= LPR; o >>= 1) {           // the RPI row groups of the wave, fixed order
-        sx += __shfl_xor(sx, o, 64);
-        sy += __shfl_xor(sy, o, 64);
+    for (int v = 0; v < NR; ++v) {
+#pragma unroll
+        for (int o = 32; o >= LPR; o >>= 1) {       // the RPI row groups of the wave, fixed order
+            sx[v] += __shfl_xor(sx[v], o, 64);
+            sy[v] += __shfl_xor(sy[v], o, 64);
+        }
+        if (lane < LPR) part[(v * 8 + wave) * LPR + lane] = make_double2(sx[v], sy[v]);
     }
-    if (lane < LPR) part[wave][lane] = make_double2(sx, sy);
     __syncthreads();
     if (tid < LPR) {
-        double tx = 0.0, ty = 0.0;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) { tx += part[w][tid].x; ty += part[w][tid].y; }
-        zold.x -= tx;
-        zold.y -= ty;
-        *reinterpret_cast<double2 *>(z + c0 + 2 * tid) = zold;
+        for (int v = 0; v < NR; ++v) {
+            double tx = 0.0, ty = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { tx += part[(v * 8 + w) * LPR + tid].x; ty += part[(v * 8 + w) * LPR + tid].y; }
+            zold[v].x -= tx;
+            zold[v].y -= ty;
+            *reinterpret_cast<double2 *>(z + v * vs + c0 + 2 * tid) = zold[v];
+        }
     }
 }
 }  // namespace
@@ -350,18 +385,26 @@ int launch_vslab_build(tgp_ctx *ctx, const double *d_A, const double *d_W, int64
 }
 
 namespace {
-template <bool UPPER>
-void launch_diag_gemv(hipStream_t st, int NPmax, const double *M, int64_t Np, int64_t r0, int rows, const double *in, double *out) {
+template <bool UPPER, int NR>
+void launch_diag_gemv(hipStream_t st, int NPmax, const double *M, int64_t Np, int64_t r0, int rows, const double *in, double *out,
+                      int64_t vs) {
     const unsigned grid = (unsigned)((rows + 3) / 4);
-    if (NPmax <= 2) diag_gemv_big_kernel<UPPER, 2><<<grid, 256, 0, st>>>(M, Np, r0, rows, in, out);
-    else if (NPmax <= 4) diag_gemv_big_kernel<UPPER, 4><<<grid, 256, 0, st>>>(M, Np, r0, rows, in, out);
-    else diag_gemv_big_kernel<UPPER, 8><<<grid, 256, 0, st>>>(M, Np, r0, rows, in, out);
+    if (NPmax <= 2) diag_gemv_big_kernel<UPPER, 2, NR><<<grid, 256, 0, st>>>(M, Np, r0, rows, in, out, vs);
+    else if (NPmax <= 4) diag_gemv_big_kernel<UPPER, 4, NR><<<grid, 256, 0, st>>>(M, Np, r0, rows, in, out, vs);
+    else diag_gemv_big_kernel<UPPER, 8, NR><<<grid, 256, 0, st>>>(M, Np, r0, rows, in, out, vs);
 }
-}  // namespace
 
-// d_b (Np) <- L^-T L^-1 d_b (or L^-1 d_b when forward_only) with the slabs of this factor; d_z: Np doubles of scratch
-int launch_potrs_big(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z,
-                     bool forward_only) {
+template <int NP, int NR>
+void launch_bulk_fwd(hipStream_t st, const double *d_A, int64_t Np, int p0, int npan, int64_t row0, int64_t below, const double *z,
+                     double *b, int64_t vs) {
+    constexpr int RPW = (16 / NP) / (NR > 1 ? 2 : 1) > 0 ? (16 / NP) / (NR > 1 ? 2 : 1) : 1;
+    bulk_fwd_kernel<NP, NR><<<(unsigned)((below + 4 * RPW - 1) / (4 * RPW)), 256, 0, st>>>(d_A, Np, p0, npan, row0, below, z, b, vs);
+}
+
+// NR right-hand sides (vectors at stride vs in d_b and d_z) through both sweeps
+template <int NR>
+int potrs_big_nr(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z, int64_t vs,
+                 bool forward_only) {
     hipStream_t st = ctx->stream;
     const double *V = slabs, *Vt = slabs + Np * S;
     const int nS = (int)((Np + S - 1) / S);
@@ -369,32 +412,51 @@ int launch_potrs_big(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const d
     for (int K = 0; K < nS; ++K) {
         const int64_t r0 = (int64_t)K * S;
         const int rows = (int)((Np - r0) < S ? (Np - r0) : S);
-        launch_diag_gemv<false>(st, NPmax, V, Np, r0, rows, d_b, d_z);
+        launch_diag_gemv<false, NR>(st, NPmax, V, Np, r0, rows, d_b, d_z, vs);
         const int64_t below = Np - (r0 + rows);
         if (below > 0) {
             const int p0 = (int)(r0 / 256), npan = rows / 256;
-            if (NPmax <= 2)
-                bulk_fwd_kernel<2><<<(unsigned)((below + 31) / 32), 256, 0, st>>>(d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b);
-            else if (NPmax <= 4)
-                bulk_fwd_kernel<4><<<(unsigned)((below + 15) / 16), 256, 0, st>>>(d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b);
-            else
-                bulk_fwd_kernel<8><<<(unsigned)((below + 7) / 8), 256, 0, st>>>(d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b);
+            if (NPmax <= 2) launch_bulk_fwd<2, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs);
+            else if (NPmax <= 4) launch_bulk_fwd<4, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs);
+            else launch_bulk_fwd<8, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs);
         }
     }
     if (forward_only) {
-        TGP_HIP(hipMemcpyAsync(d_b, d_z, (size_t)Np * sizeof(double), hipMemcpyDeviceToDevice, st));
+        for (int v = 0; v < NR; ++v)
+            TGP_HIP(hipMemcpyAsync(d_b + v * vs, d_z + v * vs, (size_t)Np * sizeof(double), hipMemcpyDeviceToDevice, st));
         TGP_HIP(hipGetLastError());
         return 0;
     }
     for (int K = nS - 1; K >= 0; --K) {
         const int64_t r0 = (int64_t)K * S;
         const int rows = (int)((Np - r0) < S ? (Np - r0) : S);
-        launch_diag_gemv<true>(st, NPmax, Vt, Np, r0, rows, d_z, d_b);
+        launch_diag_gemv<true, NR>(st, NPmax, Vt, Np, r0, rows, d_z, d_b, vs);
         if (K > 0) {
-            if (r0 / 128 >= 512) bulk_bwd_kernel<128><<<(unsigned)(r0 / 128), 512, 0, st>>>(d_A, Np, r0, rows, d_b, d_z);
-            else bulk_bwd_kernel<32><<<(unsigned)(r0 / 32), 512, 0, st>>>(d_A, Np, r0, rows, d_b, d_z);
+            if (r0 / 128 >= 512) {
+                const size_t lds = (size_t)NR * (rows * 8 > 8 * 64 * 16 ? rows * 8 : 8 * 64 * 16);
+                bulk_bwd_kernel<128, NR><<<(unsigned)(r0 / 128), 512, lds, st>>>(d_A, Np, r0, rows, d_b, d_z, vs);
+            } else {
+                const size_t lds = (size_t)NR * (rows * 8 > 8 * 16 * 16 ? rows * 8 : 8 * 16 * 16);
+                bulk_bwd_kernel<32, NR><<<(unsigned)(r0 / 32), 512, lds, st>>>(d_A, Np, r0, rows, d_b, d_z, vs);
+            }
         }
     }
     TGP_HIP(hipGetLastError());
     return 0;
+}
+}  // namespace
+
+// d_b (Np) <- L^-T L^-1 d_b (or L^-1 d_b when forward_only) with the slabs of this factor; d_z: Np doubles of scratch
+int launch_potrs_big(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z,
+                     bool forward_only) {
+    return potrs_big_nr<1>(ctx, d_A, Np, S, slabs, d_b, d_z, Np, forward_only);
+}
+
+// nrhs right-hand sides, rows of d_B (nrhs, Np), in groups of 4, 2, 1; d_Z: scratch of the same shape
+int launch_potrs_big_multi(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_B, double *d_Z, int nrhs) {
+    int v = 0, rc = 0;
+    for (; v + 4 <= nrhs && !rc; v += 4) rc = potrs_big_nr<4>(ctx, d_A, Np, S, slabs, d_B + (int64_t)v * Np, d_Z + (int64_t)v * Np, Np, false);
+    for (; v + 2 <= nrhs && !rc; v += 2) rc = potrs_big_nr<2>(ctx, d_A, Np, S, slabs, d_B + (int64_t)v * Np, d_Z + (int64_t)v * Np, Np, false);
+    for (; v < nrhs && !rc; ++v) rc = potrs_big_nr<1>(ctx, d_A, Np, S, slabs, d_B + (int64_t)v * Np, d_Z + (int64_t)v * Np, Np, false);
+    return rc;
 }

@@ -107,7 +107,12 @@ class GPInterpolation(object):
         """gp_interp.py:168-194 on the GPU: fused K build + Cholesky + solve (tgp_gp_solve), fused
         cross-kernel mat-vec (tgp_gp_predict) and, for return_cov, Kss - HT K^-1 HT^T from the
         factor kept on the device (tgp_gp_predict_cov) instead of a second factorisation."""
-        spec = kernel_to_spec(kernel)
+        try:
+            spec = kernel_to_spec(kernel)
+        except NotImplementedError:
+            # any other scikit-learn kernel tree (Sum, WhiteKernel, Matern, ...): the kernel object evaluates itself on
+            # the host, exactly as in the reference, and the device factorises what it returns (tgp_gp_solve_dense)
+            return self._return_gp_predict_dense(y, X1, X2, kernel, y_err, return_cov)
         # The reference caches only alpha (computed when it is None, whatever the arguments: gp_interp.py:179) and
         # rebuilds K + diag(y_err^2) from its ARGUMENTS for every covariance request (:186-187).  The factor kept on the
         # device therefore carries the fingerprint of what it was built from and is rebuilt when that differs.
@@ -123,6 +128,62 @@ class GPInterpolation(object):
             y_cov = ops.gp_predict_cov(spec, self._factor, X1, X2)
             return y_predict, y_cov
         return y_predict, None
+
+    def _return_gp_predict_dense(self, y, X1, X2, kernel, y_err, return_cov):
+        """gp_interp.py:177-192 for a kernel only scikit-learn can evaluate: HT, K and k(X2) come from ``kernel.__call__``
+        on the host; factorisation, solve and the posterior covariance run on the device."""
+        HT = kernel(X2, Y=X1)
+        key = None
+        if return_cov:
+            import hashlib
+            h = hashlib.blake2b(digest_size=16)
+            h.update(repr(kernel).encode())
+            h.update(np.asarray(kernel.theta, dtype=np.float64).tobytes())
+            for arr in (X1, y_err):
+                arr = np.ascontiguousarray(arr, dtype=np.float64)
+                h.update(str(arr.shape).encode())
+                h.update(arr.tobytes())
+            key = h.digest()
+        need_alpha = self._alpha is None
+        if need_alpha or (return_cov and (self._factor is None or self._factor_key != key)):
+            alpha, _, _, factor = ops.gp_solve_dense(kernel(X1), y, y_err, keep=return_cov)
+            if need_alpha:
+                self._alpha = alpha
+            self._set_factor(factor, key)
+        y_predict = np.dot(HT, self._alpha.reshape((len(self._alpha), 1))).T[0]
+        if return_cov:
+            return y_predict, ops.gp_predict_cov_dense(self._factor, HT, kernel(X2))
+        return y_predict, None
+
+    def predict_fields(self, Y, X, y_err=None):
+        """Several fields measured at the SAME positions with the same kernel and errors (one GP per PSF parameter, the Piff
+        pattern of treegp/README.rst:28; with the reference each field is its own GPInterpolation, i.e. its own K build,
+        cholesky and cho_solve).  Y: (n_fields, n) values at the positions given to ``initialize``; returns (n_fields, m)
+        predictions at X.  One K build and one factorisation serve all fields; every field keeps its own mean
+        (``normalize``) and shares the mean function table, the kernel and the errors of ``initialize``."""
+        Y = np.atleast_2d(np.asarray(Y, dtype=np.float64))
+        if Y.shape[1] != len(self._X):
+            raise ValueError("Y must be (n_fields, %d)" % len(self._X))
+        sigma = self._y_err if y_err is None else np.sqrt(np.asarray(y_err, dtype=np.float64) ** 2 + self.white_noise ** 2)
+        means = np.mean(Y - self._spatial_average, axis=1) if self.normalize else np.zeros(len(Y))
+        R = Y - means[:, None] - self._spatial_average[None, :]
+        try:
+            spec = kernel_to_spec(self.kernel)
+        except NotImplementedError:
+            spec = None
+        if spec is not None:
+            _, _, _, factor = ops.gp_solve(spec, self._X, R[0], sigma, keep=True, want_alpha=False)
+        else:
+            _, _, _, factor = ops.gp_solve_dense(self.kernel(self._X), R[0], sigma, keep=True, want_alpha=False)
+        try:
+            alphas = ops.factor_solve(factor, R)
+        finally:
+            factor.free()
+        if spec is not None:
+            pred = np.stack([ops.gp_predict(spec, self._X, a, X) for a in alphas])
+        else:
+            pred = alphas.dot(self.kernel(X, Y=self._X).T)
+        return pred + means[:, None] + self._build_average_meanify(X)[None, :]
 
     # -- data ------------------------------------------------------------------------------------
     def initialize(self, X, y, y_err=None):

@@ -50,11 +50,16 @@ class log_likelihood(object):
         definite) gives -inf, as at log_likelihood.py:28-39.  `resident`: the data already on the device
         (ops.ResidentProblem, used by optimizer() for the evaluations of one fit)."""
         try:
-            if resident is not None:
-                log_det, chi2 = ops.gp_solve_resident(kernel_to_spec(kernel), resident, ctx=ctx)
+            try:
+                spec = kernel_to_spec(kernel)
+            except NotImplementedError:
+                spec = None                       # any other scikit-learn kernel tree: it evaluates itself on the host
+            if spec is None:
+                _, log_det, chi2, _ = ops.gp_solve_dense(kernel(self.X), self.y, self.y_err, want_alpha=False, ctx=ctx)
+            elif resident is not None:
+                log_det, chi2 = ops.gp_solve_resident(spec, resident, ctx=ctx)
             else:
-                _, log_det, chi2, _ = ops.gp_solve(kernel_to_spec(kernel), self.X, self.y, self.y_err, want_alpha=False,
-                                                   ctx=ctx)
+                _, log_det, chi2, _ = ops.gp_solve(spec, self.X, self.y, self.y_err, want_alpha=False, ctx=ctx)
             ll = -0.5 * chi2 - (0.5 * self.ndata) * np.log(2.0 * np.pi) - 0.5 * log_det
         except (np.linalg.LinAlgError, FloatingPointError, ValueError, ops._lib.TgpError):
             ll = -np.inf

@@ -85,6 +85,54 @@ def gp_solve(spec, X, y, y_err=None, keep=False, want_alpha=True, ctx=None):
     return alpha, logdet.value, ydota.value, (Factor(ctx, h, n) if keep else None)
 
 
+def gp_solve_dense(K, y, y_err=None, keep=False, want_alpha=True, ctx=None):
+    """gp_solve for a kernel matrix evaluated by the caller (any scikit-learn kernel tree): K (n, n), lower triangle
+    read; y_err^2 is added to the diagonal on the device (tgp_gp_solve_dense)."""
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    K = f64(K)
+    n = K.shape[0]
+    if K.shape != (n, n):
+        raise ValueError("K must be square")
+    y = f64(y)
+    e = None if y_err is None else f64(y_err)
+    alpha = np.empty(n) if want_alpha else None
+    logdet, ydota = C.c_double(0.0), C.c_double(0.0)
+    h = C.c_void_p()
+    rc = lib.tgp_gp_solve_dense(ctx, ptr(K), n, ptr(y), ptr(e), ptr(alpha), C.byref(logdet), C.byref(ydota),
+                                C.byref(h) if keep else None)
+    check(ctx, rc, "tgp_gp_solve_dense")
+    if rc > 0:
+        raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % rc)
+    return alpha, logdet.value, ydota.value, (Factor(ctx, h, n) if keep else None)
+
+
+def factor_solve(factor, B, ctx=None):
+    """(K + D)^-1 applied to every row of B (nrhs, n) with a kept factor (tgp_factor_solve): the factor is read once per
+    sweep for up to 4 right-hand sides."""
+    ctx = ctx or factor._ctx
+    lib = _lib.load_library()
+    B = np.atleast_2d(f64(B))
+    if B.shape[1] != factor.n:
+        raise ValueError("B must be (nrhs, %d)" % factor.n)
+    out = np.empty_like(B)
+    check(ctx, lib.tgp_factor_solve(ctx, factor._h, ptr(B), B.shape[0], ptr(out)), "tgp_factor_solve")
+    return out
+
+
+def gp_predict_cov_dense(factor, HT, Kss, ctx=None):
+    """Kss - HT (K + D)^-1 HT^T for caller-evaluated HT = kernel(X2, Y=X1) (m, n) and Kss = kernel(X2) (m, m)."""
+    ctx = ctx or factor._ctx
+    lib = _lib.load_library()
+    HT, Kss = f64(HT), f64(Kss)
+    m = HT.shape[0]
+    if HT.shape != (m, factor.n) or Kss.shape != (m, m):
+        raise ValueError("HT must be (m, n) and Kss (m, m)")
+    cov = np.empty((m, m))
+    check(ctx, lib.tgp_gp_predict_cov_dense(ctx, factor._h, ptr(HT), ptr(Kss), m, ptr(cov)), "tgp_gp_predict_cov_dense")
+    return cov
+
+
 class ResidentProblem(object):
     """X, y, y_err of one GP problem kept on the device (``tgp_dev_alloc`` / ``tgp_h2d``) for a series of solves
     that differ only in the kernel -- the likelihood evaluations of a maximum-likelihood fit.  Uploading the three
