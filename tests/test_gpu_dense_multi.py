@@ -20,7 +20,7 @@ def test_sklearn_kernel_trees_against_reference_golden(golden, tag):
     import treegp_amd as treegp
     g = golden("g10_sklearn_kernels.npz")
     kern = str(g[tag + "_kernel"])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):   # none of these trees is one of the parametrised device kernels
         treegp.kernel_to_spec(treegp.eval_kernel(kern))
     gp = treegp.GPInterpolation(kernel=kern, optimizer="none", normalize=True, white_noise=0.0)
     gp.initialize(g["X"], g["y"], y_err=g["y_err"])
@@ -114,7 +114,7 @@ def test_predict_fields_equals_one_gp_per_field(kern):
 
 @pytest.mark.parametrize("n", [2048, 2300, 2900, 5000, 9000])
 def test_big_step_sweeps_match_block_chain(n, monkeypatch):
-    """trsv_big.hip (inverse slabs by recursive doubling, 1024-row steps; also 512 and 2048) against the 128-block chain of
+    """trsv_big.hip (inverse slabs by recursive doubling, 1024-row steps; also 512) against the 128-block chain of
     trsv.hip on the same factor, full solve and forward-only (likelihood) path, ragged last super-blocks included."""
     import ctypes as C
     from treegp_amd import _lib, ops
@@ -139,7 +139,7 @@ def test_big_step_sweeps_match_block_chain(n, monkeypatch):
     monkeypatch.setenv("TGP_POTRS_BIG_FROM", "0")
     ref = solve()
     monkeypatch.setenv("TGP_POTRS_BIG_FROM", "256")
-    for step in ("1024", "512", "2048"):
+    for step in ("1024", "512"):
         monkeypatch.setenv("TGP_POTRS_STEP", step)
         got = solve()
         assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max(), (step, np.abs(got - ref).max() / np.abs(ref).max())

@@ -69,6 +69,16 @@ def test_kernel_strings_and_theta(golden):
     assert np.all(kb.bounds == [-3, 3]) and np.all(kb.clone_with_theta(kb.theta).bounds == [-5, 5])
 
 
+def test_kernel_to_spec_only_describes_what_it_evaluates():
+    """Matern derives from RBF in scikit-learn and must not be taken for one; sums, white noise, rational quadratic and
+    products of two non-constant kernels go to the dense path (NotImplementedError here)."""
+    for s in ("1.0**2 * Matern(length_scale=0.3, nu=1.5)", "Matern(0.3)", "1.0**2 * RBF(0.5) + WhiteKernel(1e-3)",
+              "RationalQuadratic(0.2, 0.7)", "RBF(0.3) * VonKarman(0.2)"):
+        with pytest.raises(NotImplementedError):
+            tg.kernel_to_spec(tg.eval_kernel(s))
+    assert tg.kernel_to_spec(tg.eval_kernel("2.0**2 * RBF(0.5)")).amp == 4.0
+
+
 def test_error_behaviour():
     with pytest.raises(TypeError):
         tg.GPInterpolation(kernel=tg.eval_kernel("RBF(1)"))                    # gp_interp.py:87-89

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Triangular sweeps on one factor: the 128-block chain (trsv.hip) against the big-step sweeps with inverse slabs
 (trsv_big.hip), same right-hand side; prints times, 8 Np^2-byte rates and the difference of the two solutions.
-usage: trsv_bench.py [N ...]      env TGP_POTRS_STEP=512|1024|2048"""
+usage: trsv_bench.py [N ...]      env TGP_POTRS_STEP=512|1024"""
 import ctypes as C
 import json
 import os

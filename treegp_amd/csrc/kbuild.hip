@@ -73,8 +73,16 @@ __global__ __launch_bounds__(256) void kbuild_lower_kernel(KParams p, const doub
 // 2^-s from a range-check-free polynomial (17 fp64 instructions instead of libm's ~30; <= 1 ulp): with one transcendental
 // per 8 bytes stored the first-generation kernel was as much VALU- as HBM-bound (2.2 ms of issue at N = 65 536).
 __device__ __forceinline__ double kb_exp2_neg(double s) {     // 2^(-s), s >= 0; Taylor of 2^f, |f| <= 0.5, degree 13
-    const double t = -s;
-    const double k = rint(t);
+    // Only full-rate fp64 adds / FMAs and one 32-bit integer op: rint, the int conversion and ldexp of the textbook form
+    // are replaced by the 1.5 * 2^52 rounding constant (the low dword of t + magic IS round(t) in two's complement) and
+    // an add into the exponent field.  The probe tools/probes/write_ceiling.hip puts the arithmetic that hides under
+    // the store stream at ~32 FMA-equivalents per element; this is 18 + 8 for the quadratic form and the amplitude.
+    // s is clamped at 1021 so that the result stays a normal number: beyond it the true value is below 4.5e-308 and
+    // 2^-1021 p stands in for it (absolute error < 4.5e-308).
+    const double magic = 6755399441055744.0;
+    const double t = -fmin(s, 1021.0);
+    const double z = t + magic;
+    const double k = z - magic;
     const double f = t - k;
     double p = 1.3691488853904128881e-12;
     p = fma(p, f, 2.5678435993488205142e-11);
@@ -90,7 +98,8 @@ __device__ __forceinline__ double kb_exp2_neg(double s) {     // 2^(-s), s >= 0;
     p = fma(p, f, 2.4022650695910071233e-1);
     p = fma(p, f, 6.9314718055994530942e-1);
     p = fma(p, f, 1.0);
-    return ldexp(p, (int)k);
+    const int ki = __double2loint(z);                       // round(t), -1021 .. 0
+    return __hiloint2double(__double2hiint(p) + (ki << 20), __double2loint(p));
 }
 
 template <int KE>

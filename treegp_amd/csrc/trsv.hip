@@ -351,11 +351,11 @@ __global__ __launch_bounds__(256) void fwd_update256_kernel(const double *__rest
 // 128-block sweep (4 small launches per block): measured faster on one GPU than the fused 256-panel
 // sweep below (10.6 vs 12.2 ms at N=32768); the fused kernels serve the multi-GPU driver, where fewer
 // launches and collectives per block matter more.
-// Big-step sweeps (trsv_big.hip) from TGP_POTRS_BIG_FROM rows on (default 2048; 0 = never); TGP_POTRS_STEP = 512 | 1024 | 2048.
+// Big-step sweeps (trsv_big.hip) from TGP_POTRS_BIG_FROM rows on (default 2048; 0 = never); TGP_POTRS_STEP = 512 | 1024.
 static bool potrs_big_config(int64_t Np, int *S) {
     const int64_t big_from = getenv("TGP_POTRS_BIG_FROM") ? atoll(getenv("TGP_POTRS_BIG_FROM")) : 2048;
     const int step_env = getenv("TGP_POTRS_STEP") ? atoi(getenv("TGP_POTRS_STEP")) : 1024;
-    *S = (step_env == 512 || step_env == 2048) ? step_env : 1024;
+    *S = step_env == 512 ? 512 : 1024;
     return big_from > 0 && Np >= big_from;
 }
 

@@ -1,4 +1,4 @@
-// Triangular sweeps in steps of S = 1024 rows (cho_solve at treegp/gp_interp.py:182, log_likelihood.py:31).
+// Triangular sweeps in steps of S = 1024 (or 512) rows (cho_solve at treegp/gp_interp.py:182, log_likelihood.py:31).
 //
 // The 128-block sweep of trsv.hip is a chain of 2 N/128 dependent launches per direction (a one-workgroup GEMV with the
 // inverted diagonal block, then the streaming update): 15 ms at N = 65 536 for 34 GB of factor, 28 % of HBM.  Here the
@@ -93,6 +93,7 @@ __device__ __forceinline__ Prod level_prod(const double *A, double *V, const dou
         p.c = TT + slab_off(Np, o + rs, lo + h + cs);
         p.nseg = nsegs - first;
         p.sa = Np * 256;
+        // at most two segments (h <= 512): ONE stride suffices although consecutive panels of the factor are not equally far apart
         p.sb = panel_off(p0 + 1, Np) - panel_off(p0, Np) - (int64_t)TGP_PW * TGP_PW;
     } else {
         // rows i = rs.., columns j = cs..
@@ -390,8 +391,7 @@ void launch_diag_gemv(hipStream_t st, int NPmax, const double *M, int64_t Np, in
                       int64_t vs) {
     const unsigned grid = (unsigned)((rows + 3) / 4);
     if (NPmax <= 2) diag_gemv_big_kernel<UPPER, 2, NR><<<grid, 256, 0, st>>>(M, Np, r0, rows, in, out, vs);
-    else if (NPmax <= 4) diag_gemv_big_kernel<UPPER, 4, NR><<<grid, 256, 0, st>>>(M, Np, r0, rows, in, out, vs);
-    else diag_gemv_big_kernel<UPPER, 8, NR><<<grid, 256, 0, st>>>(M, Np, r0, rows, in, out, vs);
+    else diag_gemv_big_kernel<UPPER, 4, NR><<<grid, 256, 0, st>>>(M, Np, r0, rows, in, out, vs);
 }
 
 template <int NP, int NR>
@@ -417,8 +417,7 @@ int potrs_big_nr(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const doubl
         if (below > 0) {
             const int p0 = (int)(r0 / 256), npan = rows / 256;
             if (NPmax <= 2) launch_bulk_fwd<2, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs);
-            else if (NPmax <= 4) launch_bulk_fwd<4, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs);
-            else launch_bulk_fwd<8, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs);
+            else launch_bulk_fwd<4, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs);
         }
     }
     if (forward_only) {

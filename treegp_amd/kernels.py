@@ -207,7 +207,7 @@ def kernel_to_spec(kernel):
         s = node._spec()
         s.amp = amp
         return s
-    if isinstance(node, RBF):
+    if type(node) is RBF:                       # exactly RBF: scikit-learn's Matern derives from it
         ls = np.ravel(np.asarray(node.length_scale, dtype=np.float64))
         if ls.size == 1:
             inv = 1.0 / ls[0] ** 2
