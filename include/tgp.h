@@ -248,6 +248,15 @@ int tgp_dd_update2(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t 
  * tile columns col_lo..col_hi count from block kpanel+nseg.  nseg = 1 and 2 are tgp_dd_update / tgp_dd_update2.   */
 int tgp_dd_update_group(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
                         int nseg, const double *const *d_gathered, const int *cmax, int col_lo, int col_hi);
+/* The bulk part of the update as a persistent grid that keeps `nres` (1..3) compute units per shader engine and XCD clear for
+ * the panel chain (diagonal block, local solves, strips) that runs beside it on another stream; for the steps where this
+ * rank's share of the bulk is shorter than the chain.  tgp_dd_queue_reset: once per factorisation, on the launching context;
+ * tgp_dd_set_exclusive(chain ctx, 1): its diagonal blocks then take a compute unit of their own (44 us instead of ~170 us
+ * beside bulk waves) -- only while such a launch keeps units clear.                                                        */
+int tgp_dd_queue_reset(tgp_ctx *ctx);
+int tgp_dd_set_exclusive(tgp_ctx *ctx, int on);
+int tgp_dd_update_group_queued(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
+                               int nseg, const double *const *d_gathered, const int *cmax, int col_lo, int col_hi, int nres);
 /* Replicated factor for the solves: store panel kpanel into d_Afull, a full single-GPU packed matrix
  * (tgp_panel_elems(Np) doubles) kept on every rank -- its 256x256 diagonal block from the broadcast buffer
  * (d_bcast, may be NULL) and/or the rows below it from the all-gathered panel (d_gathered, may be NULL).

@@ -43,6 +43,21 @@ def test_world_of_one_matches_single_gpu_path():
                                        (6, 257, 2), (4, 513, 2), (3, 3000, 4), (8, 6000, 4), (2, 2700, 3), (4, 1900, 1)])
 def test_virtual_ranks(G, n, group, monkeypatch):
     monkeypatch.setenv("TGP_DIST_GROUP", str(group))
+    _run_virtual_ranks(G, n)
+
+
+@pytest.mark.parametrize("G,n,group,units", [(2, 9000, 4, "1"), (4, 6000, 2, "2"), (1, 5000, 4, "3"), (3, 7000, 3, "-1")])
+def test_virtual_ranks_queued_bulk(G, n, group, units, monkeypatch):
+    """The bulk update as the persistent grid that keeps compute units clear for the panel chain (syrk_distn_queue_kernel),
+    the chain's diagonal blocks on units of their own: forced with 1 .. 3 units per shader engine, and the per-step
+    decision (-1) with a chain estimate that makes every step chain-bound."""
+    monkeypatch.setenv("TGP_DIST_GROUP", str(group))
+    monkeypatch.setenv("TGP_DIST_QUEUE", units)
+    monkeypatch.setenv("TGP_DIST_CHAIN_US", "100000")
+    _run_virtual_ranks(G, n)
+
+
+def _run_virtual_ranks(G, n):
     import torch
     from treegp_amd import _lib, ops
     from treegp_amd.dist import DistributedGP

@@ -8,6 +8,7 @@
 # Run on the GPU box:  bash tools/pmc_bench.sh
 set -e
 R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/pmcb_* $R/gpurun_out/pmccal_*   # the derivation sums every CSV it finds
 mkdir -p $R/gpurun_out
 hipcc --offload-arch=gfx950 -O2 -w -o /tmp/fetch_calib $R/tools/probes/fetch_calib.hip
 cd /tmp && export TMPDIR=/tmp

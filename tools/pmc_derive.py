@@ -40,7 +40,7 @@ def cal_name(nm):
 def bench_name(nm):
     if "syrk_segs_kernel<4>" in nm:
         return "syrk_segs_kernel<4>"
-    if "kbuild_lower" in nm:
+    if "kbuild_lower" in nm or "kbuild_slab" in nm:
         return "kbuild_lower_kernel"
     return None
 

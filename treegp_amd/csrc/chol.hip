@@ -345,11 +345,10 @@ struct DistMap {
     int start[258];           // prefix of super-tiles per row group; start[ngroups] = total  (N up to 262144 on one rank)
     int ngroups;
 };
+// one tile of the rank's share: b is the (virtual) workgroup index of the plain launch
 template <int NSEG>
-__global__ __launch_bounds__(256, 2) void syrk_distn_kernel(double *Aloc, const int64_t *__restrict__ loff, int kpanel, int G,
-                                                            int g, DistSegs<NSEG> S, int col_lo, int ncol, int nrows,
-                                                            DistMap M) {
-    const int64_t b = blockIdx.x;
+__device__ __forceinline__ void syrk_distn_tile(int64_t b, double *Aloc, const int64_t *__restrict__ loff, int kpanel, int G, int g,
+                                                const DistSegs<NSEG> &S, int col_lo, int ncol, int nrows, const DistMap &M) {
     const int64_t st = ((b >> 3) >> 6) * 8 + (b & 7);
     if (st >= M.start[M.ngroups]) return;
     int R = 0;
@@ -378,6 +377,53 @@ __global__ __launch_bounds__(256, 2) void syrk_distn_kernel(double *Aloc, const 
     }
     double *c = Aloc + loff[bj] + (((bi - dist_first_ge(bj, g, G)) / G) * TGP_PW + hi) * TGP_PW + hj;
     gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, c);
+}
+
+template <int NSEG>
+__global__ __launch_bounds__(256, 2) void syrk_distn_kernel(double *Aloc, const int64_t *__restrict__ loff, int kpanel, int G,
+                                                            int g, DistSegs<NSEG> S, int col_lo, int ncol, int nrows,
+                                                            DistMap M) {
+    syrk_distn_tile<NSEG>(blockIdx.x, Aloc, loff, kpanel, G, g, S, col_lo, ncol, nrows, M);
+}
+
+// The same update as a PERSISTENT grid that keeps `nres` compute units per shader engine and XCD clear for the panel chain
+// (see syrk_dtv_queue_kernel: what the chain waits for beside a plain bulk launch, and why the clear units are per shader
+// engine): for the steps of the multi-GPU factorisation whose local share of the bulk is shorter than the panel chain --
+// every step of the second half at 8 ranks and N = 65 536 -- where a diagonal block next to bulk waves takes 170 - 230 us
+// instead of 44.  Workgroups take the plain launch's workgroup indices from per-XCD-class queues.
+template <int NSEG>
+__global__ __launch_bounds__(256, 2) void syrk_distn_queue_kernel(double *Aloc, const int64_t *__restrict__ loff, int kpanel, int G,
+                                                                  int g, DistSegs<NSEG> S, int col_lo, int ncol, int nrows, DistMap M,
+                                                                  unsigned slots_per_class, int nres, unsigned *__restrict__ queue) {
+    __shared__ unsigned s_slot;
+    const unsigned xcd = blockIdx.x & 7;
+    if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));      // HW_ID[15:8]: CU_ID[3:0], SH_ID, SE_ID[2:0]
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;  // XCC_ID[3:0]
+        const unsigned key = hw + 1;
+        unsigned *claims = queue + 8 + 3 * (4 * xcc + ((hw >> 5) & 3));
+        unsigned leave = 0;
+        for (int r = 0; r < nres && !leave; ++r) {
+            const unsigned prev = atomicCAS(&claims[r], 0u, key);
+            leave = (prev == 0u || prev == key) ? 1u : 0u;
+        }
+        // at most 8 nres + 8 workgroups of a class may leave: progress never depends on where the dispatcher puts workgroups
+        if (leave && atomicAdd(&queue[104 + xcd], 1u) >= 8u * (unsigned)nres + 8u) leave = 0u;
+        s_slot = leave;
+    }
+    __syncthreads();
+    const bool leave = s_slot != 0u;
+    __syncthreads();
+    if (leave) return;
+    for (;;) {
+        if (threadIdx.x == 0) s_slot = atomicAdd(&queue[xcd], 1u);
+        __syncthreads();
+        const unsigned n = s_slot;
+        __syncthreads();                         // s_slot has been read by everyone before the next round overwrites it
+        if (n >= slots_per_class) break;         // uniform
+        syrk_distn_tile<NSEG>(((int64_t)n << 3) | xcd, Aloc, loff, kpanel, G, g, S, col_lo, ncol, nrows, M);
+        __syncthreads();                         // the tile's LDS staging is done before the next tile reuses it
+    }
 }
 
 // `exclusive`: ask for so much LDS (128 KB in all) that no trailing-update workgroup fits on the compute unit beside this
@@ -764,14 +810,15 @@ int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int
     hipStream_t st = ctx->stream;
     double *R1 = blk + (int64_t)TGP_TB * TGP_PW;
     static const bool unfused = getenv("TGP_DIST_TRSM_UNFUSED") != nullptr;
-    run_potrf128(st, blk, TGP_PW, W0, ctx->d_info, base);
+    const bool excl = ctx->chain_exclusive != 0;      // a queued bulk update keeps compute units clear for this chain
+    run_potrf128(st, blk, TGP_PW, W0, ctx->d_info, base, excl);
     if (!unfused) {
         diag_mid_kernel<<<1, 256, 0, st>>>(R1, W0);
     } else {
         gemm_col_kernel<0, TGP_TB><<<1, 256, 0, st>>>(R1, W0, R1);
         gemm_col_kernel<1, TGP_PW><<<1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
     }
-    run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, ctx->d_info, base + TGP_TB);
+    run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, ctx->d_info, base + TGP_TB, excl);
     TGP_HIP(hipGetLastError());
     return 0;
 }
@@ -796,17 +843,21 @@ int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, 
 
 template <int NSEG>
 static void launch_distn(hipStream_t st, unsigned grid, double *d_Aloc, const int64_t *d_loff, int kpanel, int G, int g,
-                         const double *const *P, const int *cmax, int col_lo, int ncol, int nrows, const DistMap &M) {
+                         const double *const *P, const int *cmax, int col_lo, int ncol, int nrows, const DistMap &M, int nres,
+                         unsigned *queue) {
     DistSegs<NSEG> S;
     for (int s = 0; s < NSEG; ++s) {
         S.P[s] = P[s];
         S.cmax[s] = cmax[s];
     }
-    syrk_distn_kernel<NSEG><<<grid, 256, 0, st>>>(d_Aloc, d_loff, kpanel, G, g, S, col_lo, ncol, nrows, M);
+    if (nres > 0 && queue)
+        syrk_distn_queue_kernel<NSEG><<<512 + 8, 256, 0, st>>>(d_Aloc, d_loff, kpanel, G, g, S, col_lo, ncol, nrows, M, grid / 8, nres, queue);
+    else
+        syrk_distn_kernel<NSEG><<<grid, 256, 0, st>>>(d_Aloc, d_loff, kpanel, G, g, S, col_lo, ncol, nrows, M);
 }
 
 int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
-                      const double *const *d_P, const int *cmax, int col_lo, int col_hi) {
+                      const double *const *d_P, const int *cmax, int col_lo, int col_hi, int queue_nres) {
     TGP_ARG(nseg >= 1 && nseg <= 4);
     const int64_t nB = Np / TGP_PW;
     const int64_t nloc = dist_panel_blocks(kpanel + nseg, nB, g, G);      // local blocks > kpanel + nseg - 1
@@ -834,11 +885,17 @@ int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64
     if (total == 0) return 0;
     const unsigned grid = (unsigned)(((total + 7) / 8) * 8 * 64);
     hipStream_t st = ctx->stream;
+    // queued form: one set of counters per launch, zeroed by tgp_dd_queue_reset at the start of a factorisation; when the
+    // sets run out the launch is a plain one
+    int nres = queue_nres > 3 ? 3 : queue_nres;
+    unsigned *queue = nullptr;
+    if (nres > 0 && ctx->dist_nqueue < TGP_NQUEUE) queue = ctx->d_queue + TGP_QUEUE_WORDS * (ctx->dist_nqueue++);
+    else nres = 0;
     switch (nseg) {
-        case 1: launch_distn<1>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M); break;
-        case 2: launch_distn<2>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M); break;
-        case 3: launch_distn<3>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M); break;
-        default: launch_distn<4>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M); break;
+        case 1: launch_distn<1>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue); break;
+        case 2: launch_distn<2>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue); break;
+        case 3: launch_distn<3>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue); break;
+        default: launch_distn<4>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue); break;
     }
     TGP_HIP(hipGetLastError());
     return 0;

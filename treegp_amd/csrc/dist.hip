@@ -94,6 +94,27 @@ int tgp_dd_update_group(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int
     return launch_syrk_distn(ctx, d_Aloc, d_loff, Np, kpanel, G, g, nseg, d_gathered, cmax, col_lo, col_hi);
 }
 
+// The bulk update as a persistent grid that keeps `nres` (1 .. 3) compute units per shader engine clear for the panel chain
+// running on another stream / context (chol.hip: syrk_distn_queue_kernel); tgp_dd_queue_reset once per factorisation, on
+// the stream of the context that launches the bulk; tgp_dd_set_exclusive(ctx, 1) on the CHAIN's context makes its diagonal
+// blocks insist on a compute unit of their own (safe only while such a bulk keeps units clear, or on an idle chip).
+int tgp_dd_queue_reset(tgp_ctx *ctx) {
+    TGP_HIP(hipMemsetAsync(ctx->d_queue, 0, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned), ctx->stream));
+    ctx->dist_nqueue = 0;
+    return 0;
+}
+int tgp_dd_set_exclusive(tgp_ctx *ctx, int on) {
+    if (!ctx) return -1;
+    ctx->chain_exclusive = on ? 1 : 0;
+    return 0;
+}
+int tgp_dd_update_group_queued(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
+                               const double *const *d_gathered, const int *cmax, int col_lo, int col_hi, int nres) {
+    TGP_ARG(d_Aloc && d_loff && d_gathered && cmax && nseg >= 1 && nseg <= 4 && nres >= 0);
+    for (int s = 0; s < nseg; ++s) TGP_ARG(d_gathered[s] && cmax[s] >= 0);
+    return launch_syrk_distn(ctx, d_Aloc, d_loff, Np, kpanel, G, g, nseg, d_gathered, cmax, col_lo, col_hi, nres);
+}
+
 // ---- replicated factor for the solves ---------------------------------------------------------------------------
 // Every rank sees every panel once (diagonal block in the broadcast, the rows below in the all-gather).  Keeping them,
 // in the single-GPU packed layout (17 GB at N = 65536, 69 GB at 131072: what 288 GB of HBM per GPU are for), lets each

@@ -40,6 +40,8 @@ struct tgp_ctx {
     size_t scratch2_bytes = 0;
     void *vslab = nullptr;        // inverse slabs of the 1024-row triangular sweeps (trsv_big.hip) when the caller keeps none
     size_t vslab_bytes = 0;
+    int dist_nqueue = 0;          // queue sets handed out since tgp_dd_queue_reset (multi-GPU driver)
+    int chain_exclusive = 0;      // tgp_dd_set_exclusive: diagonal blocks of this context ask for a compute unit of their own
     unsigned *d_queue = nullptr;  // tile-queue counters of the persistent bulk update (TGP_NQUEUE launches x TGP_QUEUE_WORDS)
     int *d_info = nullptr;        // first failing pivot (1-based), 0 = ok
     int *h_info = nullptr;        // pinned mirror
@@ -142,7 +144,7 @@ int launch_kbuild_lower_dist(tgp_ctx *ctx, const tgp_kernel *k, const double *d_
 int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base);
 int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, const double *W0, const double *W1);
 int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
-                      const double *const *d_P, const int *cmax, int col_lo, int col_hi);
+                      const double *const *d_P, const int *cmax, int col_lo, int col_hi, int queue_nres = 0);
 int launch_diag256_fwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y);
 int launch_diag256_bwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y, const double *s);
 int launch_fwd_update_rows(tgp_ctx *ctx, const double *Lrows, int64_t rows, const double *z, double *yrows);

@@ -256,13 +256,24 @@ class HipLocalOps(object):
                                           self._p(gathered0), cmax0, self._p(gathered1), cmax1, col_lo, col_hi),
                   "tgp_dd_update2")
 
-    def update_group(self, k, bufs, cmaxs, col_lo=0, col_hi=-1, side=False):
+    def queue_reset(self):                 # once per factorisation: counters of the queued bulk launches
+        self._chk(self.lib.tgp_dd_queue_reset(self.ctx), "tgp_dd_queue_reset")
+
+    def chain_exclusive(self, on):         # the side chain's diagonal blocks take a compute unit of their own
+        self.lib.tgp_dd_set_exclusive(self.ctx_side, 1 if on else 0)
+
+    def update_group(self, k, bufs, cmaxs, col_lo=0, col_hi=-1, side=False, queue_nres=0):
         """after the group of len(bufs) consecutive panels k, k+1, ... in one pass of depth 256 len(bufs); tile columns
         count from block k + len(bufs)"""
         ns = len(bufs)
         ctx = self.ctx_side if side else self.ctx
         ptrs = (C.c_void_p * ns)(*[b.data_ptr() for b in bufs])
         cm = (C.c_int * ns)(*[int(c) for c in cmaxs])
+        if queue_nres > 0 and not side:
+            self._chk(self.lib.tgp_dd_update_group_queued(ctx, self._p(self.A), self._p(self.d_loff), self.Np, k, self.G, self.g,
+                                                          ns, ptrs, cm, col_lo, col_hi, int(queue_nres)),
+                      "tgp_dd_update_group_queued", ctx)
+            return
         self._chk(self.lib.tgp_dd_update_group(ctx, self._p(self.A), self._p(self.d_loff), self.Np, k, self.G, self.g, ns,
                                                ptrs, cm, col_lo, col_hi), "tgp_dd_update_group", ctx)
 
@@ -425,6 +436,31 @@ class DistributedCholesky(object):
             else:
                 fn()
 
+        # Chain-bound steps (this rank's share of the bulk shorter than the panel chain that runs beside it): the bulk as a
+        # persistent grid that keeps compute units clear for the chain, whose diagonal blocks then take a unit of their own.
+        # TGP_DIST_QUEUE: -1 decide per step (default), 0 never, 1..3 always with that many units per shader engine.
+        # Rank-local decisions: no collective depends on them.
+        queue_mode = int(os.environ.get("TGP_DIST_QUEUE", "-1"))
+        chain_us = float(os.environ.get("TGP_DIST_CHAIN_US", "600")) * GS       # one group's chain beside the bulk
+        can_queue = queue_mode != 0 and hasattr(ops, "queue_reset")
+        if can_queue:
+            ops.queue_reset()
+
+        def bulk_queue_units(k):
+            """clear units per shader engine for the bulk after group k (0 = plain launch)"""
+            if not can_queue:
+                return 0
+            if queue_mode > 0:
+                return min(queue_mode, 3)
+            tiles = GS * self._local_update_flops(k + GS - 1) / (2.0 * BLK * GS * 128 * 128)
+            if tiles < 64:
+                return 0
+            tile_us = 63.0 * GS                                   # measured: 126 us per 128 x 128 tile at depth 512
+            for r in (3, 2, 1):
+                if tiles * tile_us / (512 - 64 * r) <= chain_us:
+                    return r
+            return 0
+
         ops.side_wait_main()                                     # K build (main) precedes panel 0
         with ops.on_side():
             cur_w = side_group(0, self.gathered[:GS])
@@ -437,13 +473,21 @@ class DistributedCholesky(object):
             cm = [c for _, c in cur_w]
             timed(lambda: ops.update_group(k, cur, cm, 0, 2 * GS))           # Ua: the next group's columns
             ops.side_wait_main()
+            units = bulk_queue_units(k)
+            if can_queue:
+                ops.chain_exclusive(units > 0)
             with ops.on_side():
                 nxt_w = side_group(k + GS, nxt)
-            timed(lambda: ops.update_group(k, cur, cm, 2 * GS, -1))          # Ub: the bulk
+            if units > 0:
+                timed(lambda: ops.update_group(k, cur, cm, 2 * GS, -1, queue_nres=units))   # Ub, keeping units clear
+            else:
+                timed(lambda: ops.update_group(k, cur, cm, 2 * GS, -1))      # Ub: the bulk
             self.update_flops += GS * self._local_update_flops(k + GS - 1)
             self.update_launches += 2
             cur_w, k, flip = nxt_w, k + GS, 1 - flip
         ops.main_wait_side()                                     # the last chain has no gather to wait on
+        if can_queue:
+            ops.chain_exclusive(False)
         if keep:
             ops.main_wait_keeps()                                # the replicated factor is complete before the solves
         # any rank's failure is everybody's failure; report the smallest failing index
