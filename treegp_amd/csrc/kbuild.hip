@@ -72,39 +72,9 @@ __global__ __launch_bounds__(256) void kbuild_lower_kernel(KParams p, const doub
 // rows is not part of the factor and is not written.  Gaussian kernels take their exponent pre-scaled by 0.5 log2 e and
 // 2^-s from a range-check-free polynomial (17 fp64 instructions instead of libm's ~30; <= 1 ulp): with one transcendental
 // per 8 bytes stored the first-generation kernel was as much VALU- as HBM-bound (2.2 ms of issue at N = 65 536).
-__device__ __forceinline__ double kb_exp2_neg(double s) {     // 2^(-s), s >= 0; Taylor of 2^f, |f| <= 0.5, degree 13
-    // Only full-rate fp64 adds / FMAs and one 32-bit integer op: rint, the int conversion and ldexp of the textbook form
-    // are replaced by the 1.5 * 2^52 rounding constant (the low dword of t + magic IS round(t) in two's complement) and
-    // an add into the exponent field.  The probe tools/probes/write_ceiling.hip puts the arithmetic that hides under
-    // the store stream at ~32 FMA-equivalents per element; this is 18 + 8 for the quadratic form and the amplitude.
-    // s is clamped at 1021 so that the result stays a normal number: beyond it the true value is below 4.5e-308 and
-    // 2^-1021 p stands in for it (absolute error < 4.5e-308).
-    const double magic = 6755399441055744.0;
-    const double t = -fmin(s, 1021.0);
-    const double z = t + magic;
-    const double k = z - magic;
-    const double f = t - k;
-    double p = 1.3691488853904128881e-12;
-    p = fma(p, f, 2.5678435993488205142e-11);
-    p = fma(p, f, 4.4455382718708114976e-10);
-    p = fma(p, f, 7.0549116208011233299e-9);
-    p = fma(p, f, 1.0178086009239699727e-7);
-    p = fma(p, f, 1.3215486790144309488e-6);
-    p = fma(p, f, 1.525273380405984028e-5);
-    p = fma(p, f, 1.5403530393381609954e-4);
-    p = fma(p, f, 1.3333558146428443423e-3);
-    p = fma(p, f, 9.618129107628477162e-3);
-    p = fma(p, f, 5.5504108664821579953e-2);
-    p = fma(p, f, 2.4022650695910071233e-1);
-    p = fma(p, f, 6.9314718055994530942e-1);
-    p = fma(p, f, 1.0);
-    const int ki = __double2loint(z);                       // round(t), -1021 .. 0
-    return __hiloint2double(__double2hiint(p) + (ki << 20), __double2loint(p));
-}
-
 template <int KE>
 __device__ __forceinline__ double kb_value(const KParams &p, double dx, double dy) {
-    if constexpr (KE == KE_GAUSS) return p.amp * kb_exp2_neg(quad_form(p, dx, dy));   // p.a, p.b2, p.c pre-scaled by the host
+    if constexpr (KE == KE_GAUSS) return p.amp * tgp_exp2_neg(quad_form(p, dx, dy));   // p.a, p.b2, p.c pre-scaled by the host
     else return kernel_value<KE>(p, dx, dy);
 }
 

@@ -37,6 +37,39 @@ static inline int kind_to_ke(int kind) {
     }
 }
 
+// 2^(-s) for s >= 0, <= 1 ulp
+__device__ __forceinline__ double tgp_exp2_neg(double s) {     // 2^(-s), s >= 0; Taylor of 2^f, |f| <= 0.5, degree 13
+    // fp64 adds / FMAs and one 32-bit integer op: rint, the int conversion and ldexp of the textbook form are replaced by
+    // the 1.5 * 2^52 rounding constant (the low dword of t + magic IS round(t) in two's complement) and an add into the
+    // exponent field.  Used by the K build (kbuild.hip: the probe tools/probes/write_ceiling.hip puts the arithmetic that
+    // hides under its store stream at ~32 FMA-equivalents per element; this is 18 + 8 for the quadratic form and the
+    // amplitude).  It was tried in the hope that rint / cvt / ldexp were slow instructions; they are not (the fused predict
+    // keeps the textbook form, which is one instruction shorter), so the K build's rate did not move with it either.
+    // s is clamped at 1021 so that the result stays a normal number: beyond it the true value is below 4.5e-308 and
+    // 2^-1021 p stands in for it (absolute error < 4.5e-308).
+    const double magic = 6755399441055744.0;
+    const double t = -fmin(s, 1021.0);
+    const double z = t + magic;
+    const double k = z - magic;
+    const double f = t - k;
+    double p = 1.3691488853904128881e-12;
+    p = fma(p, f, 2.5678435993488205142e-11);
+    p = fma(p, f, 4.4455382718708114976e-10);
+    p = fma(p, f, 7.0549116208011233299e-9);
+    p = fma(p, f, 1.0178086009239699727e-7);
+    p = fma(p, f, 1.3215486790144309488e-6);
+    p = fma(p, f, 1.525273380405984028e-5);
+    p = fma(p, f, 1.5403530393381609954e-4);
+    p = fma(p, f, 1.3333558146428443423e-3);
+    p = fma(p, f, 9.618129107628477162e-3);
+    p = fma(p, f, 5.5504108664821579953e-2);
+    p = fma(p, f, 2.4022650695910071233e-1);
+    p = fma(p, f, 6.9314718055994530942e-1);
+    p = fma(p, f, 1.0);
+    const int ki = __double2loint(z);                       // round(t), -1021 .. 0
+    return __hiloint2double(__double2hiint(p) + (ki << 20), __double2loint(p));
+}
+
 __device__ __forceinline__ double quad_form(const KParams &p, double dx, double dy) {
     return p.a * dx * dx + p.b2 * dx * dy + p.c * dy * dy;
 }
