@@ -139,6 +139,8 @@ void tgp_destroy(tgp_ctx *ctx) {
     if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : ctx->ev_slab)
+        if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->prof_events) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);

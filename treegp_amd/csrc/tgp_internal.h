@@ -38,6 +38,7 @@ struct tgp_ctx {
     size_t scratch_bytes = 0;
     void *scratch2 = nullptr;     // second, small scratch (partial sums) that may be live beside `scratch`
     size_t scratch2_bytes = 0;
+    hipEvent_t ev_slab[17] = {nullptr};   // slab-build pipeline (trsv.hip), created on first use
     void *vslab = nullptr;        // inverse slabs of the 1024-row triangular sweeps (trsv_big.hip) when the caller keeps none
     size_t vslab_bytes = 0;
     int dist_nqueue = 0;          // queue sets handed out since tgp_dd_queue_reset (multi-GPU driver)
@@ -158,8 +159,16 @@ int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np,
 int launch_potrs_128(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only);
 size_t vslab_bytes(int64_t Np, int S);
 int launch_vslab_build(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, int S, double *slabs);
+// slabs being built on the side stream in chunks of `chunk` super-blocks while the forward sweep already runs: ready[c] is
+// recorded behind chunk c (chunk 0 is built on the sweep's own stream)
+struct SlabPipeline {
+    int chunk;
+    hipEvent_t ready[16];
+};
+int launch_vslab_build_range(tgp_ctx *ctx, hipStream_t st, const double *d_A, const double *d_W, int64_t Np, int S, double *slabs,
+                             int64_t row_lo, int64_t row_hi);
 int launch_potrs_big(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z,
-                     bool forward_only);
+                     bool forward_only, const SlabPipeline *pipe = nullptr);
 int launch_potrs_big_multi(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_B, double *d_Z, int nrhs);
 int launch_logdet(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out);
 int launch_dot(tgp_ctx *ctx, const double *d_a, const double *d_b, int64_t n, double *d_out);

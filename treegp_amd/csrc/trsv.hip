@@ -359,11 +359,12 @@ static bool potrs_big_config(int64_t Np, int *S) {
     return big_from > 0 && Np >= big_from;
 }
 
-// the inverse slabs of this factor: the caller's cache (built on first use) or the context's buffer (rebuilt every call)
-static int acquire_slabs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, int S, double **slab_cache, double **out) {
-    bool build = true;
+// the inverse slabs of this factor: the caller's cache (built on first use) or the context's buffer (rebuilt every call).
+// *need_build says whether they have to be built now.
+static int acquire_slabs(tgp_ctx *ctx, int64_t Np, int S, double **slab_cache, double **out, bool *need_build) {
+    *need_build = true;
     if (slab_cache) {
-        if (*slab_cache) build = false;
+        if (*slab_cache) *need_build = false;
         else TGP_HIP(hipMalloc((void **)slab_cache, vslab_bytes(Np, S)));
         *out = *slab_cache;
     } else {
@@ -377,7 +378,37 @@ static int acquire_slabs(tgp_ctx *ctx, const double *d_A, const double *d_W, int
         }
         *out = (double *)ctx->vslab;
     }
-    return build ? launch_vslab_build(ctx, d_A, d_W, Np, S, *out) : 0;
+    return 0;
+}
+
+// Tried and left off (TGP_POTRS_PIPELINE=1 turns it on): the slab build is MFMA work, the sweeps are HBM streams, and step K of
+// the forward sweep needs only super-block K's slab, so the build can run on the side stream in chunks, each announced by an
+// event, while the forward sweep is already under way.  Measured: N = 65 536 7.54 vs 7.53 ms, N = 32 768 3.72 vs 2.47 ms,
+// N = 16 384 2.80 vs 0.93 ms, N = 8192 0.61 vs 0.46 ms -- a cross-stream event wait costs more than the chunk it hides.
+static int build_slabs_pipelined(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, int S, double *slabs,
+                                 SlabPipeline *pipe, bool *piped) {
+    static const bool on = getenv("TGP_POTRS_PIPELINE") && atoi(getenv("TGP_POTRS_PIPELINE")) == 1;
+    const int nS = (int)((Np + S - 1) / S);
+    *piped = on && ctx->lookahead && !ctx->ext_stream && nS >= 8;
+    if (!*piped) return launch_vslab_build(ctx, d_A, d_W, Np, S, slabs);
+    int rc = tgp_ensure_side_stream(ctx);
+    if (rc) return rc;
+    for (auto &e : ctx->ev_slab)
+        if (!e) TGP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const int nchunk = nS >= 16 ? 8 : 4;
+    pipe->chunk = (nS + nchunk - 1) / nchunk;
+    hipStream_t st = ctx->stream, sd = ctx->side_stream;
+    TGP_HIP(hipEventRecord(ctx->ev_slab[16], st));               // the factor is complete on the main stream
+    TGP_HIP(hipStreamWaitEvent(sd, ctx->ev_slab[16], 0));
+    rc = launch_vslab_build_range(ctx, st, d_A, d_W, Np, S, slabs, 0, (int64_t)pipe->chunk * S);
+    if (rc) return rc;
+    for (int c = 1; c * pipe->chunk < nS; ++c) {
+        rc = launch_vslab_build_range(ctx, sd, d_A, d_W, Np, S, slabs, (int64_t)c * pipe->chunk * S, (int64_t)(c + 1) * pipe->chunk * S);
+        if (rc) return rc;
+        pipe->ready[c] = ctx->ev_slab[c];
+        TGP_HIP(hipEventRecord(pipe->ready[c], sd));
+    }
+    return 0;
 }
 
 int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only,
@@ -387,9 +418,15 @@ int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np,
     int rc = tgp_ensure_scratch2(ctx, (size_t)Np * sizeof(double));
     if (rc) return rc;
     double *slabs = nullptr;
-    rc = acquire_slabs(ctx, d_A, d_W, Np, S, slab_cache, &slabs);
+    bool build = false, piped = false;
+    rc = acquire_slabs(ctx, Np, S, slab_cache, &slabs, &build);
     if (rc) return rc;
-    return launch_potrs_big(ctx, d_A, Np, S, slabs, d_b, (double *)ctx->scratch2, forward_only);
+    SlabPipeline pipe;
+    if (build) {
+        rc = build_slabs_pipelined(ctx, d_A, d_W, Np, S, slabs, &pipe, &piped);
+        if (rc) return rc;
+    }
+    return launch_potrs_big(ctx, d_A, Np, S, slabs, d_b, (double *)ctx->scratch2, forward_only, piped ? &pipe : nullptr);
 }
 
 int launch_potrs_multi(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_B, int nrhs, double **slab_cache) {
@@ -404,8 +441,13 @@ int launch_potrs_multi(tgp_ctx *ctx, const double *d_A, const double *d_W, int64
     int rc = tgp_ensure_scratch2(ctx, (size_t)nrhs * Np * sizeof(double));
     if (rc) return rc;
     double *slabs = nullptr;
-    rc = acquire_slabs(ctx, d_A, d_W, Np, S, slab_cache, &slabs);
+    bool build = false;
+    rc = acquire_slabs(ctx, Np, S, slab_cache, &slabs, &build);
     if (rc) return rc;
+    if (build) {
+        rc = launch_vslab_build(ctx, d_A, d_W, Np, S, slabs);
+        if (rc) return rc;
+    }
     return launch_potrs_big_multi(ctx, d_A, Np, S, slabs, d_B, (double *)ctx->scratch2, nrhs);
 }
 

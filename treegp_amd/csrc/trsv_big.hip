@@ -31,12 +31,13 @@ __device__ __forceinline__ int64_t slab_off(int64_t Np, int64_t row, int lcol) {
 // V diagonal 128-blocks <- W, Vt diagonal 128-blocks <- W^T, and zeros in the sibling corner of each 256 x 256 diagonal block
 // that the 256-deep products and the GEMVs read but nothing writes (V: upper right, Vt: lower left).  One workgroup per block.
 __global__ __launch_bounds__(256) void vinit_kernel(const double *__restrict__ W, double *__restrict__ V, double *__restrict__ Vt,
-                                                    int64_t Np, int S) {
+                                                    int64_t Np, int S, int boff) {
     __shared__ double T[128 * 129];
     const int tid = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * 128;
+    const int blk = blockIdx.x + boff;               // 128-row block; a launch covers the blocks of a range of super-blocks
+    const int64_t r0 = (int64_t)blk * 128;
     const int lc0 = (int)(r0 % S);
-    const bool odd = (blockIdx.x & 1) != 0;
+    const bool odd = (blk & 1) != 0;
     const double *src = W + r0 * 128;
     const int c = (tid & 63) * 2, rr = tid >> 6;
     const double2 zero = make_double2(0.0, 0.0);
@@ -75,10 +76,11 @@ struct Prod {
 };
 // r16: rows of C per workgroup (128 for the big tile, 16 for the latency tile)
 template <int KD, bool XPROD>
-__device__ __forceinline__ Prod level_prod(const double *A, double *V, const double *Vt, double *TT, int64_t Np, int S, int h, int crows) {
+__device__ __forceinline__ Prod level_prod(const double *A, double *V, const double *Vt, double *TT, int64_t Np, int S, int h, int crows,
+                                           int qoff) {
     const int nti = h >> 7, ntr = h / crows;          // column tiles (128 wide), row slices
     const int t = blockIdx.x % (nti * ntr);
-    const int64_t o = (int64_t)(blockIdx.x / (nti * ntr)) * 2 * h;
+    const int64_t o = (int64_t)(blockIdx.x / (nti * ntr) + qoff) * 2 * h;
     const int lo = (int)(o % S);
     const int rs = (t / nti) * crows, cs = (t % nti) * 128;      // row / column offset of this tile inside the h x h block
     Prod p;
@@ -110,8 +112,8 @@ __device__ __forceinline__ Prod level_prod(const double *A, double *V, const dou
 
 template <int KD, bool XPROD>
 __global__ __launch_bounds__(256) void vprod_kernel(const double *__restrict__ A, double *V, const double *Vt, double *TT, int64_t Np,
-                                                    int S, int h) {
-    const Prod p = level_prod<KD, XPROD>(A, V, Vt, TT, Np, S, h, 128);
+                                                    int S, int h, int qoff) {
+    const Prod p = level_prod<KD, XPROD>(A, V, Vt, TT, Np, S, h, 128, qoff);
     if (!p.valid) return;
     gemm_tile_128<XPROD ? 2 : 0, TGP_PW, KD, TileDefault, 0>(p.a, p.b, p.c, nullptr, nullptr, nullptr, p.nseg, p.sa, p.sb);
 }
@@ -120,18 +122,19 @@ __global__ __launch_bounds__(256) void vprod_kernel(const double *__restrict__ A
 // takes 60 - 100 us, which is what a level costs when the matrix has too few tiles to fill the chip
 template <int KD, bool XPROD>
 __global__ __launch_bounds__(256) void vprod_small_kernel(const double *__restrict__ A, double *V, const double *Vt, double *TT,
-                                                          int64_t Np, int S, int h) {
-    const Prod p = level_prod<KD, XPROD>(A, V, Vt, TT, Np, S, h, 16);
+                                                          int64_t Np, int S, int h, int qoff) {
+    const Prod p = level_prod<KD, XPROD>(A, V, Vt, TT, Np, S, h, 16, qoff);
     if (!p.valid) return;
     if (p.nseg >= 2) nt_small_tile<XPROD ? 2 : 0, KD, 2>(p.a, 256, p.b, 256, p.c, 256, p.a + p.sa, p.b + p.sb);
     else nt_small_tile<XPROD ? 2 : 0, KD, 1>(p.a, 256, p.b, 256, p.c, 256, nullptr, nullptr);
 }
 
 // Vt(o + cs + c, lo + h + rs + r) = V(o + h + rs + r, lo + cs + c) for the 128 x 128 tiles of the h x h off-diagonal block
-__global__ __launch_bounds__(256) void vtrans_kernel(const double *__restrict__ V, double *__restrict__ Vt, int64_t Np, int S, int h) {
+__global__ __launch_bounds__(256) void vtrans_kernel(const double *__restrict__ V, double *__restrict__ Vt, int64_t Np, int S, int h,
+                                                     int qoff) {
     __shared__ double T[128 * 129];
     const int nt = h >> 7, t = blockIdx.x % (nt * nt);
-    const int64_t o = (int64_t)(blockIdx.x / (nt * nt)) * 2 * h;
+    const int64_t o = (int64_t)(blockIdx.x / (nt * nt) + qoff) * 2 * h;
     const int lo = (int)(o % S), rs = (t / nt) * 128, cs = (t % nt) * 128;
     if (o + h + rs >= Np) return;
     const int tid = threadIdx.x, c = (tid & 63) * 2, rr = tid >> 6;
@@ -352,37 +355,46 @@ __global__ __launch_bounds__(512) void bulk_bwd_kernel(const double *__restrict_
 size_t vslab_bytes(int64_t Np, int S) { return (size_t)3 * Np * S * sizeof(double); }
 
 // slabs: [V | Vt | TT], each Np x S.  Nothing is cleared: every part a later kernel reads is written first (vinit_kernel's
-// corner blocks, the level products, the transposing copies).
-int launch_vslab_build(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, int S, double *slabs) {
-    hipStream_t st = ctx->stream;
+// corner blocks, the level products, the transposing copies).  Builds the slabs of rows [row_lo, row_hi) (multiples of S, or
+// Np) on stream `st`: super-blocks are independent of each other.
+int launch_vslab_build_range(tgp_ctx *ctx, hipStream_t st, const double *d_A, const double *d_W, int64_t Np, int S, double *slabs,
+                             int64_t row_lo, int64_t row_hi) {
     double *V = slabs, *Vt = slabs + Np * S, *TT = slabs + 2 * Np * S;
-    vinit_kernel<<<(unsigned)(Np / 128), 256, 0, st>>>(d_W, V, Vt, Np, S);
+    if (row_hi > Np) row_hi = Np;
+    if (row_hi <= row_lo) return 0;
+    const int64_t span = row_hi - row_lo;
+    vinit_kernel<<<(unsigned)(span / 128), 256, 0, st>>>(d_W, V, Vt, Np, S, (int)(row_lo / 128));
     static const int64_t small_below = getenv("TGP_VSLAB_SMALL_BELOW") ? atoll(getenv("TGP_VSLAB_SMALL_BELOW")) : 12288;
     for (int h = 128; h < S && h < Np; h *= 2) {
         const int nt = h / 128;
-        const unsigned nq = (unsigned)((Np + 2 * h - 1) / (2 * h));
+        const unsigned nq = (unsigned)((span + 2 * h - 1) / (2 * h));
+        const int qoff = (int)(row_lo / (2 * h));
         const unsigned grid = nq * nt * nt;
         const bool small = Np < small_below && h <= 512;         // the latency tile takes at most two 256-deep segments
         const unsigned sgrid = nq * nt * (h / 16);
         if (h == 128) {
             if (small) {
-                vprod_small_kernel<128, false><<<sgrid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h);
-                vprod_small_kernel<128, true><<<sgrid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h);
+                vprod_small_kernel<128, false><<<sgrid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h, qoff);
+                vprod_small_kernel<128, true><<<sgrid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h, qoff);
             } else {
-                vprod_kernel<128, false><<<grid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h);
-                vprod_kernel<128, true><<<grid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h);
+                vprod_kernel<128, false><<<grid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h, qoff);
+                vprod_kernel<128, true><<<grid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h, qoff);
             }
         } else if (small) {
-            vprod_small_kernel<256, false><<<sgrid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h);
-            vprod_small_kernel<256, true><<<sgrid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h);
+            vprod_small_kernel<256, false><<<sgrid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h, qoff);
+            vprod_small_kernel<256, true><<<sgrid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h, qoff);
         } else {
-            vprod_kernel<256, false><<<grid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h);
-            vprod_kernel<256, true><<<grid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h);
+            vprod_kernel<256, false><<<grid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h, qoff);
+            vprod_kernel<256, true><<<grid, 256, 0, st>>>(d_A, V, Vt, TT, Np, S, h, qoff);
         }
-        vtrans_kernel<<<grid, 256, 0, st>>>(V, Vt, Np, S, h);
+        vtrans_kernel<<<grid, 256, 0, st>>>(V, Vt, Np, S, h, qoff);
     }
     TGP_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_vslab_build(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, int S, double *slabs) {
+    return launch_vslab_build_range(ctx, ctx->stream, d_A, d_W, Np, S, slabs, 0, Np);
 }
 
 namespace {
@@ -404,12 +416,14 @@ void launch_bulk_fwd(hipStream_t st, const double *d_A, int64_t Np, int p0, int 
 // NR right-hand sides (vectors at stride vs in d_b and d_z) through both sweeps
 template <int NR>
 int potrs_big_nr(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z, int64_t vs,
-                 bool forward_only) {
+                 bool forward_only, const SlabPipeline *pipe = nullptr) {
     hipStream_t st = ctx->stream;
     const double *V = slabs, *Vt = slabs + Np * S;
     const int nS = (int)((Np + S - 1) / S);
     const int NPmax = S / 256;
     for (int K = 0; K < nS; ++K) {
+        // slabs built beside this sweep (launch_potrs): super-block K's chunk has to be there
+        if (pipe && K > 0 && K % pipe->chunk == 0) TGP_HIP(hipStreamWaitEvent(st, pipe->ready[K / pipe->chunk], 0));
         const int64_t r0 = (int64_t)K * S;
         const int rows = (int)((Np - r0) < S ? (Np - r0) : S);
         launch_diag_gemv<false, NR>(st, NPmax, V, Np, r0, rows, d_b, d_z, vs);
@@ -447,8 +461,8 @@ int potrs_big_nr(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const doubl
 
 // d_b (Np) <- L^-T L^-1 d_b (or L^-1 d_b when forward_only) with the slabs of this factor; d_z: Np doubles of scratch
 int launch_potrs_big(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z,
-                     bool forward_only) {
-    return potrs_big_nr<1>(ctx, d_A, Np, S, slabs, d_b, d_z, Np, forward_only);
+                     bool forward_only, const SlabPipeline *pipe) {
+    return potrs_big_nr<1>(ctx, d_A, Np, S, slabs, d_b, d_z, Np, forward_only, pipe);
 }
 
 // nrhs right-hand sides, rows of d_B (nrhs, Np), in groups of 4, 2, 1; d_Z: scratch of the same shape
