@@ -21,7 +21,11 @@
 
 #define K56_XMAX 697.8738840444552
 
-__host__ __device__ __forceinline__ double vonkarman_unit(double u) {
+// `cheb`: where the 6 x K56_NDEG Chebyshev table is read from.  The octave index differs from lane to lane, so on the device
+// every coefficient fetch is a gather; from global memory that is 24 gathers per element and costs more than the ~120
+// fp64 operations around them -- kernels that evaluate many elements per workgroup stage the table (1.2 KB) in LDS with
+// vonkarman_stage_table and pass that copy.
+__host__ __device__ __forceinline__ double vonkarman_unit_tab(double u, const double *cheb) {
     if (u == 0.0) return 1.0;
     const double x = K56_TWO_PI * u;
     if (x <= 1.0) {
@@ -46,7 +50,7 @@ __host__ __device__ __forceinline__ double vonkarman_unit(double u) {
         idx = 5;
         z = 64.0 / x - 1.0;                   // (-1, 1]
     }
-    const double *c = k56_cheb[idx];
+    const double *c = cheb + idx * K56_NDEG;
     const double z2 = z + z;
     double b1 = 0.0, b2 = 0.0;
 #pragma unroll
@@ -58,3 +62,13 @@ __host__ __device__ __forceinline__ double vonkarman_unit(double u) {
     const double g = fma(z, b1, c[0]) - b2;
     return (K56_PRE * cbrt(u)) * exp(-x) * g;
 }
+
+__host__ __device__ __forceinline__ double vonkarman_unit(double u) { return vonkarman_unit_tab(u, &k56_cheb[0][0]); }
+
+#ifdef __HIPCC__
+// copy the table into `lds` (6 * K56_NDEG doubles); the caller synchronises the workgroup afterwards
+__device__ __forceinline__ void vonkarman_stage_table(double *lds) {
+    for (int i = threadIdx.x; i < 6 * K56_NDEG; i += blockDim.x) lds[i] = (&k56_cheb[0][0])[i];
+}
+#endif
+

@@ -73,9 +73,9 @@ __global__ __launch_bounds__(256) void kbuild_lower_kernel(KParams p, const doub
 // 2^-s from a range-check-free polynomial (17 fp64 instructions instead of libm's ~30; <= 1 ulp): with one transcendental
 // per 8 bytes stored the first-generation kernel was as much VALU- as HBM-bound (2.2 ms of issue at N = 65 536).
 template <int KE>
-__device__ __forceinline__ double kb_value(const KParams &p, double dx, double dy) {
+__device__ __forceinline__ double kb_value(const KParams &p, double dx, double dy, const double *tab) {
     if constexpr (KE == KE_GAUSS) return p.amp * tgp_exp2_neg(quad_form(p, dx, dy));   // p.a, p.b2, p.c pre-scaled by the host
-    else return kernel_value<KE>(p, dx, dy);
+    else return kernel_value_tab<KE>(p, dx, dy, tab);                                   // von Karman: Chebyshev table in LDS
 }
 
 __device__ __forceinline__ void kb_store(double *dst, const double2 &v) {
@@ -91,6 +91,11 @@ template <int KE>
 __global__ __launch_bounds__(256) void kbuild_slab_kernel(KParams p, const double *__restrict__ X, int64_t n, int64_t Np,
                                                           const double *__restrict__ yerr, double *__restrict__ A) {
     constexpr int SR = 64;                                   // rows per workgroup
+    __shared__ double vk_tab[KE == KE_GAUSS ? 1 : 6 * K56_NDEG];
+    if constexpr (KE != KE_GAUSS) {
+        vonkarman_stage_table(vk_tab);
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // slabs before panel q: 4 (q P - q (q - 1) / 2) with P panels in all
@@ -128,8 +133,8 @@ __global__ __launch_bounds__(256) void kbuild_slab_kernel(KParams p, const doubl
             const double xi = X[2 * ic], yi = X[2 * ic + 1];                       // wave-uniform
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                v[h].x = kb_value<KE>(p, xi - xj[h][0], yi - yj[h][0]);
-                v[h].y = kb_value<KE>(p, xi - xj[h][1], yi - yj[h][1]);
+                v[h].x = kb_value<KE>(p, xi - xj[h][0], yi - yj[h][0], vk_tab);
+                v[h].y = kb_value<KE>(p, xi - xj[h][1], yi - yj[h][1], vk_tab);
             }
             if (diag_slab) {
                 // exact diagonal (kernels.py:121) + noise (gp_interp.py:180)

@@ -74,6 +74,18 @@ __device__ __forceinline__ double quad_form(const KParams &p, double dx, double 
     return p.a * dx * dx + p.b2 * dx * dy + p.c * dy * dy;
 }
 
+// the same with the von Karman Chebyshev table read from `tab` (an LDS copy, bessel_k56.h); tab is ignored for Gaussians
+template <int KE>
+__device__ __forceinline__ double kernel_value_tab(const KParams &p, double dx, double dy, const double *tab) {
+    if constexpr (KE == KE_GAUSS) {
+        return p.amp * exp(-0.5 * (p.a * dx * dx + p.b2 * dx * dy + p.c * dy * dy));
+    } else if constexpr (KE == KE_VK) {
+        return p.amp * vonkarman_unit_tab(sqrt(dx * dx + dy * dy) * p.inv_ell, tab);
+    } else {
+        return p.amp * vonkarman_unit_tab(sqrt(p.a * dx * dx + p.b2 * dx * dy + p.c * dy * dy), tab);
+    }
+}
+
 // value WITHOUT the amplitude; coincident points give exactly 1
 template <int KE>
 __device__ __forceinline__ double kernel_unit(const KParams &p, double dx, double dy) {

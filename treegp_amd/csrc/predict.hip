@@ -19,6 +19,8 @@ __global__ __launch_bounds__(256) void predict_partial_kernel(KParams p, const d
                                                               const double *__restrict__ Xs, int64_t m,
                                                               double *__restrict__ partial, int64_t chunk) {
     __shared__ double sx[PT], sy[PT], sa[PT];
+    __shared__ double vk_tab[KE == KE_GAUSS ? 1 : 6 * K56_NDEG];       // von Karman: the Chebyshev table, gathered per lane
+    if constexpr (KE != KE_GAUSS) vonkarman_stage_table(vk_tab);       // (the first barrier of the loop below publishes it)
     const int tid = threadIdx.x;
     const int64_t q = (int64_t)blockIdx.x * 256 + tid;
     const int64_t i_begin = (int64_t)blockIdx.y * chunk;
@@ -35,9 +37,9 @@ __global__ __launch_bounds__(256) void predict_partial_kernel(KParams p, const d
         const int cnt = (int)((i_end - i0 < PT) ? (i_end - i0) : PT);
         if (cnt == PT) {
 #pragma unroll 4
-            for (int t = 0; t < PT; ++t) acc += kernel_value<KE>(p, xq - sx[t], yq - sy[t]) * sa[t];
+            for (int t = 0; t < PT; ++t) acc += kernel_value_tab<KE>(p, xq - sx[t], yq - sy[t], vk_tab) * sa[t];
         } else {
-            for (int t = 0; t < cnt; ++t) acc += kernel_value<KE>(p, xq - sx[t], yq - sy[t]) * sa[t];
+            for (int t = 0; t < cnt; ++t) acc += kernel_value_tab<KE>(p, xq - sx[t], yq - sy[t], vk_tab) * sa[t];
         }
     }
     if (q < m) partial[(int64_t)blockIdx.y * m + q] = acc;
