@@ -416,7 +416,7 @@ int tgp_factor_solve(tgp_ctx *ctx, tgp_factor *f, const double *B, int nrhs, dou
     TGP_HIP(hipMemsetAsync(d_B, 0, (size_t)nrhs * Np * 8, st));
     TGP_HIP(hipMemcpy2DAsync(d_B, (size_t)Np * 8, B, (size_t)n * 8, (size_t)n * 8, (size_t)nrhs, hipMemcpyHostToDevice, st));
     TGP_HIP(hipEventRecord(ctx->ev[0], st));
-    rc = launch_potrs_multi(ctx, f->d_A, f->d_W, Np, d_B, nrhs, &f->d_slabs);
+    rc = launch_potrs_multi(ctx, f->d_A, f->d_W, Np, d_B, nrhs, &f->d_slabs, &f->slab_S);
     if (rc) return rc;
     TGP_HIP(hipEventRecord(ctx->ev[1], st));
     TGP_HIP(hipMemcpy2DAsync(Xout, (size_t)n * 8, d_B, (size_t)Np * 8, (size_t)n * 8, (size_t)nrhs, hipMemcpyDeviceToHost, st));

@@ -56,6 +56,7 @@ struct tgp_factor {
     double *d_A = nullptr;        // packed lower panels
     double *d_W = nullptr;        // inverted 128x128 diagonal blocks
     double *d_slabs = nullptr;    // inverse slabs of the big-step sweeps, built by the first solve with this factor
+    int slab_S = 0;               // the step they were built for
 };
 
 #define TGP_HIP(call)                                                                   \
@@ -155,7 +156,7 @@ int launch_logdet_dist(tgp_ctx *ctx, const double *d_Aloc, const int64_t *d_loff
 // slab_cache: where the caller keeps this factor's inverse slabs (built on first use, owned by the caller: hipFree);
 // nullptr = rebuild them into the context's own buffer on every call
 int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only = false,
-                 double **slab_cache = nullptr);
+                 double **slab_cache = nullptr, int *slab_S = nullptr);
 int launch_potrs_128(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only);
 size_t vslab_bytes(int64_t Np, int S);
 int launch_vslab_build(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, int S, double *slabs);
@@ -181,4 +182,5 @@ int launch_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t
 int launch_unpack_lower(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out);
 int launch_pack_lower(tgp_ctx *ctx, const double *d_K, int64_t n, int64_t Np, const double *d_yerr, double *d_A);
 // d_B: (nrhs, Np) right-hand sides, solved in place, the factor read once per sweep for groups of up to 8 of them
-int launch_potrs_multi(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_B, int nrhs, double **slab_cache);
+int launch_potrs_multi(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_B, int nrhs, double **slab_cache,
+                       int *slab_S = nullptr);

@@ -361,11 +361,17 @@ static bool potrs_big_config(int64_t Np, int *S) {
 
 // the inverse slabs of this factor: the caller's cache (built on first use) or the context's buffer (rebuilt every call).
 // *need_build says whether they have to be built now.
-static int acquire_slabs(tgp_ctx *ctx, int64_t Np, int S, double **slab_cache, double **out, bool *need_build) {
+static int acquire_slabs(tgp_ctx *ctx, int64_t Np, int S, double **slab_cache, int *slab_S, double **out, bool *need_build) {
     *need_build = true;
     if (slab_cache) {
+        if (*slab_cache && slab_S && *slab_S != S) {             // built for another step (TGP_POTRS_STEP changed): start over
+            TGP_HIP(hipStreamSynchronize(ctx->stream));
+            TGP_HIP(hipFree(*slab_cache));
+            *slab_cache = nullptr;
+        }
         if (*slab_cache) *need_build = false;
         else TGP_HIP(hipMalloc((void **)slab_cache, vslab_bytes(Np, S)));
+        if (slab_S) *slab_S = S;
         *out = *slab_cache;
     } else {
         const size_t need = vslab_bytes(Np, S);
@@ -412,14 +418,14 @@ static int build_slabs_pipelined(tgp_ctx *ctx, const double *d_A, const double *
 }
 
 int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only,
-                 double **slab_cache) {
+                 double **slab_cache, int *slab_S) {
     int S;
     if (!potrs_big_config(Np, &S)) return launch_potrs_128(ctx, d_A, d_W, Np, d_b, forward_only);
     int rc = tgp_ensure_scratch2(ctx, (size_t)Np * sizeof(double));
     if (rc) return rc;
     double *slabs = nullptr;
     bool build = false, piped = false;
-    rc = acquire_slabs(ctx, Np, S, slab_cache, &slabs, &build);
+    rc = acquire_slabs(ctx, Np, S, slab_cache, slab_S, &slabs, &build);
     if (rc) return rc;
     SlabPipeline pipe;
     if (build) {
@@ -429,7 +435,8 @@ int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np,
     return launch_potrs_big(ctx, d_A, Np, S, slabs, d_b, (double *)ctx->scratch2, forward_only, piped ? &pipe : nullptr);
 }
 
-int launch_potrs_multi(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_B, int nrhs, double **slab_cache) {
+int launch_potrs_multi(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_B, int nrhs, double **slab_cache,
+                       int *slab_S) {
     int S;
     if (!potrs_big_config(Np, &S)) {
         for (int v = 0; v < nrhs; ++v) {
@@ -442,7 +449,7 @@ int launch_potrs_multi(tgp_ctx *ctx, const double *d_A, const double *d_W, int64
     if (rc) return rc;
     double *slabs = nullptr;
     bool build = false;
-    rc = acquire_slabs(ctx, Np, S, slab_cache, &slabs, &build);
+    rc = acquire_slabs(ctx, Np, S, slab_cache, slab_S, &slabs, &build);
     if (rc) return rc;
     if (build) {
         rc = launch_vslab_build(ctx, d_A, d_W, Np, S, slabs);
