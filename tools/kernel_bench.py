@@ -20,7 +20,7 @@ def out(**kw):
     print(json.dumps(kw), flush=True)
 
 
-def kbuild(kind, n, reps=3):
+def kbuild(kind, n, reps=12):
     X, y, y_err, _ = star_field(n, 16)
     iL = headline_invlam()
     if kind == "gauss":
