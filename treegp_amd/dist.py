@@ -69,7 +69,7 @@ class TorchComm(object):
         """Non-blocking all-gather where the backend has one (RCCL runs it on its own stream, so it
         overlaps the kernels queued behind it); returns an object with .wait()."""
         if self.native_gather:
-            return self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
+            return _Work(self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True), out)
         self.all_gather(out, inp)
         return _Done(out)
 
@@ -86,12 +86,23 @@ class TorchComm(object):
                 self.dist.broadcast(chunk, src=r, group=self.group)
 
 
+class _Work(object):
+    """An asynchronous gather in flight (torch.distributed Work) and the tensor it fills."""
+
+    def __init__(self, work, tensor):
+        self.work, self.tensor = work, tensor
+
+    def wait(self):
+        self.work.wait()
+
+
 class _Done(object):
     """Handle of a gather that was issued synchronously on the then-current stream: wait() orders the
     now-current stream behind it (no-op for CPU tensors)."""
 
     def __init__(self, tensor=None):
         self.ev = None
+        self.tensor = tensor                 # where the gathered panel is to be read from
         if tensor is not None and getattr(tensor, "is_cuda", False):
             import torch
             self.ev = torch.cuda.Event()
@@ -109,8 +120,9 @@ class SelfComm(object):
     rank, size = 0, 1
 
     def all_gather_start(self, out, inp):
-        self.all_gather(out, inp)
-        return _Done(out)
+        # the "gathered" panel of a world of one is the rank's own rows, in the very layout they are stored in: no copy --
+        # the update reads them where they are (17 GB of copies per factorisation at N = 65 536 otherwise, 77 ms)
+        return _Done(inp)
 
     def broadcast(self, t, src):
         pass
@@ -402,7 +414,7 @@ class DistributedCholesky(object):
                 return None, 0
             cmax = -(-rem // G)                                  # most blocks > k any rank holds
             send = ops.panel_send_view(k, cmax)
-            return comm.all_gather_start(buf[:G * cmax * BLK * BLK], send), cmax
+            return comm.all_gather_start(buf[:G * cmax * BLK * BLK], send), cmax     # the handle knows where the panel lands
 
         keep_events = {}                                         # id(first buffer of a set) -> event after that set's keeps
 
@@ -418,10 +430,10 @@ class DistributedCholesky(object):
                     w, c = out[j - 1]
                     w.wait()                                     # side stream: panel k+j-1 is on every rank
                     # panel k+j's two tile columns against the j panels before it, one launch of depth 256 j
-                    ops.update_group(k, bufs[:j], [oc for _, oc in out], 0, 2, side=True)
+                    ops.update_group(k, [ow.tensor for ow, _ in out], [oc for _, oc in out], 0, 2, side=True)
                 out.append(factor_and_gather(k + j, bufs[j]))
                 if keep and out[-1][0] is not None:
-                    ops.keep_rows(k + j, bufs[j], out[-1][1], out[-1][0])   # copied on the keep stream, off this chain
+                    ops.keep_rows(k + j, out[-1][0].tensor, out[-1][1], out[-1][0])   # copied on the keep stream, off this chain
             if keep:
                 keep_events[id(bufs[0])] = ops.keeps_done()
             return out
@@ -471,6 +483,7 @@ class DistributedCholesky(object):
             for w, _ in cur_w:
                 w.wait()                                         # main stream: the whole group is on every rank
             cm = [c for _, c in cur_w]
+            cur = [w.tensor for w, _ in cur_w]                   # where each gathered panel of the group is (see _Done / _Work)
             timed(lambda: ops.update_group(k, cur, cm, 0, 2 * GS))           # Ua: the next group's columns
             ops.side_wait_main()
             units = bulk_queue_units(k)
