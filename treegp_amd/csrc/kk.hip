@@ -87,6 +87,15 @@ __global__ __launch_bounds__(256) void kk_pairs_kernel(KKArgs a, double *__restr
     const int tid = threadIdx.x, wave = tid >> 6;
     double *myh = hist + (size_t)wave * NACC * nb;
     for (int t = tid; t < 4 * NACC * nb; t += 256) hist[t] = 0.0;
+    constexpr int NTOP = 4;                       // Log bins kept in registers (see the pair loop)
+    const int topbase = a.nbins - NTOP;           // may be negative for fewer than NTOP bins: those slots then stay empty
+    double racc[TWOD ? 1 : NTOP][5];
+    if constexpr (!TWOD) {
+#pragma unroll
+        for (int q = 0; q < NTOP; ++q)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) racc[q][c] = 0.0;
+    }
 
     const int64_t boot = blockIdx.z;
     const int64_t *idx = a.idx ? a.idx + boot * a.n : nullptr;
@@ -151,18 +160,50 @@ __global__ __launch_bounds__(256) void kk_pairs_kernel(KKArgs a, double *__restr
             } else {
                 if (t >= t0 && rsq >= a.minsq && rsq < a.maxsq) {
                     const double lr = 0.5 * log(rsq);
-                    const int b = (int)((lr - a.lmin) / a.bs);
+                    const int b = bin_of(lr - a.lmin, a.bs, a.inv_bs);      // = (int)((lr - lmin) / bs), dividing only next to an edge
                     if (b >= 0 && b < a.nbins) {
                         const double ww = wi * sw[t];
-                        lds_add(myh + b, ww * (ki * sk[t]));
-                        lds_add(myh + nb + b, ww);
-                        lds_add(myh + 2 * nb + b, ww * sqrt(rsq));
-                        lds_add(myh + 3 * nb + b, ww * lr);
-                        lds_add(myh + 4 * nb + b, 1.0);
+                        const double v0 = ww * (ki * sk[t]), v2 = ww * sqrt(rsq), v3 = ww * lr;
+                        // Log bins of a 2-D field are crowded at the top (populations grow like r^2: the last four of 20 bins
+                        // take ~85 % of the pairs) and same-address fp64 LDS atomics retire one lane per clock: the kernel sat
+                        // exactly on that ceiling (tools/probes/lds_atomic_ceiling.hip).  The top NTOP bins are therefore
+                        // accumulated in registers, one set per lane, with 0/1 weights (5 FMAs per bin and pair, no
+                        // divergence), and only the other bins go through the LDS atomics.
+                        const int k = b - topbase;
+                        if (k >= 0) {
+#pragma unroll
+                            for (int q = 0; q < NTOP; ++q) {
+                                const double m = (k == q) ? 1.0 : 0.0;
+                                racc[q][0] = fma(m, v0, racc[q][0]);
+                                racc[q][1] = fma(m, ww, racc[q][1]);
+                                racc[q][2] = fma(m, v2, racc[q][2]);
+                                racc[q][3] = fma(m, v3, racc[q][3]);
+                                racc[q][4] += m;
+                            }
+                        } else {
+                            lds_add(myh + b, v0);
+                            lds_add(myh + nb + b, ww);
+                            lds_add(myh + 2 * nb + b, v2);
+                            lds_add(myh + 3 * nb + b, v3);
+                            lds_add(myh + 4 * nb + b, 1.0);
+                        }
                     }
                 }
             }
         }
+    }
+    if constexpr (!TWOD) {
+        // the lanes' register accumulators: fixed-order butterfly over the wave, lane 0 adds them to the wave's histogram
+        // (nobody else touches it: the LDS atomics of this wave are complete in program order)
+#pragma unroll
+        for (int q = 0; q < NTOP; ++q)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                double v = racc[q][c];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if ((tid & 63) == 0 && topbase + q >= 0 && v != 0.0) lds_add(myh + c * nb + topbase + q, v);
+            }
     }
     __syncthreads();
     double *o = out + (size_t)boot * NACC * nb;
