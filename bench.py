@@ -286,6 +286,12 @@ def main():
             out["roofline_trsv"] = {"bound": "hbm", "achieved": tr_rate, "peak": 8000.0, "unit": "GB/s", "frac": tr_rate / 8000.0,
                                     "traffic": None, "algorithmic_bytes": tr_bytes, "kernel": "potrs: forward + backward sweep",
                                     "avg_ms": acc["trsv_ms"] / K}
+            # the fused predict is fp64-VALU-bound, 30 algorithmic flops per (query, training point) pair
+            m_rank = m if world == 1 else -(-m // world)
+            pr_tf = 30.0 * m_rank * n * K / (acc["predict_ms"] * 1e-3) / 1e12
+            out["roofline_predict"] = {"bound": "valu", "achieved": pr_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": pr_tf / 78.6,
+                                       "pairs_per_sec": m_rank * n * K / (acc["predict_ms"] * 1e-3),
+                                       "kernel": "predict_gauss_fast_kernel", "avg_ms": acc["predict_ms"] / K}
             out["phases_ms_per_step"] = {k: acc[k] / K for k in ("kbuild_ms", "chol_ms", "trsv_ms", "predict_ms", "syrk_ms")}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 4 * args.cpu_sample, n)

@@ -154,3 +154,32 @@ def test_big_step_sweeps_match_block_chain(n, monkeypatch):
     np.testing.assert_allclose(l1, l0, rtol=1e-12)
     for b in (dX, de, dA, dW):
         b.free()
+
+
+def test_ml_fit_with_a_scikit_learn_only_kernel():
+    """optimizer="log-likelihood" on a kernel tree the device kernels cannot describe (Sum with a fitted WhiteKernel): every
+    likelihood evaluation goes through the dense route; the result is checked against the same likelihood evaluated with
+    NumPy / SciPy on the host at the fitted theta, and the fit has to improve on its starting point."""
+    import treegp_amd as treegp
+    from scipy.linalg import cho_factor, cho_solve
+    rng = np.random.default_rng(17)
+    n = 300
+    X = rng.uniform(0, 1, (n, 2))
+    truth = treegp.eval_kernel("0.8**2 * RBF(0.2) + WhiteKernel(0.05**2)")
+    y = rng.multivariate_normal(np.zeros(n), truth(X))
+    y_err = np.full(n, 1e-3)
+    gp = treegp.GPInterpolation(kernel="0.5**2 * RBF(0.4) + WhiteKernel(0.2**2)", optimizer="log-likelihood", normalize=False)
+    gp.initialize(X, y, y_err=y_err)
+    l0 = gp.return_log_likelihood()
+    gp.solve()
+    l1 = gp.return_log_likelihood()
+    assert l1 > l0 + 1.0
+
+    def host_logl(kernel):
+        K = kernel(X) + np.diag(y_err ** 2)
+        c = cho_factor(K, lower=True)
+        return -0.5 * y @ cho_solve(c, y) - 0.5 * n * np.log(2 * np.pi) - np.sum(np.log(np.diag(c[0])))
+    np.testing.assert_allclose(l1, host_logl(gp.kernel), rtol=1e-10)
+    np.testing.assert_allclose(gp._optimizer._logL, l1, rtol=1e-12)
+    # the fitted noise level is in the right decade
+    assert 0.01 < np.sqrt(gp.kernel.k2.noise_level) < 0.2
