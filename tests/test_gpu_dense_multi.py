@@ -183,3 +183,34 @@ def test_ml_fit_with_a_scikit_learn_only_kernel():
     np.testing.assert_allclose(gp._optimizer._logL, l1, rtol=1e-12)
     # the fitted noise level is in the right decade
     assert 0.01 < np.sqrt(gp.kernel.k2.noise_level) < 0.2
+
+
+def test_device_level_multi_rhs_entry_point():
+    """tgp_d_potrs_multi on device pointers (what a multi-GPU driver or a resident pipeline calls): every row equals
+    tgp_d_potrs on that row, below and above the big-step threshold."""
+    import ctypes as C
+    from treegp_amd import _lib, ops
+    from treegp_amd.synthetic import star_field, headline_invlam
+    lib, ctx = _lib.load_library(), _lib.get_ctx()
+    iL = headline_invlam()
+    spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=iL[0, 0], b=iL[0, 1], c=iL[1, 1])
+    for n, nrhs in ((700, 3), (3300, 6)):
+        X, y, y_err, _ = star_field(n, 8, seed=n)
+        Np = lib.tgp_padded_n(n)
+        dX = ops.DeviceBuffer.from_array(ctx, X); de = ops.DeviceBuffer.from_array(ctx, y_err)
+        dA = ops.DeviceBuffer(ctx, lib.tgp_panel_elems(Np) * 8); dW = ops.DeviceBuffer(ctx, Np * 128 * 8)
+        _lib.check(ctx, lib.tgp_d_kbuild_lower(ctx, C.byref(spec.to_c()), dX.ptr, n, de.ptr, dA.ptr), "kbuild")
+        assert lib.tgp_d_potrf(ctx, dA.ptr, Np, dW.ptr) == 0
+        B = np.zeros((nrhs, Np))
+        B[:, :n] = np.random.default_rng(n).standard_normal((nrhs, n))
+        dB = ops.DeviceBuffer.from_array(ctx, B)
+        _lib.check(ctx, lib.tgp_d_potrs_multi(ctx, dA.ptr, dW.ptr, Np, dB.ptr, nrhs), "potrs_multi")
+        got = dB.to_array((nrhs, Np))
+        for v in range(nrhs):
+            db = ops.DeviceBuffer.from_array(ctx, B[v])
+            _lib.check(ctx, lib.tgp_d_potrs(ctx, dA.ptr, dW.ptr, Np, db.ptr), "potrs")
+            ref = db.to_array(Np)
+            db.free()
+            np.testing.assert_allclose(got[v], ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+        for b in (dX, de, dA, dW, dB):
+            b.free()
