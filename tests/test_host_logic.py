@@ -289,3 +289,17 @@ def test_robust_2dfit_minuit_plumbing(fake, monkeypatch):
     np.testing.assert_allclose(fit.result[1:4], truth, atol=2e-3)
     np.testing.assert_allclose(fit.result[0], 1.7, atol=2e-3)
     np.testing.assert_allclose(fit.result[4], 0.02, atol=1e-4)
+
+
+def test_native_host_logic_under_sanitizers(tmp_path):
+    """tools/sanitize_host.sh: all translation units rebuilt with AddressSanitizer + UBSan on the host side and the pure host
+    logic (Morton keys, counting sorts, layout helpers, tile maps, the no-device error path) run on the CPU."""
+    import shutil
+    import subprocess
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "sanitize_host.sh"), str(tmp_path)], capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "host logic ok under sanitizers" in r.stdout
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
