@@ -214,3 +214,27 @@ def test_device_level_multi_rhs_entry_point():
             np.testing.assert_allclose(got[v], ref, rtol=0, atol=1e-12 * np.abs(ref).max())
         for b in (dX, de, dA, dW, dB):
             b.free()
+
+
+@pytest.mark.parametrize("n,m", [(2300, 300), (3100, 700), (4096, 513)])
+def test_posterior_covariance_big_step_substitution(n, m, monkeypatch):
+    """return_cov from N = 2048 on: the substitution Bt = HT L^-T in 1024-column steps with the factor's inverse slabs and
+    depth-1024 updates, against the oracle (gp_interp.py:184-192) and against the 128-block substitution on the same factor."""
+    from oracle import gp_oracle as O
+    from treegp_amd import _lib, ops
+    from treegp_amd.synthetic import star_field, headline_invlam
+    X, y, y_err, Xs = star_field(n, m, seed=n + m)
+    iL = headline_invlam()
+    kw = dict(amp=0.9, a=iL[0, 0], b=iL[0, 1], c=iL[1, 1])
+    spec = ops.KernelSpec(_lib.TGP_ARBF, **kw)
+    _, _, _, f = ops.gp_solve(spec, X, y - y.mean(), y_err, keep=True)
+    cov = ops.gp_predict_cov(spec, f, X, Xs)
+    monkeypatch.setenv("TGP_COV_BIG", "0")
+    old = ops.gp_predict_cov(spec, f, X, Xs)
+    monkeypatch.delenv("TGP_COV_BIG")
+    f.free()
+    K = O.kernel_matrix("gauss", X, **kw)
+    ref = O.gp_predict_cov(K, y_err, O.kernel_matrix("gauss", Xs, X, **kw), O.kernel_matrix("gauss", Xs, **kw))
+    np.testing.assert_allclose(cov, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+    np.testing.assert_allclose(cov, old, rtol=0, atol=1e-11 * np.abs(old).max())
+    np.testing.assert_allclose(cov, cov.T, rtol=0, atol=1e-13 * np.abs(cov).max())

@@ -94,11 +94,14 @@ def posterior_cov(n, m):
     iL = headline_invlam()
     spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=iL[0, 0], b=iL[0, 1], c=iL[1, 1])
     alpha, _, _, fac = ops.gp_solve(spec, X, y - y.mean(), y_err, keep=True)
+    ops.gp_predict_cov(spec, fac, X, Xs)                                    # builds the factor's inverse slabs
     t0 = time.perf_counter()
     cov = ops.gp_predict_cov(spec, fac, X, Xs)
     dt = time.perf_counter() - t0
+    tm = _lib.timings(fac._ctx)
     flops = 2.0 * m * n * (n / 2 + m)
-    out(kernel="gp_predict_cov", n=n, m=m, wall_ms=dt * 1e3, TFLOPs=flops / dt / 1e12, min_diag=float(np.diag(cov).min()))
+    out(kernel="gp_predict_cov", n=n, m=m, wall_ms=dt * 1e3, device_ms=tm[3], transfer_ms=tm[9], device_TFLOPs=flops / tm[3] / 1e9,
+        min_diag=float(np.diag(cov).min()))
 
 
 if __name__ == "__main__":
@@ -111,3 +114,4 @@ if __name__ == "__main__":
         pair_binning(32768, 444)
     if "cov" in which:
         posterior_cov(8192, 4096)
+        posterior_cov(32768, 4096)

@@ -62,6 +62,35 @@ __global__ __launch_bounds__(256, 2) void cov_update_kernel(double *Bt, int64_t 
     gemm_tile_dtv<4, TGP_TB, 1>(a, b, cc, nullptr, nullptr);
 }
 
+// ---- the substitution in steps of S = 1024 columns, with the factor's inverse slabs (trsv_big.hip) -------------------------
+//   T  = Bt[:, K] V_K^T            (V_K = inverse of the S x S diagonal block: k <= j, 256-deep segments; out of place)
+//   Bt[:, c] -= Bt[:, K] L[c, K]^T  for the tile columns c right of super-block K, ONE pass of depth 1024 on the DTV tile
+// instead of eight dependent pairs of depth-128 launches per super-block.
+__global__ __launch_bounds__(256) void cov_diag_big_kernel(const double *__restrict__ Bt, int64_t Mp, const double *__restrict__ V,
+                                                           int64_t Np, int64_t r0, int ncolt, double *__restrict__ T) {
+    const int ti = blockIdx.x / ncolt, tj = blockIdx.x % ncolt;          // 128-row tile of the queries, 128-column tile of the block
+    const int64_t p0 = r0 >> 8;
+    const double *a = Bt + p0 * Mp * TGP_PW + (int64_t)ti * TGP_TB * TGP_PW;
+    const double *b = V + (r0 + (int64_t)tj * TGP_TB) * TGP_PW;          // slab panel 0, rows r0 + 128 tj ..
+    double *c = T + (int64_t)(tj >> 1) * Mp * TGP_PW + (int64_t)ti * TGP_TB * TGP_PW + (tj & 1) * TGP_TB;
+    const int nseg = (tj >> 1) + 1;                                      // V_K is lower triangular: columns k <= j
+    gemm_tile_128<0, TGP_PW, TGP_PW, TileDefault, 0>(a, b, c, nullptr, nullptr, nullptr, nseg, Mp * TGP_PW, Np * TGP_PW);
+}
+
+__global__ __launch_bounds__(256, 2) void cov_update_big_kernel(double *Bt, int64_t Mp, const double *A, int64_t Np, int64_t r0) {
+    const int64_t ti = blockIdx.x;
+    const int64_t p0 = r0 >> 8;
+    const int64_t c = (r0 >> 7) + 8 + blockIdx.y;                        // global 128-tile column right of the super-block
+    SegPtrs<4> sp;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        sp.a[s] = Bt + (p0 + s) * Mp * TGP_PW + ti * TGP_TB * TGP_PW;
+        sp.b[s] = A + panel_off(p0 + s, Np) + (c * TGP_TB - (p0 + s) * TGP_PW) * TGP_PW;
+    }
+    double *cc = Bt + (c >> 1) * Mp * TGP_PW + ti * TGP_TB * TGP_PW + (c & 1) * TGP_TB;
+    gemm_tile_dtv_segs<4, TGP_PW, 4>(sp, cc);
+}
+
 // C(ti, tj) -= sum over all panels of Bt[ti] Bt[tj]^T        (C in the same panel layout, Mp rows)
 __global__ __launch_bounds__(256, 2) void cov_syrk_kernel(double *Cpm, const double *Bt, int64_t Mp, int nP) {
     const int64_t ti = blockIdx.x, tj = blockIdx.y;
@@ -98,15 +127,37 @@ int cov_plan(tgp_ctx *ctx, const tgp_factor *f, int64_t m, bool coords, CovPlan 
     return 0;
 }
 // d_Bt holds HT, d_C holds k(X2, X2), both in zero-padded panels: substitution, Kss - Bt Bt^T, result to the host
-int cov_finish(tgp_ctx *ctx, const tgp_factor *f, const CovPlan &pl, double *cov) {
+int cov_finish(tgp_ctx *ctx, tgp_factor *f, const CovPlan &pl, double *cov) {
     hipStream_t st = ctx->stream;
     const int nb = 2 * pl.nP;
     const unsigned mt = (unsigned)(pl.Mp / TGP_TB);
-    for (int kb = 0; kb < nb; ++kb) {
-        double *Bk = pl.d_Bt + (int64_t)(kb >> 1) * pl.Mp * TGP_PW + (kb & 1) * TGP_TB;
-        cov_trsm_kernel<<<mt, 256, 0, st>>>(Bk, f->d_W + (int64_t)kb * TGP_TB * TGP_TB);
-        const int nc = nb - kb - 1;
-        if (nc > 0) cov_update_kernel<<<dim3(mt, (unsigned)nc), 256, 0, st>>>(pl.d_Bt, pl.Mp, f->d_A, pl.Np, kb);
+    const bool no_big = getenv("TGP_COV_BIG") && atoi(getenv("TGP_COV_BIG")) == 0;     // A/B: the 128-block substitution
+    int S = 0;
+    const double *slabs = nullptr;
+    if (!no_big) {
+        int rc = factor_slabs(ctx, f, &S, &slabs);
+        if (rc) return rc;
+    }
+    if (S == 1024 && slabs) {
+        int rc = tgp_ensure_scratch2(ctx, (size_t)pl.Mp * S * sizeof(double));
+        if (rc) return rc;
+        double *T = (double *)ctx->scratch2;
+        for (int64_t r0 = 0; r0 < pl.Np; r0 += S) {
+            const int64_t rows = (pl.Np - r0) < S ? (pl.Np - r0) : S;
+            const int ncolt = (int)(rows / TGP_TB);
+            cov_diag_big_kernel<<<mt * (unsigned)ncolt, 256, 0, st>>>(pl.d_Bt, pl.Mp, slabs, pl.Np, r0, ncolt, T);
+            TGP_HIP(hipMemcpyAsync(pl.d_Bt + (r0 >> 8) * pl.Mp * TGP_PW, T, (size_t)(rows / TGP_PW) * pl.Mp * TGP_PW * sizeof(double),
+                                   hipMemcpyDeviceToDevice, st));
+            const int64_t right = (pl.Np - (r0 + rows)) / TGP_TB;
+            if (right > 0) cov_update_big_kernel<<<dim3(mt, (unsigned)right), 256, 0, st>>>(pl.d_Bt, pl.Mp, f->d_A, pl.Np, r0);
+        }
+    } else {
+        for (int kb = 0; kb < nb; ++kb) {
+            double *Bk = pl.d_Bt + (int64_t)(kb >> 1) * pl.Mp * TGP_PW + (kb & 1) * TGP_TB;
+            cov_trsm_kernel<<<mt, 256, 0, st>>>(Bk, f->d_W + (int64_t)kb * TGP_TB * TGP_TB);
+            const int nc = nb - kb - 1;
+            if (nc > 0) cov_update_kernel<<<dim3(mt, (unsigned)nc), 256, 0, st>>>(pl.d_Bt, pl.Mp, f->d_A, pl.Np, kb);
+        }
     }
     cov_syrk_kernel<<<dim3(mt, mt), 256, 0, st>>>(pl.d_C, pl.d_Bt, pl.Mp, pl.nP);
     TGP_HIP(hipGetLastError());

@@ -417,6 +417,26 @@ static int build_slabs_pipelined(tgp_ctx *ctx, const double *d_A, const double *
     return 0;
 }
 
+// the inverse slabs of a kept factor (built on first use), for code outside the sweeps (posterior covariance); *S = 0 when
+// the problem is below the big-step threshold
+int factor_slabs(tgp_ctx *ctx, tgp_factor *f, int *S, const double **slabs) {
+    *slabs = nullptr;
+    *S = 0;
+    int step;
+    if (!potrs_big_config(f->Np, &step)) return 0;
+    double *sl = nullptr;
+    bool build = false;
+    int rc = acquire_slabs(ctx, f->Np, step, &f->d_slabs, &f->slab_S, &sl, &build);
+    if (rc) return rc;
+    if (build) {
+        rc = launch_vslab_build(ctx, f->d_A, f->d_W, f->Np, step, sl);
+        if (rc) return rc;
+    }
+    *S = step;
+    *slabs = sl;
+    return 0;
+}
+
 int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only,
                  double **slab_cache, int *slab_S) {
     int S;
