@@ -28,11 +28,19 @@ Outputs (inputs + the reference's outputs, nothing else):
   g10_sklearn_kernels.npz  kernel trees only scikit-learn can evaluate (Sum + WhiteKernel, Matern, RationalQuadratic):
                         the reference's predict / covariance / log-likelihood for them (dense-K entry point)
 
+  g11_ml_fit.npz        the reference's maximum-likelihood fits (log_likelihood.optimizer: L-BFGS-B with SciPy's own finite
+                        differences) on its test_hyp_search.py-style problems: fitted theta and log-likelihood
+  g12_two_pcf_host.npz  the pure host pieces of treegp/two_pcf.py run by the reference itself: get_correlation_length_matrix,
+                        robust_2dfit's model / chi2 / linear amplitudes at given parameters (both anisotropic kernels), the
+                        bootstrap resampling stream of a seeded two_pcf object, the 1-D coordinate padding
+
 ``treegp/utils.py`` starts with ``import treecorr`` (utils.py:2) although ``vcorr``, ``xiB`` and
 ``comp_eb`` (utils.py:5-107) never touch it.  For G9 only, an EMPTY module object named
 ``treecorr`` is registered so that this one import statement resolves; it has no attributes,
 so any code path that really needed TreeCorr would stop with AttributeError (the route
-SURVEY.md 8(c) prescribes).
+SURVEY.md 8(c) prescribes).  ``treegp/two_pcf.py`` (G12) likewise starts with ``import treecorr`` and ``import iminuit``
+(two_pcf.py:3,6); the functions used here -- :12-31, :34-65, :68-148, :209-281 -- call neither, and both names resolve to
+EMPTY module objects.
 """
 import importlib
 import os
@@ -60,6 +68,13 @@ def load_reference():
     pkg.VonKarman = k.VonKarman
     pkg.AnisotropicVonKarman = k.AnisotropicVonKarman
     return pkg
+
+
+def load_reference_two_pcf():
+    """treegp/two_pcf.py unmodified; ``import treecorr`` / ``import iminuit`` resolve to empty module objects."""
+    sys.modules.setdefault("treecorr", types.ModuleType("treecorr"))
+    sys.modules.setdefault("iminuit", types.ModuleType("iminuit"))
+    return importlib.import_module("treegp.two_pcf")
 
 
 def load_reference_utils():
@@ -369,6 +384,79 @@ def main():
         out.update({tag + "_kernel": kern, tag + "_y_pred": gp.predict(Xs), tag + "_alpha": gp._alpha, tag + "_cov128": cov,
                     tag + "_logL": gp.return_log_likelihood()})
     np.savez(os.path.join(OUT, "g10_sklearn_kernels.npz"), **out)
+    # ---------------- G11: the reference's maximum-likelihood fits -------------------------------------
+    out = {}
+    np.random.seed(42)
+    x1 = np.random.uniform(-10, 10, 100).reshape((100, 1))
+    for tag, kern, X in (("rbf1d", "1.000000**2 * RBF(0.500000)", x1),):
+        K = tg.eval_kernel(kern)(X)
+        np.random.seed(43)
+        yy = np.random.multivariate_normal(np.zeros(len(X)), K) + np.random.normal(scale=0.01, size=len(X))
+        gp = GP(kernel="0.7**2 * RBF(0.8)", optimizer="log-likelihood", normalize=True)
+        gp.initialize(X, yy, y_err=0.01 * np.ones(len(X)))
+        gp.solve()
+        out.update({tag + "_X": X, tag + "_y": yy, tag + "_kernel0": "0.7**2 * RBF(0.8)", tag + "_theta": gp.kernel.theta,
+                    tag + "_logL": gp._optimizer._logL, tag + "_theta_true": tg.eval_kernel(kern).theta})
+    rng = np.random.default_rng(77)
+    X2 = rng.uniform(-10, 10, (300, 2))
+    invL = np.linalg.inv(corr_len_matrix(2.0, 0.2, -0.1))
+    ktrue = tg.eval_kernel("1.5**2 * AnisotropicRBF(invLam={0!r})".format(invL))
+    yy = rng.multivariate_normal(np.zeros(300), ktrue(X2)) + 0.02 * rng.standard_normal(300)
+    k0 = "1.0**2 * AnisotropicRBF(invLam={0!r})".format(np.linalg.inv(corr_len_matrix(1.5, 0.0, 0.0)))
+    gp = GP(kernel=k0, optimizer="log-likelihood", normalize=True)
+    gp.initialize(X2, yy, y_err=0.02 * np.ones(300))
+    gp.solve()
+    out.update(arbf2d_X=X2, arbf2d_y=yy, arbf2d_kernel0=k0, arbf2d_theta=gp.kernel.theta, arbf2d_logL=gp._optimizer._logL,
+               arbf2d_theta_true=ktrue.theta)
+    np.savez(os.path.join(OUT, "g11_ml_fit.npz"), **out)
+
+    # ---------------- G12: pure host pieces of treegp/two_pcf.py ------------------------------------------
+    tp = load_reference_two_pcf()
+    out = {}
+    pars = np.array([[0.05, 0.2, 0.1], [1.7, -0.3, 0.25], [3000.0, 0.0, 0.0], [0.4, 0.0, -0.6]])
+    out["clm_params"] = pars
+    out["clm"] = np.stack([tp.get_correlation_length_matrix(*q) for q in pars])
+    nb, mx = 11, 0.9
+    c = (np.arange(nb) + 0.5) * 2 * mx / nb - mx
+    xx, yv = np.meshgrid(c, c)
+    px, py = xx.ravel(), yv.ravel()
+    rng = np.random.default_rng(123)
+    mask = np.ones(nb * nb, dtype=bool)
+    mask[nb * nb // 2 + 1:] = False                                # half plane, like two_pcf.py:311-321
+    nm = int(mask.sum())
+    A = rng.standard_normal((nm, nm))
+    W = A @ A.T / nm + np.eye(nm)                                  # positive-definite weights of the kept pixels (two_pcf.py:384-387)
+    out.update(fit_x=px, fit_y=py, fit_W=W, fit_mask=mask)
+    trial = np.array([[0.35, 0.1, -0.05], [0.5, 0.0, 0.0], [0.2, -0.3, 0.3], [0.6, 1.2, 0.0], [np.nan, 0.0, 0.0]])
+    out["fit_trial"] = trial
+    for tag, kstr in (("arbf", "1.0**2 * AnisotropicRBF(invLam=array([[1., 0.], [0., 1.]]))"),
+                      ("avk", "AnisotropicVonKarman(invLam=array([[1., 0.], [0., 1.]]))")):
+        kern = tg.eval_kernel(kstr)
+        kcls = tp.get_kernel_class(kern)
+        truth = 1.3 ** 2 * kcls(invLam=np.linalg.inv(tp.get_correlation_length_matrix(0.35, 0.1, -0.05)))
+        data = truth(np.array([px, py]).T, Y=np.zeros((nb * nb, 2)))[:, 0] + 0.03 + 0.01 * rng.standard_normal(nb * nb)
+        fit = tp.robust_2dfit(kern, data, px, py, W, mask=mask)
+        chi2, alpha, model = [], [], []
+        for q in trial:
+            v = fit.chi2(q)
+            chi2.append(v)
+            ok = np.isfinite(v)
+            alpha.append(np.ravel(fit.alpha) if ok else [np.nan, np.nan])
+            m = fit._model_skl(1.0, q[0], q[1], q[2]) if np.isfinite(q[0]) else None
+            model.append(m if m is not None else np.full(nb * nb, np.nan))
+        out.update({tag + "_kernel": kstr, tag + "_data": data, tag + "_chi2": np.array(chi2, dtype=float), tag + "_alpha": np.array(alpha, dtype=float),
+                    tag + "_model": np.array(model, dtype=float)})
+    rng = np.random.default_rng(5)
+    n = 57
+    Xb = rng.uniform(0, 1, (n, 2)); yb = rng.standard_normal(n); eb = rng.uniform(0.1, 0.2, n)
+    obj = tp.two_pcf(Xb, yb, eb, 0.0, 0.3, nbins=7, anisotropic=True)
+    draws = [obj.resample_bootstrap() for _ in range(3)]
+    out.update(boot_X=Xb, boot_y=yb, boot_yerr=eb, boot_u=np.stack([d[0] for d in draws]), boot_v=np.stack([d[1] for d in draws]),
+               boot_yr=np.stack([d[2] for d in draws]), boot_er=np.stack([d[3] for d in draws]))
+    x1d = rng.uniform(-3, 3, (9, 1))
+    obj1 = tp.two_pcf(x1d, yb[:9], eb[:9], 0.1, 1.0, nbins=5)
+    out.update(pad_X1=x1d, pad_X=obj1.X)
+    np.savez(os.path.join(OUT, "g12_two_pcf_host.npz"), **out)
     print("golden vectors written to", OUT)
 
 

@@ -448,3 +448,39 @@ def test_kk_edge_cases_vs_oracle():
         xo, wo, no = O.kk_twod(xs, ys, ks, None, 0.0, 0.7, 5)
         assert np.array_equal(npairs, no)
         np.testing.assert_allclose(xi, xo, rtol=1e-10, atol=1e-14)
+
+
+def test_robust_2dfit_model_and_chi2_against_reference(golden):
+    """g12: robust_2dfit._model_skl and chi2 (treegp/two_pcf.py:96-148) for both anisotropic kernels at the parameter sets
+    the reference itself evaluated (including |g| > 1 and a NaN: chi2 = inf)."""
+    import sys
+    T = sys.modules["treegp_amd.two_pcf"]
+    g = golden("g12_two_pcf_host.npz")
+    for tag in ("arbf", "avk"):
+        kern = treegp.eval_kernel(str(g[tag + "_kernel"]))
+        fit = T.robust_2dfit(kern, g[tag + "_data"], g["fit_x"], g["fit_y"], g["fit_W"], mask=g["fit_mask"])
+        for q, chi2, alpha, model in zip(g["fit_trial"], g[tag + "_chi2"], g[tag + "_alpha"], g[tag + "_model"]):
+            got = fit.chi2(q)
+            if np.isfinite(chi2):
+                np.testing.assert_allclose(fit._model_skl(1.0, *q), model, rtol=0, atol=1e-12)
+                np.testing.assert_allclose(got, chi2, rtol=1e-8)
+                np.testing.assert_allclose(np.ravel(fit.alpha), alpha, rtol=1e-8)
+            else:
+                assert got == np.inf
+
+
+def test_ml_fit_reaches_the_reference_optimum(golden):
+    """g11: the reference's own maximum-likelihood fits (L-BFGS-B with SciPy's finite differences, log_likelihood.py:43-62);
+    the fit here starts from the same kernel and has to end at the same optimum: log-likelihood within 1e-6 of the
+    reference's (relative), theta within 2e-3 (the finite-difference gradient's noise floor)."""
+    g = golden("g11_ml_fit.npz")
+    for tag, yerr in (("rbf1d", 0.01), ("arbf2d", 0.02)):
+        X, y = g[tag + "_X"], g[tag + "_y"]
+        gp = treegp.GPInterpolation(kernel=str(g[tag + "_kernel0"]), optimizer="log-likelihood", normalize=True)
+        gp.initialize(X, y, y_err=yerr * np.ones(len(y)))
+        gp.solve()
+        ref_l = float(g[tag + "_logL"])
+        assert gp._optimizer._logL >= ref_l - 1e-6 * abs(ref_l), (gp._optimizer._logL, ref_l)
+        np.testing.assert_allclose(gp.kernel.theta, g[tag + "_theta"], atol=2e-3)
+        # and the likelihood at the reference's optimum is the reference's number
+        np.testing.assert_allclose(gp.return_log_likelihood(theta=g[tag + "_theta"]), ref_l, rtol=1e-10)

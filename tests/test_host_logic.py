@@ -303,3 +303,33 @@ def test_native_host_logic_under_sanitizers(tmp_path):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "host logic ok under sanitizers" in r.stdout
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
+def test_two_pcf_host_pieces_against_reference(golden, monkeypatch):
+    """g12: the pure host pieces of treegp/two_pcf.py as the reference itself runs them -- correlation-length matrix, the
+    seeded bootstrap resampling stream (two_pcf.py:264-281), the 1-D coordinate padding (:248-251), and robust_2dfit's chi2
+    algebra (:115-148) fed with the reference's own model values (the model itself needs the GPU: tests/test_gpu_api.py)."""
+    import sys
+    T = sys.modules["treegp_amd.two_pcf"]
+    g = golden("g12_two_pcf_host.npz")
+    for q, ref in zip(g["clm_params"], g["clm"]):
+        np.testing.assert_allclose(T.get_correlation_length_matrix(*q), ref, rtol=1e-15, atol=0)
+    obj = tg.two_pcf(g["boot_X"], g["boot_y"], g["boot_yerr"], 0.0, 0.3, nbins=7, anisotropic=True)
+    for r in range(3):
+        u, v, yr, er = obj.resample_bootstrap()
+        np.testing.assert_array_equal(u, g["boot_u"][r]); np.testing.assert_array_equal(v, g["boot_v"][r])
+        np.testing.assert_array_equal(yr, g["boot_yr"][r]); np.testing.assert_array_equal(er, g["boot_er"][r])
+    obj1 = tg.two_pcf(g["pad_X1"], g["boot_y"][:9], g["boot_yerr"][:9], 0.1, 1.0, nbins=5)
+    np.testing.assert_array_equal(obj1.X, g["pad_X"])
+    # chi2 / linear amplitudes with the reference's model values standing in for the kernel evaluation
+    monkeypatch.setattr(T, "get_kernel_class", lambda k: None)
+    for tag in ("arbf", "avk"):
+        fit = T.robust_2dfit(None, g[tag + "_data"], g["fit_x"], g["fit_y"], g["fit_W"], mask=g["fit_mask"])
+        for q, chi2, alpha, model in zip(g["fit_trial"], g[tag + "_chi2"], g[tag + "_alpha"], g[tag + "_model"]):
+            fit._model_skl = lambda s, c, g1, g2, m=model: (None if (max(abs(g1), abs(g2)) > 1) else m)
+            got = fit.chi2(q)
+            if np.isfinite(chi2):
+                np.testing.assert_allclose(got, chi2, rtol=1e-9)
+                np.testing.assert_allclose(np.ravel(fit.alpha), alpha, rtol=1e-9)
+            else:
+                assert got == np.inf
