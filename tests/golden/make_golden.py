@@ -34,6 +34,11 @@ Outputs (inputs + the reference's outputs, nothing else):
                         robust_2dfit's model / chi2 / linear amplitudes at given parameters (both anisotropic kernels), the
                         bootstrap resampling stream of a seeded two_pcf object, the 1-D coordinate padding
 
+  g13_meanify.npz       treegp/meanify.py (add_field + meanify, statistics "mean" and "median", default and explicit limits, with empty
+                        bins) run by the reference itself; its module-level ``import fitsio`` (meanify.py:7) resolves to an empty
+                        module object -- only save_results, not used here, calls it.  (statistics="weighted" stops with a NameError
+                        inside the reference, meanify.py:108, and therefore has no golden values.)
+
 ``treegp/utils.py`` starts with ``import treecorr`` (utils.py:2) although ``vcorr``, ``xiB`` and
 ``comp_eb`` (utils.py:5-107) never touch it.  For G9 only, an EMPTY module object named
 ``treecorr`` is registered so that this one import statement resolves; it has no attributes,
@@ -75,6 +80,12 @@ def load_reference_two_pcf():
     sys.modules.setdefault("treecorr", types.ModuleType("treecorr"))
     sys.modules.setdefault("iminuit", types.ModuleType("iminuit"))
     return importlib.import_module("treegp.two_pcf")
+
+
+def load_reference_meanify():
+    """treegp/meanify.py unmodified; ``import fitsio`` resolves to an empty module object (only save_results uses it)."""
+    sys.modules.setdefault("fitsio", types.ModuleType("fitsio"))
+    return importlib.import_module("treegp.meanify")
 
 
 def load_reference_utils():
@@ -457,6 +468,30 @@ def main():
     obj1 = tp.two_pcf(x1d, yb[:9], eb[:9], 0.1, 1.0, nbins=5)
     out.update(pad_X1=x1d, pad_X=obj1.X)
     np.savez(os.path.join(OUT, "g12_two_pcf_host.npz"), **out)
+    # ---------------- G13: meanify run by the reference --------------------------------------------------
+    mf = load_reference_meanify()
+    rng = np.random.default_rng(2024)
+    fields = []
+    for _ in range(3):
+        npt = 1500
+        c = np.array([rng.uniform(0, 2048, npt), rng.uniform(0, 2048, npt)]).T
+        c = c[(c[:, 0] - 600) ** 2 + (c[:, 1] - 1500) ** 2 > 250 ** 2]         # a hole: empty bins -> nan -> filtered
+        pv = 0.02 + 5e-8 * (c[:, 0] - 1024) ** 2 + 5e-8 * (c[:, 1] - 1024) ** 2 + 0.01 * rng.standard_normal(len(c))
+        fields.append((c, pv))
+    out = {"nfields": len(fields)}
+    for i, (c, pv) in enumerate(fields):
+        out["coords%d" % i] = c
+        out["params%d" % i] = pv
+    for stat in ("mean", "median"):
+        for tag, lim in (("auto", {}), ("lim", dict(lu_min=100.0, lu_max=1900.0, lv_min=0.0, lv_max=2048.0))):
+            m = mf.meanify(bin_spacing=120.0, statistics=stat)
+            for c, pv in fields:
+                m.add_field(c, pv)
+            m.meanify(**lim)
+            key = stat + "_" + tag
+            out.update({key + "_average": m._average, key + "_coords0": m.coords0, key + "_params0": m.params0, key + "_wrms0": m.wrms0,
+                        key + "_xedge": m._xedge, key + "_yedge": m._yedge, key + "_u0": m._u0, key + "_v0": m._v0})
+    np.savez(os.path.join(OUT, "g13_meanify.npz"), **out)
     print("golden vectors written to", OUT)
 
 

@@ -148,3 +148,29 @@ def test_meanify_argument_errors():
         m.add_field(np.zeros((3, 2)), np.zeros(3))
     with pytest.raises(ValueError):
         treegp_amd.meanify().add_field(np.zeros((3, 1)), np.zeros(3))
+
+
+@pytest.mark.parametrize("stat", ["mean", "median"])
+def test_meanify_class_against_reference_golden(stat, golden):
+    """g13: the treegp_amd.meanify class (tgp_binned_stat_2d) against the values the reference's own meanify produced for the
+    same fields: grid, bin centres, the nan filter of empty bins, means to 1e-13, medians bit for bit."""
+    import treegp_amd
+    g = golden("g13_meanify.npz")
+    nf = int(g["nfields"])
+    for tag, lim in (("auto", {}), ("lim", dict(lu_min=100.0, lu_max=1900.0, lv_min=0.0, lv_max=2048.0))):
+        key = stat + "_" + tag
+        m = treegp_amd.meanify(bin_spacing=120.0, statistics=stat)
+        for i in range(nf):
+            m.add_field(g["coords%d" % i], g["params%d" % i])
+        m.meanify(**lim)
+        np.testing.assert_array_equal(m._xedge, g[key + "_xedge"])
+        np.testing.assert_array_equal(m._yedge, g[key + "_yedge"])
+        np.testing.assert_array_equal(m._u0, g[key + "_u0"])
+        np.testing.assert_array_equal(m._v0, g[key + "_v0"])
+        np.testing.assert_array_equal(m.coords0, g[key + "_coords0"])
+        np.testing.assert_array_equal(np.isnan(m._average), np.isnan(g[key + "_average"]))
+        if stat == "median":
+            np.testing.assert_array_equal(m.params0, g[key + "_params0"])
+        else:
+            np.testing.assert_allclose(m.params0, g[key + "_params0"], rtol=1e-13)
+        np.testing.assert_array_equal(m.wrms0, g[key + "_wrms0"])

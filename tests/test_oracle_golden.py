@@ -214,3 +214,23 @@ def test_meanify_grid_geometry_against_reference_fixture(golden):
     w = O.meanify_grid(coords, params, params_err=err, bin_spacing=40.0, statistics="weighted")
     np.testing.assert_array_equal(w["coords0"], g["X0"])
     assert np.all(w["wrms0"] >= 0) and np.all(np.isfinite(w["params0"]))
+
+
+def test_meanify_values_against_reference(golden):
+    """g13: treegp/meanify.py run by the reference itself (mean and median, default and explicit limits, a hole that leaves
+    empty bins): oracle.meanify_grid reproduces its grid, bin centres, filtered coordinates and values."""
+    g = golden("g13_meanify.npz")
+    nf = int(g["nfields"])
+    coords = np.concatenate([g["coords%d" % i] for i in range(nf)], axis=0)
+    params = np.concatenate([g["params%d" % i] for i in range(nf)])
+    for stat in ("mean", "median"):
+        for tag, lim in (("auto", {}), ("lim", dict(lu_min=100.0, lu_max=1900.0, lv_min=0.0, lv_max=2048.0))):
+            key = stat + "_" + tag
+            m = O.meanify_grid(coords, params, bin_spacing=120.0, statistics=stat, **lim)
+            np.testing.assert_array_equal(m["xedge"], g[key + "_xedge"])
+            np.testing.assert_array_equal(m["yedge"], g[key + "_yedge"])
+            np.testing.assert_array_equal(m["u0"], g[key + "_u0"])
+            np.testing.assert_array_equal(m["coords0"], g[key + "_coords0"])
+            np.testing.assert_allclose(m["average"], g[key + "_average"], rtol=1e-14, equal_nan=True)
+            np.testing.assert_allclose(m["params0"], g[key + "_params0"], rtol=1e-14)
+            assert np.isnan(g[key + "_average"]).any() and len(m["params0"]) < m["average"].size
