@@ -23,6 +23,9 @@ Parity status
   isotropic path runs TreeCorr with its default ``bin_slop`` (approximate binning), which
   exact binning does not reproduce bit for bit.
 
+* ``meanify_grid``: PINNED against ``treegp/meanify.py`` run by the reference itself (``g13_meanify.npz``, mean and median;
+  the reference's weighted branch raises a NameError and has no values).
+
 All kernels are described by plain numbers, never by the product's classes:
 ``kind`` in {"gauss", "vk", "avk"}:
   gauss : exp(-0.5 * q),            q = a dx^2 + 2 b dx dy + c dy^2
