@@ -12,8 +12,8 @@ Parity status
   reference's own exact O(N^2) pair binner ``treegp/utils.py:5-74`` (``vcorr``), run
   unmodified by ``tests/golden/make_golden.py`` -> ``g9_vcorr.npz`` (vector fields; a
   scalar field with ``dy = 0`` on a grid that coincides with a KK log-bin grid, where
-  ``xi+`` / ``logr`` are KK's ``xi`` / ``meanlogr``).  Per-point weights enter ``kk_log`` as the
-  factor ``w_i w_j`` on the same sums; that factor itself has no reference-held value.
+  ``xi+`` / ``logr`` are KK's ``xi`` / ``meanlogr``; with ``dx = w k`` and ``dx = w`` the ratio of its bin averages is the
+  WEIGHTED ``xi`` and their product with the pair count the ``weight``: case f).
 * TwoD-pixel pair sums (``kk_twod``) and what TreeCorr does beyond exact binning:
   **parity unpinned**.  The arithmetic lives in the third-party TreeCorr library (PyPI
   ``treecorr``, ``requirements.txt:6`` pins ``>=5.0``), which is neither vendored in the

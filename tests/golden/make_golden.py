@@ -364,6 +364,13 @@ def main():
     assert len(logr) == nbins
     out.update(c_x=x, c_y=y, c_k=kf, c_min_sep=min_sep, c_max_sep=max_sep, c_nbins=nbins, c_dlogr=dlogr,
                c_logr=logr, c_xiplus=xip, c_ximinus=xim, c_xicross=xix, c_xiz2=xiz2)
+    # (f) per-point weights through the same unweighted binner: with dx = w k the bin averages are <w_i w_j k_i k_j> and with
+    #     dx = w they are <w_i w_j>; their ratio is the WEIGHTED KK xi (the pair counts cancel), <w_i w_j> times the pair count
+    #     is KK's weight.  Same points and bins as (c).
+    wts = 1.0 / (0.03 * rng.uniform(0.8, 1.2, n)) ** 2
+    f1 = ut.vcorr(x, y, wts * kf, np.zeros(n), rmin=min_sep, rmax=max_sep, dlogr=dlogr)
+    f2 = ut.vcorr(x, y, wts, np.zeros(n), rmin=min_sep, rmax=max_sep, dlogr=dlogr)
+    out.update(f_w=wts, f_xiplus_wk=f1[1], f_xiplus_w=f2[1])
     # (d) the subsampling branch (utils.py:28-35): legacy global RandomState, seeded here
     n = 900
     x, y = rng.uniform(0, 1, n), rng.uniform(0, 1, n)

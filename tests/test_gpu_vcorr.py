@@ -120,7 +120,12 @@ def test_kk_log_against_reference_golden(golden):
     np.testing.assert_array_equal(wt, npairs)
     assert np.all(np.exp(meanlogr) <= meanr * (1 + 1e-12))                   # geometric mean <= arithmetic mean, per bin
     _cmp_golden(utils.vcorr(x, y, k, np.zeros_like(k), rmin=mn, rmax=mx, dlogr=float(g["c_dlogr"])), g, "c")
-    # per-point weights: uniform weights leave xi unchanged and scale the weight by w^2
+    # per-point weights against the reference's binner (g9 case f): xi = <w w k k> / <w w>, weight = <w w> npairs
+    xiw, wtw, _, _, npw = ops.kk_log(x, y, k, g["f_w"], mn, mx, nb)
+    np.testing.assert_array_equal(npw, npairs)
+    np.testing.assert_allclose(xiw, g["f_xiplus_wk"] / g["f_xiplus_w"], rtol=0, atol=1e-12 * np.abs(xiw).max())
+    np.testing.assert_allclose(wtw, g["f_xiplus_w"] * npairs, rtol=1e-12)
+    # uniform weights leave xi unchanged and scale the weight by w^2
     xi2, wt2 = ops.kk_log(x, y, k, np.full(len(x), 3.0), mn, mx, nb)[:2]
     np.testing.assert_allclose(xi2, xi, rtol=1e-12, atol=1e-15)
     np.testing.assert_allclose(wt2, 9.0 * npairs, rtol=1e-12)

@@ -161,6 +161,12 @@ def test_kk_log_against_reference_binner(golden):
     # weighted sums are the same expression with w_i w_j folded in: uniform weights c leave xi unchanged
     xi2 = O.kk_log(x, y, k, np.full(len(x), 3.0), mn, mx, nb)[0]
     np.testing.assert_allclose(xi2, xi, rtol=1e-13, atol=1e-16)
+    # per-point weights, pinned by the reference's binner too (g9 case f): weighted xi = <w w k k> / <w w>, weight = <w w> npairs
+    w = g["f_w"]
+    xiw, wtw, _, _, npw = O.kk_log(x, y, k, w, mn, mx, nb)
+    np.testing.assert_array_equal(npw, npairs)
+    np.testing.assert_allclose(xiw, g["f_xiplus_wk"] / g["f_xiplus_w"], rtol=0, atol=1e-12 * np.abs(xiw).max())
+    np.testing.assert_allclose(wtw, g["f_xiplus_w"] * npairs, rtol=1e-12)
 
 
 def test_sklearn_kernel_trees_host_side(golden):
