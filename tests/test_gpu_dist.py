@@ -224,3 +224,38 @@ def test_bench_self_launch_rehearsal(G):
     out = json.loads(lines[0])
     assert out["n_gpus"] == G and out["ranks_seen"] == G and out["steps"] == 2
     assert out["value"] > 0 and out["unit"] == "points/s" and out["scaling"] == "strong"
+
+
+def test_bench_line_schema_single_gpu():
+    """The one JSON line of `python bench.py` (contract of the round driver): keys, units and the roofline / cpu_baseline
+    objects, on a small instance of the workload (the CPU leg on a 1024-point sample)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--ntrain", "24576",
+                        "--cpu-sample", "1024"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "roofline_kbuild", "roofline_trsv", "roofline_predict"):
+        assert key in out, key
+    assert out["unit"] == "points/s" and out["dtype"] == "f64" and out["data"] == "synthetic" and out["vs_baseline"] is None
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True
+    assert "workload" in out["config"] and "model" not in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert 0.3 < rf["frac"] < 1.0 and "traffic" in rf and "traffic_source" in rf
+    for sub in ("roofline_kbuild", "roofline_trsv"):
+        assert out[sub]["bound"] == "hbm" and out[sub]["unit"] == "GB/s" and 0 < out[sub]["frac"] < 1
+    cb = out["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample", "passes", "phases_s"):
+        assert key in cb, key
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["passes"] >= 3
+    assert any(k.startswith("extrapolated_n") for k in cb)
+    np.testing.assert_allclose(out["value"], (24576 + 4 * 24576) / (out["ms_per_step"] * 1e-3), rtol=1e-9)
