@@ -118,6 +118,15 @@ int tgp_gp_predict_cov(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel *k, const d
 int tgp_gp_predict_cov_dense(tgp_ctx *ctx, tgp_factor *f, const double *HT, const double *Kss,
                              int64_t m, double *cov);
 
+/* ---- S2d: gradient of the log marginal likelihood from a kept factor and its alpha ---------
+ * (the reference's optimiser passes no jac, treegp/log_likelihood.py:57 -- this is what a caller who wants one
+ * gets, in the kernel-derivative convention of treegp/kernels.py:128-150.)
+ *   grad[0..3] = 1/2 sum_ij (alpha_i alpha_j - [K^-1]_ij) dK_ij/dp   for p = log amp, a, b, c   (b = invLam[0,1] = invLam[1,0])
+ * Gaussian kernels only (TGP_RBF, TGP_ARBF): -1 with a message for the von Karman kinds.  K^-1 is formed on the device
+ * (2/3 n^3 flops, two n x n buffers) and never leaves it.                                                             */
+int tgp_gp_loglik_grad(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel *k, const double *X, int64_t n,
+                       const double *alpha, double *grad);
+
 /* ---- S4: binned scalar pair correlation, exact binning -----------------------------------
  * w == NULL: unit weights.  TwoD: nbins x nbins pixels over [-max_sep, max_sep]^2, outputs
  * of length nbins^2 (flat index iy*nbins+ix).  Log: nbins log-spaced bins in

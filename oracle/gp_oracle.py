@@ -124,6 +124,24 @@ def log_likelihood(K, y, y_err):
     return ll
 
 
+def loglik_grad_invlam(X, y, y_err, amp, invLam, dinvLam):
+    """d logL / d theta_k = 1/2 sum_ij (alpha_i alpha_j - [K^-1]_ij) dK_ij/dtheta_k for K = amp exp(-1/2 dX^T invLam dX)
+    + diag(y_err^2) (gp_interp.py:180), with the reference's kernel derivative dK/dtheta_k = -1/2 K dX^T dinvLam[k] dX
+    (kernels.py:128-150; dinvLam[k] = d invLam / d theta_k).  Also returns d logL / d log amp (scikit-learn's ConstantKernel:
+    dK/dtheta = K).  O(n^2) memory per theta: small cases only."""
+    X = _as2d(X)
+    n, nd = X.shape
+    dX = X[:, None, :] - X[None, :, :]
+    K = amp * np.exp(-0.5 * np.einsum("ijk,kl,ijl->ij", dX, invLam, dX))
+    np.fill_diagonal(K, amp)
+    alpha, _ = gp_solve(K, y, y_err)
+    Kn = K + np.diag(np.asarray(y_err, float) ** 2)
+    M = np.outer(alpha, alpha) - cho_solve((cholesky(Kn, lower=False), False), np.eye(n))
+    g_amp = 0.5 * np.sum(M * K)
+    g = [0.5 * np.sum(M * (-0.5 * K * np.einsum("ijk,kl,ijl->ij", dX, np.asarray(G, float), dX))) for G in dinvLam]
+    return g_amp, np.array(g)
+
+
 def knn_mean(X0, y0, X, k=4):
     """gp_interp.py:236-238: KNeighborsRegressor(n_neighbors=k) = uniform mean of the
     k nearest (Euclidean) neighbours; brute force restatement."""

@@ -34,6 +34,8 @@ Outputs (inputs + the reference's outputs, nothing else):
                         robust_2dfit's model / chi2 / linear amplitudes at given parameters (both anisotropic kernels), the
                         bootstrap resampling stream of a seeded two_pcf object, the 1-D coordinate padding
 
+  g14_loglik_grad.npz   d logL / d theta = 1/2 tr((alpha alpha^T - K^-1) dK/dtheta) with the reference's own dK/dtheta
+                        (kernel(X, eval_gradient=True), kernels.py:128-150) for Gaussian kernel trees; pins tgp_gp_loglik_grad
   g13_meanify.npz       treegp/meanify.py (add_field + meanify, statistics "mean" and "median", default and explicit limits, with empty
                         bins) run by the reference itself; its module-level ``import fitsio`` (meanify.py:7) resolves to an empty
                         module object -- only save_results, not used here, calls it.  (statistics="weighted" stops with a NameError
@@ -150,9 +152,48 @@ def read_fits_bintable_row0(path):
     return out
 
 
+def make_g14(tg):
+    """Gradient of the log marginal likelihood with the REFERENCE's kernel derivative (``kernel(X, eval_gradient=True)``:
+    treegp/kernels.py:128-150 for AnisotropicRBF, composed by scikit-learn's Product / ConstantKernel / RBF) in the standard
+    formula 1/2 tr((alpha alpha^T - K^-1) dK/dtheta_k), K = kernel(X) + diag(y_err^2) as at gp_interp.py:180.  The reference
+    never forms this gradient itself (log_likelihood.py:57 passes no jac); what is pinned is its dK/dtheta convention and the
+    likelihood it belongs to (logL from the reference's own log_likelihood class)."""
+    from scipy import linalg
+    out = {}
+    rng = np.random.default_rng(1414)
+    cases = []
+    X = rng.uniform(0, 1, (700, 2))
+    invL = np.linalg.inv(corr_len_matrix(0.08, 0.25, -0.1))
+    cases.append(("arbf2d", "0.8**2 * AnisotropicRBF(invLam={0!r})".format(invL), X, 0.03 * rng.uniform(0.8, 1.2, 700)))
+    X = rng.uniform(-10, 10, (300, 1))
+    cases.append(("arbf1d", "1.3**2 * AnisotropicRBF(scale_length=[1.5])", X, 0.1 * np.ones(300)))
+    X = rng.uniform(0, 1, (520, 2))
+    cases.append(("rbf2d", "0.6**2 * RBF(0.07)", X, 0.02 * rng.uniform(0.8, 1.2, 520)))
+    X = rng.uniform(0, 1, (2300, 2))
+    invL = np.linalg.inv(corr_len_matrix(0.05, 0.2, 0.1))
+    cases.append(("arbf2d_big", "1.0**2 * AnisotropicRBF(invLam={0!r})".format(invL), X, 0.03 * rng.uniform(0.8, 1.2, 2300)))
+    for tag, kern, X, y_err in cases:
+        k = tg.eval_kernel(kern)
+        y = sine_field(rng, X if X.shape[1] == 2 else X / 20.0) + y_err * rng.standard_normal(len(X))
+        K, dK = k(X, eval_gradient=True)
+        Kn = K + np.eye(len(X)) * y_err ** 2
+        fac = linalg.cho_factor(Kn, lower=False)
+        alpha = linalg.cho_solve(fac, y)
+        Kinv = linalg.cho_solve(fac, np.eye(len(X)))
+        grad = 0.5 * np.einsum("ij,ijk->k", np.outer(alpha, alpha) - Kinv, dK)
+        logL = tg.log_likelihood(X, y, y_err).log_likelihood(k)
+        out.update({tag + "_kernel": kern, tag + "_X": X, tag + "_y": y, tag + "_y_err": y_err, tag + "_theta": k.theta,
+                    tag + "_grad": grad, tag + "_logL": logL})
+    out["tags"] = np.array([c[0] for c in cases])
+    np.savez(os.path.join(OUT, "g14_loglik_grad.npz"), **out)
+
+
 def main():
     tg = load_reference()
     GP = tg.GPInterpolation
+    if "--only-g14" in sys.argv:
+        make_g14(tg)
+        return
 
     # ---------------- G1: config 1 ------------------------------------------------
     rng = np.random.default_rng(20240613)
@@ -499,6 +540,7 @@ def main():
             out.update({key + "_average": m._average, key + "_coords0": m.coords0, key + "_params0": m.params0, key + "_wrms0": m.wrms0,
                         key + "_xedge": m._xedge, key + "_yedge": m._yedge, key + "_u0": m._u0, key + "_v0": m._v0})
     np.savez(os.path.join(OUT, "g13_meanify.npz"), **out)
+    make_g14(tg)
     print("golden vectors written to", OUT)
 
 

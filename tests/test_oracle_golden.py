@@ -240,3 +240,24 @@ def test_meanify_values_against_reference(golden):
             np.testing.assert_allclose(m["average"], g[key + "_average"], rtol=1e-14, equal_nan=True)
             np.testing.assert_allclose(m["params0"], g[key + "_params0"], rtol=1e-14)
             assert np.isnan(g[key + "_average"]).any() and len(m["params0"]) < m["average"].size
+
+
+def test_loglik_gradient_against_reference_kernel_derivative(golden):
+    """g14: 1/2 tr((alpha alpha^T - K^-1) dK/dtheta) with the reference's own dK/dtheta.  The oracle's restatement, driven by the
+    host chain rule of the product (kernels.spec_jacobian: d(log amp, a, b, c)/dtheta), reproduces it -- pins both without a GPU."""
+    import treegp_amd as treegp
+    from treegp_amd.kernels import kernel_to_spec, spec_jacobian
+    g = golden("g14_loglik_grad.npz")
+    for tag in ("arbf2d", "arbf1d", "rbf2d"):
+        k = treegp.eval_kernel(str(g[tag + "_kernel"]))
+        np.testing.assert_allclose(k.theta, g[tag + "_theta"], rtol=1e-13)
+        spec, J = kernel_to_spec(k), spec_jacobian(k)
+        assert J.shape == (len(k.theta), 4)
+        X = g[tag + "_X"]
+        nd = X.shape[1]
+        invLam = np.array([[spec.a, spec.b], [spec.b, spec.c]])[:nd, :nd]
+        basis = [np.array([[1.0, 0], [0, 0]])[:nd, :nd], np.array([[0, 1.0], [1.0, 0]])[:nd, :nd], np.array([[0, 0], [0, 1.0]])[:nd, :nd]]
+        g_amp, g_abc = O.loglik_grad_invlam(X, g[tag + "_y"], g[tag + "_y_err"], spec.amp, invLam, basis)
+        grad = J.dot(np.concatenate([[g_amp], g_abc]))
+        ref = g[tag + "_grad"]
+        np.testing.assert_allclose(grad, ref, rtol=1e-7, atol=1e-7 * np.abs(ref).max(), err_msg=tag)

@@ -126,8 +126,9 @@ int cov_plan(tgp_ctx *ctx, const tgp_factor *f, int64_t m, bool coords, CovPlan 
     pl->d_C = take((size_t)pl->Mp * pl->Mp * 8);
     return 0;
 }
-// d_Bt holds HT, d_C holds k(X2, X2), both in zero-padded panels: substitution, Kss - Bt Bt^T, result to the host
-int cov_finish(tgp_ctx *ctx, tgp_factor *f, const CovPlan &pl, double *cov) {
+// Bt <- Bt L^-T by block substitution.  `tri`: Bt starts as the identity (m == n), so at the step that eliminates columns
+// [r0, r0 + rows) only the row tiles above r0 + rows hold anything: the launches cover those tiles only (a third of the work).
+int cov_substitute(tgp_ctx *ctx, tgp_factor *f, const CovPlan &pl, bool tri) {
     hipStream_t st = ctx->stream;
     const int nb = 2 * pl.nP;
     const unsigned mt = (unsigned)(pl.Mp / TGP_TB);
@@ -145,20 +146,32 @@ int cov_finish(tgp_ctx *ctx, tgp_factor *f, const CovPlan &pl, double *cov) {
         for (int64_t r0 = 0; r0 < pl.Np; r0 += S) {
             const int64_t rows = (pl.Np - r0) < S ? (pl.Np - r0) : S;
             const int ncolt = (int)(rows / TGP_TB);
-            cov_diag_big_kernel<<<mt * (unsigned)ncolt, 256, 0, st>>>(pl.d_Bt, pl.Mp, slabs, pl.Np, r0, ncolt, T);
-            TGP_HIP(hipMemcpyAsync(pl.d_Bt + (r0 >> 8) * pl.Mp * TGP_PW, T, (size_t)(rows / TGP_PW) * pl.Mp * TGP_PW * sizeof(double),
-                                   hipMemcpyDeviceToDevice, st));
+            const unsigned mte = tri ? (unsigned)((r0 + rows) / TGP_TB) : mt;          // row tiles that are not all zero yet
+            cov_diag_big_kernel<<<mte * (unsigned)ncolt, 256, 0, st>>>(pl.d_Bt, pl.Mp, slabs, pl.Np, r0, ncolt, T);
+            for (int64_t q = 0; q < rows / TGP_PW; ++q)
+                TGP_HIP(hipMemcpyAsync(pl.d_Bt + ((r0 >> 8) + q) * pl.Mp * TGP_PW, T + q * pl.Mp * TGP_PW,
+                                       (size_t)mte * TGP_TB * TGP_PW * sizeof(double), hipMemcpyDeviceToDevice, st));
             const int64_t right = (pl.Np - (r0 + rows)) / TGP_TB;
-            if (right > 0) cov_update_big_kernel<<<dim3(mt, (unsigned)right), 256, 0, st>>>(pl.d_Bt, pl.Mp, f->d_A, pl.Np, r0);
+            if (right > 0) cov_update_big_kernel<<<dim3(mte, (unsigned)right), 256, 0, st>>>(pl.d_Bt, pl.Mp, f->d_A, pl.Np, r0);
         }
     } else {
         for (int kb = 0; kb < nb; ++kb) {
             double *Bk = pl.d_Bt + (int64_t)(kb >> 1) * pl.Mp * TGP_PW + (kb & 1) * TGP_TB;
-            cov_trsm_kernel<<<mt, 256, 0, st>>>(Bk, f->d_W + (int64_t)kb * TGP_TB * TGP_TB);
+            const unsigned mte = tri ? (unsigned)(kb + 1) : mt;
+            cov_trsm_kernel<<<mte, 256, 0, st>>>(Bk, f->d_W + (int64_t)kb * TGP_TB * TGP_TB);
             const int nc = nb - kb - 1;
-            if (nc > 0) cov_update_kernel<<<dim3(mt, (unsigned)nc), 256, 0, st>>>(pl.d_Bt, pl.Mp, f->d_A, pl.Np, kb);
+            if (nc > 0) cov_update_kernel<<<dim3(mte, (unsigned)nc), 256, 0, st>>>(pl.d_Bt, pl.Mp, f->d_A, pl.Np, kb);
         }
     }
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+// d_Bt holds HT, d_C holds k(X2, X2), both in zero-padded panels: substitution, Kss - Bt Bt^T, result to the host
+int cov_finish(tgp_ctx *ctx, tgp_factor *f, const CovPlan &pl, double *cov) {
+    hipStream_t st = ctx->stream;
+    const unsigned mt = (unsigned)(pl.Mp / TGP_TB);
+    int rc = cov_substitute(ctx, f, pl, false);
+    if (rc) return rc;
     cov_syrk_kernel<<<dim3(mt, mt), 256, 0, st>>>(pl.d_C, pl.d_Bt, pl.Mp, pl.nP);
     TGP_HIP(hipGetLastError());
     TGP_HIP(hipEventRecord(ctx->ev[1], st));
@@ -224,4 +237,129 @@ extern "C" int tgp_gp_predict_cov_dense(tgp_ctx *ctx, tgp_factor *f, const doubl
                                  (size_t)w * 8, (size_t)m, hipMemcpyHostToDevice, st));
     }
     return cov_finish(ctx, f, pl, cov);
+}
+
+// ---- gradient of the log marginal likelihood (kernel derivative convention of treegp/kernels.py:128-150) ------------
+//   dlogL/dp = 1/2 sum_ij (alpha_i alpha_j - [K^-1]_ij) dK_ij/dp
+// for the four numbers a Gaussian kernel is made of on the device: p = log amp, a, b, c (invLam 00, 01 = 10, 11); the chain rule
+// from there to theta stays on the host (kernels.spec_jacobian: the dInvLam/dtheta matrices of kernels.py:138-145).
+// K^-1 = L^-T L^-1 comes from the substitution above started at the identity: Bt = L^-T is upper triangular, so both the
+// substitution and the product Bt Bt^T skip what is known to be zero (2/3 N^3 flops together, twice a factorisation), and the
+// sum over (i, j) is one pass over the lower triangle with dK/dp evaluated from the coordinates.
+namespace {
+__global__ __launch_bounds__(256) void ident_panels_kernel(double *Bt, int64_t Mp, int64_t Np) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < Np) Bt[(i >> 8) * Mp * TGP_PW + i * TGP_PW + (i & 255)] = 1.0;
+}
+
+// lower tile pairs (ti >= tj), linear in blockIdx.x:  C(ti, tj) = -sum_{p >= ti / 2} Bt[ti][p] Bt[tj][p]^T   (C zero before)
+__global__ __launch_bounds__(256, 2) void kinv_syrk_kernel(double *Cpm, const double *Bt, int64_t Mp, int nP) {
+    const int64_t t = blockIdx.x;
+    int64_t ti = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > t) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int64_t tj = t - ti * (ti + 1) / 2;
+    const int64_t p0 = ti >> 1;                                     // row tile ti of L^-T is zero left of its own panel
+    const double *a = Bt + p0 * Mp * TGP_PW + ti * TGP_TB * TGP_PW;
+    const double *b = Bt + p0 * Mp * TGP_PW + tj * TGP_TB * TGP_PW;
+    double *c = Cpm + (tj >> 1) * Mp * TGP_PW + ti * TGP_TB * TGP_PW + (tj & 1) * TGP_TB;
+    gemm_tile_dtv<4, TGP_PW, 0>(a, b, c, nullptr, nullptr, nP - (int)p0, Mp * TGP_PW, Mp * TGP_PW);
+}
+
+// 64 rows x one 256-column panel per workgroup over the lower triangle; four partial sums per workgroup
+__global__ __launch_bounds__(256) void loglik_grad_kernel(KParams p, const double *__restrict__ X, const double *__restrict__ alpha,
+                                                          const double *__restrict__ Cpm, int64_t Mp, int64_t n,
+                                                          double *__restrict__ partial) {
+    __shared__ double red[4][4];
+    const int tid = threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * TGP_PW + tid;
+    const int64_t i0 = (int64_t)blockIdx.y * 64;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if ((int64_t)blockIdx.x * TGP_PW <= i0 + 63 && j < n) {
+        const double xj = X[2 * j], yj = X[2 * j + 1], aj = alpha[j];
+        const double *col = Cpm + (int64_t)blockIdx.x * Mp * TGP_PW + tid;
+        for (int r = 0; r < 64; ++r) {
+            const int64_t i = i0 + r;
+            if (i >= n) break;
+            if (j > i) continue;
+            const double m = alpha[i] * aj + col[i * TGP_PW];       // alpha_i alpha_j - [K^-1]_ij   (C holds -K^-1)
+            if (i == j) {
+                acc[0] += 0.5 * m * p.amp;                          // the pair (i, i) counts once, d K_ii / d log amp = amp
+            } else {
+                const double dx = X[2 * i] - xj, dy = X[2 * i + 1] - yj;
+                const double e = p.amp * exp(-0.5 * quad_form(p, dx, dy)) * m;
+                acc[0] += e;
+                acc[1] -= 0.5 * e * dx * dx;
+                acc[2] -= e * dx * dy;
+                acc[3] -= 0.5 * e * dy * dy;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double v = acc[q];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((tid & 63) == 0) red[tid >> 6][q] = v;
+    }
+    __syncthreads();
+    if (tid < 4) partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// fixed-order sum of the workgroups' partial sums (one workgroup: the result does not depend on the schedule)
+__global__ __launch_bounds__(256) void loglik_grad_reduce_kernel(const double *__restrict__ partial, int64_t count, double *__restrict__ out) {
+    __shared__ double red[256][4];
+    const int tid = threadIdx.x;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t q = tid; q < count; q += 256)
+        for (int s = 0; s < 4; ++s) acc[s] += partial[q * 4 + s];
+    for (int s = 0; s < 4; ++s) red[tid][s] = acc[s];
+    __syncthreads();
+    for (int step = 128; step > 0; step >>= 1) {
+        if (tid < step)
+            for (int s = 0; s < 4; ++s) red[tid][s] += red[tid + step][s];
+        __syncthreads();
+    }
+    if (tid < 4) out[tid] = red[0][tid];
+}
+}  // namespace
+
+extern "C" int tgp_gp_loglik_grad(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel *k, const double *X, int64_t n, const double *alpha,
+                                  double *grad) {
+    TGP_ARG(f && k && X && alpha && grad && n == f->n);
+    if (kind_to_ke(k->kind) != KE_GAUSS) {
+        ctx->err = "tgp_gp_loglik_grad: analytic derivatives exist for the Gaussian kernels only (RBF, AnisotropicRBF), as in the "
+                   "reference (treegp/kernels.py:128-150)";
+        return -1;
+    }
+    TGP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    CovPlan pl;
+    int rc = cov_plan(ctx, f, n, true, &pl);              // m = n: d_Bt (Np x Np) <- L^-T, d_C (Np x Np) <- -K^-1; d_Xs holds alpha
+    if (rc) return rc;
+    const int64_t nrb = (n + 63) / 64;
+    const int64_t nparts = nrb * pl.nP;
+    rc = tgp_ensure_scratch2(ctx, (size_t)(nparts * 4 + 4) * sizeof(double) > (size_t)pl.Mp * 1024 * sizeof(double)
+                                      ? (size_t)(nparts * 4 + 4) * sizeof(double) : (size_t)pl.Mp * 1024 * sizeof(double));
+    if (rc) return rc;
+    TGP_HIP(hipEventRecord(ctx->ev[0], st));
+    TGP_HIP(hipMemcpyAsync(pl.d_X, X, 2 * n * 8, hipMemcpyHostToDevice, st));
+    TGP_HIP(hipMemcpyAsync(pl.d_Xs, alpha, n * 8, hipMemcpyHostToDevice, st));
+    TGP_HIP(hipMemsetAsync(pl.d_Bt, 0, (size_t)pl.Mp * pl.Np * 8, st));
+    TGP_HIP(hipMemsetAsync(pl.d_C, 0, (size_t)pl.Mp * pl.Mp * 8, st));
+    ident_panels_kernel<<<(unsigned)(pl.Np / 256), 256, 0, st>>>(pl.d_Bt, pl.Mp, pl.Np);
+    rc = cov_substitute(ctx, f, pl, true);
+    if (rc) return rc;
+    const int64_t mt = pl.Mp / TGP_TB;
+    kinv_syrk_kernel<<<(unsigned)(mt * (mt + 1) / 2), 256, 0, st>>>(pl.d_C, pl.d_Bt, pl.Mp, pl.nP);
+    double *partial = (double *)ctx->scratch2;             // the substitution's staging buffer is free again
+    loglik_grad_kernel<<<dim3((unsigned)pl.nP, (unsigned)nrb), 256, 0, st>>>(make_kparams(k), pl.d_X, pl.d_Xs, pl.d_C, pl.Mp, n, partial);
+    loglik_grad_reduce_kernel<<<1, 256, 0, st>>>(partial, nparts, partial + nparts * 4);
+    TGP_HIP(hipGetLastError());
+    TGP_HIP(hipEventRecord(ctx->ev[1], st));
+    TGP_HIP(hipMemcpyAsync(grad, partial + nparts * 4, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    TGP_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timings[3] = ms;
+    return 0;
 }

@@ -216,3 +216,40 @@ def kernel_to_spec(kernel):
             return ops.KernelSpec(_lib.TGP_RBF, amp=amp, a=1.0 / ls[0] ** 2, b=0.0, c=1.0 / ls[1] ** 2)
         raise NotImplementedError("RBF with %d length scales" % ls.size)
     raise NotImplementedError("kernel %r is not supported by the GPU hot path" % (kernel,))
+
+
+def spec_jacobian(kernel):
+    """d(log amp, a, b, c) / d theta, shape (ntheta, 4), for the Gaussian kernel trees ``kernel_to_spec`` accepts
+    (theta in scikit-learn's order: a Product's k1 first).  ``ops.gp_loglik_grad`` returns d logL / d(log amp, a, b, c);
+    its product with this matrix is d logL / d theta with the kernel derivative of the reference:
+    dK/dtheta_k = -1/2 K dX^T (dInvLam/dtheta_k) dX with dInvLam = dL L^T + L dL^T, dL the single-element matrices of
+    ``treegp/kernels.py:138-145`` (AnisotropicRBF), and scikit-learn's own for ConstantKernel (K) and RBF."""
+    if isinstance(kernel, Product):
+        return np.vstack([spec_jacobian(kernel.k1), spec_jacobian(kernel.k2)])
+    if isinstance(kernel, ConstantKernel):
+        if kernel.hyperparameter_constant_value.fixed:
+            return np.zeros((0, 4))
+        return np.array([[1.0, 0.0, 0.0, 0.0]])
+    if isinstance(kernel, AnisotropicRBF):
+        L, nd = kernel._L, kernel.ndim
+        rows = []
+        for k in range(kernel.ntheta):
+            dL = np.zeros((nd, nd))
+            if k < nd:
+                dL[k, k] = L[k, k]                          # theta_k = log L_kk
+            else:
+                dL[kernel._t[0][k - nd], kernel._t[1][k - nd]] = 1.0
+            half = dL.dot(L.T)
+            g = half + half.T
+            rows.append([0.0, g[0, 0], g[0, 1] if nd == 2 else 0.0, g[1, 1] if nd == 2 else 0.0])
+        return np.array(rows).reshape(kernel.ntheta, 4)
+    if type(kernel) is RBF:
+        if kernel.hyperparameter_length_scale.fixed:
+            return np.zeros((0, 4))
+        ls = np.ravel(np.asarray(kernel.length_scale, dtype=np.float64))
+        if ls.size == 1:                                    # a = c = l^-2, theta = log l
+            return np.array([[0.0, -2.0 / ls[0] ** 2, 0.0, -2.0 / ls[0] ** 2]])
+        if ls.size == 2:
+            return np.array([[0.0, -2.0 / ls[0] ** 2, 0.0, 0.0], [0.0, 0.0, 0.0, -2.0 / ls[1] ** 2]])
+    raise NotImplementedError("no analytic derivative for %r (the reference has one for AnisotropicRBF only: "
+                              "treegp/kernels.py:128-150)" % (kernel,))

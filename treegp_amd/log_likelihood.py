@@ -20,7 +20,7 @@ import numpy as np
 from scipy import optimize
 
 from . import _lib, ops
-from .kernels import kernel_to_spec
+from .kernels import kernel_to_spec, spec_jacobian
 
 _FD_STEP = 1e-8                  # scipy.optimize.minimize(method="L-BFGS-B") default `eps` (absolute forward step)
 _PARALLEL_MAX_N = 16384          # beyond this one solve fills the GPU by itself
@@ -44,6 +44,10 @@ class log_likelihood(object):
         self.X, self.y, self.y_err = X, y, y_err
         self.ndata = len(X[:, 0])
         self.parallel_fd = os.environ.get("TGP_ML_PARALLEL", "1") != "0" and self.ndata <= _PARALLEL_MAX_N
+        # "fd": the reference's fit (SciPy differentiates numerically, log_likelihood.py:57).  "analytic": L-BFGS-B is given
+        # the exact gradient instead (log_likelihood_gradient; Gaussian kernels only) -- a different path through theta-space
+        # to the same optimum, opt-in
+        self.gradient = os.environ.get("TGP_ML_GRADIENT", "fd")
 
     def log_likelihood(self, kernel, ctx=None, resident=None):
         """-0.5 y.K^-1.y - (n/2) log 2 pi - 0.5 log det K; any failure (e.g. K not positive
@@ -66,6 +70,26 @@ class log_likelihood(object):
         if not np.isfinite(ll):
             ll = -np.inf
         return ll
+
+    def log_likelihood_gradient(self, kernel, ctx=None):
+        """(log L, d log L / d theta): 1/2 tr((alpha alpha^T - K^-1) dK/dtheta_k) with the kernel derivative of
+        ``treegp/kernels.py:128-150``; K^-1 is formed on the device from the factor of the same solve
+        (``ops.gp_loglik_grad``).  Failures give (-inf, zeros) as ``log_likelihood`` gives -inf."""
+        ntheta = len(kernel.theta)
+        try:
+            spec = kernel_to_spec(kernel)
+            jac = spec_jacobian(kernel)
+            alpha, log_det, chi2, factor = ops.gp_solve(spec, self.X, self.y, self.y_err, keep=True, ctx=ctx)
+            try:
+                g4 = ops.gp_loglik_grad(spec, factor, self.X, alpha, ctx=ctx)
+            finally:
+                factor.free()
+            ll = -0.5 * chi2 - (0.5 * self.ndata) * np.log(2.0 * np.pi) - 0.5 * log_det
+        except (np.linalg.LinAlgError, FloatingPointError, ValueError, ops._lib.TgpError):
+            return -np.inf, np.zeros(ntheta)
+        if not np.isfinite(ll):
+            return -np.inf, np.zeros(ntheta)
+        return ll, jac.dot(g4)
 
     def optimizer(self, kernel):
         """L-BFGS-B on -log L over theta (log_likelihood.py:43-62)."""
@@ -93,7 +117,16 @@ class log_likelihood(object):
         return fitted
 
     def _minimise(self, cost, template):
-        if self.parallel_fd:
+        if self.gradient == "analytic":
+            work = template.clone_with_theta(template.theta)
+
+            def cost_and_gradient(theta):
+                work.theta = theta
+                ll, grad = self.log_likelihood_gradient(work)
+                return -ll, -grad
+
+            best = optimize.minimize(cost_and_gradient, template.theta, jac=True, method="L-BFGS-B")["x"]
+        elif self.parallel_fd:
             ntheta = len(template.theta)
             ctxs = _contexts(ntheta + 1)
             works = [template.clone_with_theta(template.theta) for _ in range(ntheta + 1)]

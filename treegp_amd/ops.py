@@ -206,6 +206,20 @@ def gp_predict_cov(spec, factor, X, Xs, ctx=None):
     return cov
 
 
+def gp_loglik_grad(spec, factor, X, alpha, ctx=None):
+    """1/2 sum_ij (alpha_i alpha_j - [K^-1]_ij) dK_ij/dp for p = (log amp, a, b, c), from the factor and alpha of one
+    ``gp_solve(..., keep=True)`` (include/tgp.h, seam S2d).  Gaussian kernels only; ``kernels.spec_jacobian`` maps the four
+    numbers to d logL / d theta."""
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    X2 = as_xy(X)
+    alpha = f64(alpha)
+    grad = np.empty(4)
+    rc = lib.tgp_gp_loglik_grad(ctx, factor._h, C.byref(spec.to_c()), ptr(X2), X2.shape[0], ptr(alpha), ptr(grad))
+    check(ctx, rc, "tgp_gp_loglik_grad")
+    return grad
+
+
 # ---- pair binning across ranks (SURVEY 8e): i-tiles / bootstrap resamples dealt to the ranks ------
 _pair = threading.local()                  # per thread: the tests run virtual ranks as threads
 
