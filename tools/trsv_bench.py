@@ -42,7 +42,7 @@ def run(n, reps=3):
     os.environ.pop("TGP_POTRS_BIG_FROM", None)
     a, b = res["chain128"][1], res["big"][1]
     bytes_alg = 8.0 * Np * Np
-    print(json.dumps(dict(n=n, step=int(os.environ.get("TGP_POTRS_STEP", "1024")), chain128_ms=res["chain128"][0], big_ms=res["big"][0],
+    print(json.dumps(dict(n=n, step=int(os.environ.get("TGP_POTRS_STEP", "512" if Np < 12288 else "1024")), chain128_ms=res["chain128"][0], big_ms=res["big"][0],
                           chain128_GBps=bytes_alg / res["chain128"][0] / 1e6, big_GBps=bytes_alg / res["big"][0] / 1e6,
                           big_frac_hbm=bytes_alg / res["big"][0] / 1e6 / 8000, max_rel_diff=float(np.abs(a - b).max() / np.abs(a).max()))),
           flush=True)

@@ -458,6 +458,7 @@ void tgp_factor_free(tgp_ctx *ctx, tgp_factor *f) {
     if (f->d_A) (void)hipFree(f->d_A);
     if (f->d_W) (void)hipFree(f->d_W);
     if (f->d_slabs) (void)hipFree(f->d_slabs);
+    if (f->d_slabs2) (void)hipFree(f->d_slabs2);
     delete f;
 }
 

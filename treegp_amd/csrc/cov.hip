@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void cov_update_kernel(double *Bt, int64_t 
     gemm_tile_dtv<4, TGP_TB, 1>(a, b, cc, nullptr, nullptr);
 }
 
-// ---- the substitution in steps of S = 1024 columns, with the factor's inverse slabs (trsv_big.hip) -------------------------
+// ---- the substitution in steps of S = 1024 (512) columns, with the factor's inverse slabs (trsv_big.hip) -------------------------
 //   T  = Bt[:, K] V_K^T            (V_K = inverse of the S x S diagonal block: k <= j, 256-deep segments; out of place)
 //   Bt[:, c] -= Bt[:, K] L[c, K]^T  for the tile columns c right of super-block K, ONE pass of depth 1024 on the DTV tile
 // instead of eight dependent pairs of depth-128 launches per super-block.
@@ -77,18 +77,19 @@ __global__ __launch_bounds__(256) void cov_diag_big_kernel(const double *__restr
     gemm_tile_128<0, TGP_PW, TGP_PW, TileDefault, 0>(a, b, c, nullptr, nullptr, nullptr, nseg, Mp * TGP_PW, Np * TGP_PW);
 }
 
+template <int NS>                                                          // NS = S / 256 panels per super-block
 __global__ __launch_bounds__(256, 2) void cov_update_big_kernel(double *Bt, int64_t Mp, const double *A, int64_t Np, int64_t r0) {
     const int64_t ti = blockIdx.x;
     const int64_t p0 = r0 >> 8;
-    const int64_t c = (r0 >> 7) + 8 + blockIdx.y;                        // global 128-tile column right of the super-block
-    SegPtrs<4> sp;
+    const int64_t c = (r0 >> 7) + 2 * NS + blockIdx.y;                   // global 128-tile column right of the super-block
+    SegPtrs<NS> sp;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < NS; ++s) {
         sp.a[s] = Bt + (p0 + s) * Mp * TGP_PW + ti * TGP_TB * TGP_PW;
         sp.b[s] = A + panel_off(p0 + s, Np) + (c * TGP_TB - (p0 + s) * TGP_PW) * TGP_PW;
     }
     double *cc = Bt + (c >> 1) * Mp * TGP_PW + ti * TGP_TB * TGP_PW + (c & 1) * TGP_TB;
-    gemm_tile_dtv_segs<4, TGP_PW, 4>(sp, cc);
+    gemm_tile_dtv_segs<4, TGP_PW, NS>(sp, cc);
 }
 
 // C(ti, tj) -= sum over all panels of Bt[ti] Bt[tj]^T        (C in the same panel layout, Mp rows)
@@ -136,10 +137,10 @@ int cov_substitute(tgp_ctx *ctx, tgp_factor *f, const CovPlan &pl, bool tri) {
     int S = 0;
     const double *slabs = nullptr;
     if (!no_big) {
-        int rc = factor_slabs(ctx, f, &S, &slabs);
+        int rc = factor_slabs(ctx, f, 1024, &S, &slabs);
         if (rc) return rc;
     }
-    if (S == 1024 && slabs) {
+    if ((S == 1024 || S == 512) && slabs) {
         int rc = tgp_ensure_scratch2(ctx, (size_t)pl.Mp * S * sizeof(double));
         if (rc) return rc;
         double *T = (double *)ctx->scratch2;
@@ -152,7 +153,8 @@ int cov_substitute(tgp_ctx *ctx, tgp_factor *f, const CovPlan &pl, bool tri) {
                 TGP_HIP(hipMemcpyAsync(pl.d_Bt + ((r0 >> 8) + q) * pl.Mp * TGP_PW, T + q * pl.Mp * TGP_PW,
                                        (size_t)mte * TGP_TB * TGP_PW * sizeof(double), hipMemcpyDeviceToDevice, st));
             const int64_t right = (pl.Np - (r0 + rows)) / TGP_TB;
-            if (right > 0) cov_update_big_kernel<<<dim3(mte, (unsigned)right), 256, 0, st>>>(pl.d_Bt, pl.Mp, f->d_A, pl.Np, r0);
+            if (right > 0 && S == 1024) cov_update_big_kernel<4><<<dim3(mte, (unsigned)right), 256, 0, st>>>(pl.d_Bt, pl.Mp, f->d_A, pl.Np, r0);
+            if (right > 0 && S == 512) cov_update_big_kernel<2><<<dim3(mte, (unsigned)right), 256, 0, st>>>(pl.d_Bt, pl.Mp, f->d_A, pl.Np, r0);
         }
     } else {
         for (int kb = 0; kb < nb; ++kb) {

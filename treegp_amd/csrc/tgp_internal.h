@@ -57,6 +57,8 @@ struct tgp_factor {
     double *d_W = nullptr;        // inverted 128x128 diagonal blocks
     double *d_slabs = nullptr;    // inverse slabs of the big-step sweeps, built by the first solve with this factor
     int slab_S = 0;               // the step they were built for
+    double *d_slabs2 = nullptr;   // slabs of another step for the block substitution of cov.hip (factor_slabs)
+    int slab2_S = 0;
 };
 
 #define TGP_HIP(call)                                                                   \
@@ -159,7 +161,7 @@ int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np,
                  double **slab_cache = nullptr, int *slab_S = nullptr);
 int launch_potrs_128(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only);
 size_t vslab_bytes(int64_t Np, int S);
-int factor_slabs(tgp_ctx *ctx, tgp_factor *f, int *S, const double **slabs);
+int factor_slabs(tgp_ctx *ctx, tgp_factor *f, int want_S, int *S, const double **slabs);
 int launch_vslab_build(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, int S, double *slabs);
 // slabs being built on the side stream in chunks of `chunk` super-blocks while the forward sweep already runs: ready[c] is
 // recorded behind chunk c (chunk 0 is built on the sweep's own stream)

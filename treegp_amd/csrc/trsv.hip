@@ -354,7 +354,10 @@ __global__ __launch_bounds__(256) void fwd_update256_kernel(const double *__rest
 // Big-step sweeps (trsv_big.hip) from TGP_POTRS_BIG_FROM rows on (default 2048; 0 = never); TGP_POTRS_STEP = 512 | 1024.
 static bool potrs_big_config(int64_t Np, int *S) {
     const int64_t big_from = getenv("TGP_POTRS_BIG_FROM") ? atoll(getenv("TGP_POTRS_BIG_FROM")) : 2048;
-    const int step_env = getenv("TGP_POTRS_STEP") ? atoi(getenv("TGP_POTRS_STEP")) : 1024;
+    // step: 512 below Np = 12 288, 1024 from there.  The third doubling level of the slab build (512 -> 1024) is 2 x 2 Np 512^2
+    // flops on Np / 8 tiles -- at Np = 8192 half a GPU for 0.15 ms, more than the eight extra sweep launches it saves
+    // (measured 512 / 1024: Np = 2304 0.129 / 0.157 ms, 4096 0.175 / 0.224, 8192 0.384 / 0.455, 16 384 0.976 / 0.948, 32 768 2.50 / 2.46).
+    const int step_env = getenv("TGP_POTRS_STEP") ? atoi(getenv("TGP_POTRS_STEP")) : (Np < 12288 ? 512 : 1024);
     *S = step_env == 512 ? 512 : 1024;
     return big_from > 0 && Np >= big_from;
 }
@@ -417,16 +420,20 @@ static int build_slabs_pipelined(tgp_ctx *ctx, const double *d_A, const double *
     return 0;
 }
 
-// the inverse slabs of a kept factor (built on first use), for code outside the sweeps (posterior covariance); *S = 0 when
-// the problem is below the big-step threshold
-int factor_slabs(tgp_ctx *ctx, tgp_factor *f, int *S, const double **slabs) {
+// the inverse slabs of a kept factor (built on first use), for code outside the sweeps (posterior covariance, likelihood
+// gradient); *S = 0 when the problem is below the big-step threshold.  want_S = 0: whatever step the sweeps use (their
+// cache); want_S = 1024 while the sweeps run in 512-steps (Np < 12 288): a second cache of the factor -- the block
+// substitution of cov.hip is MFMA work and prefers the deeper step (10.2 against 10.9 ms at N = 8192, M = 4096).
+int factor_slabs(tgp_ctx *ctx, tgp_factor *f, int want_S, int *S, const double **slabs) {
     *slabs = nullptr;
     *S = 0;
     int step;
     if (!potrs_big_config(f->Np, &step)) return 0;
+    const bool own = want_S && want_S != step && !getenv("TGP_POTRS_STEP");
+    if (own) step = want_S;
     double *sl = nullptr;
     bool build = false;
-    int rc = acquire_slabs(ctx, f->Np, step, &f->d_slabs, &f->slab_S, &sl, &build);
+    int rc = acquire_slabs(ctx, f->Np, step, own ? &f->d_slabs2 : &f->d_slabs, own ? &f->slab2_S : &f->slab_S, &sl, &build);
     if (rc) return rc;
     if (build) {
         rc = launch_vslab_build(ctx, f->d_A, f->d_W, f->Np, step, sl);
