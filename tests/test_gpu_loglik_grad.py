@@ -101,3 +101,24 @@ def test_fit_with_the_analytic_gradient_reaches_the_reference_optimum(golden, mo
         ref_l = float(g[tag + "_logL"])
         assert gp._optimizer._logL >= ref_l - 1e-6 * abs(ref_l), (gp._optimizer._logL, ref_l)
         np.testing.assert_allclose(gp.kernel.theta, g[tag + "_theta"], atol=2e-3)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 128, 129, 255, 256, 257, 300, 513, 2049])
+def test_gradient_against_the_oracle_at_ragged_sizes(n):
+    """Partial tiles, partial panels, one point, one point past a panel / a 1024-step; 2-D sheared and 1-D kernels."""
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(100 + n)
+    for nd, kern in ((2, "0.7**2 * AnisotropicRBF(invLam=array([[40., -9.], [-9., 25.]]))"), (1, "1.1**2 * AnisotropicRBF(scale_length=[0.2])")):
+        X = rng.uniform(0, 1, (n, nd))
+        y = np.sin(5 * X[:, 0]) + 0.1 * rng.standard_normal(n)
+        y_err = 0.1 * rng.uniform(0.8, 1.2, n)
+        k = treegp.eval_kernel(kern)
+        spec = kernel_to_spec(k)
+        alpha, _, _, fac = ops.gp_solve(spec, X, y, y_err, keep=True)
+        g4 = ops.gp_loglik_grad(spec, fac, X, alpha)
+        fac.free()
+        invLam = np.array([[spec.a, spec.b], [spec.b, spec.c]])[:nd, :nd]
+        basis = [np.array([[1.0, 0], [0, 0]])[:nd, :nd], np.array([[0, 1.0], [1.0, 0]])[:nd, :nd], np.array([[0, 0], [0, 1.0]])[:nd, :nd]]
+        g_amp, g_abc = O.loglik_grad_invlam(X, y, y_err, spec.amp, invLam, basis)
+        ref = np.concatenate([[g_amp], g_abc])
+        np.testing.assert_allclose(g4, ref, rtol=1e-8, atol=1e-8 * max(np.abs(ref).max(), 1.0), err_msg="n=%d nd=%d" % (n, nd))
