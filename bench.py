@@ -33,7 +33,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix peak
 def cpu_baseline(n_s, m_s, n_headline):
     """The reference's own SciPy call sequence (oracle/cpu_reference_path.py) on the host cores, protocol of
     BASELINE.md section 3: BLAS threads = the fastest of {cgroup quota, physical cores, half, quarter, 16, 32}
-    on a dpotrf probe, 1 warm-up + 5 timed passes (3 if the time budget is spent), median per phase; sample =
+    on a dpotrf probe, 1 warm-up + 5 timed passes (fewer, never below 3, only if a 90 s budget is spent), median per phase; sample =
     configs[1] in full (N=8192 / M=32768).  `extrapolated_n65536` scales the measured phases to the headline size
     (dpotrf by N^3, pair loops by N^2 and M N) and is labelled as such."""
     from oracle import cpu_reference_path as R
@@ -278,7 +278,7 @@ def main():
                 out["roofline_kbuild"] = {"bound": "hbm", "achieved": out["kbuild_GBps"], "peak": 8000.0, "unit": "GB/s",
                                           "frac": out["kbuild_GBps"] / 8000.0, "traffic": kb_t, "traffic_source": kb_src,
                                           "algorithmic_bytes": acc["kbuild_bytes"] / K,
-                                          "kernel": "kbuild_lower_kernel<GAUSS>", "avg_launch_ms": acc["kbuild_ms"] / K}
+                                          "kernel": "kbuild_slab_kernel<GAUSS>", "avg_launch_ms": acc["kbuild_ms"] / K}
             # both triangular sweeps read the packed factor once each, ~8 Np^2 bytes per solve
             npad = (n + 255) // 256 * 256
             tr_bytes = 2 * 8.0 * (npad * (npad + 1) / 2.0)

@@ -118,9 +118,9 @@ def pick_blas_threads(candidates, n=4096):
     return max(rates, key=rates.get), rates
 
 
-def timed_passes(X, y, y_err, Xs, invLam, amp, threads, passes=5, budget_s=45.0):
+def timed_passes(X, y, y_err, Xs, invLam, amp, threads, passes=5, budget_s=90.0):
     """1 warm-up + up to ``passes`` timed passes of solve_predict with BLAS limited to ``threads``; stops early (never
-    below 3 timed passes) when the time budget is spent.  Returns ({phase: median seconds}, number of timed passes)."""
+    below 3 timed passes) when the time budget is spent -- configs[1] in full is ~10 s a pass on 16 threads, 5 passes fit.  Returns ({phase: median seconds}, number of timed passes)."""
     from threadpoolctl import threadpool_limits
     rows = []
     t_start = time.perf_counter()
