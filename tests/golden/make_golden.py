@@ -185,6 +185,18 @@ def make_g14(tg):
         out.update({tag + "_kernel": kern, tag + "_X": X, tag + "_y": y, tag + "_y_err": y_err, tag + "_theta": k.theta,
                     tag + "_grad": grad, tag + "_logL": logL})
     out["tags"] = np.array([c[0] for c in cases])
+    # the kernel derivatives themselves, kernel(X, eval_gradient=True), 40 points: AnisotropicRBF 2-D / 1-D under a Product
+    # (kernels.py:128-150 + scikit-learn's Product rule) and what VonKarman returns there (kernels.py:278-288)
+    Xk = rng.uniform(0, 1, (40, 2))
+    kg = {"kg_arbf2d": "0.8**2 * AnisotropicRBF(invLam={0!r})".format(np.linalg.inv(corr_len_matrix(0.3, 0.25, -0.1))),
+          "kg_arbf1d": "1.3**2 * AnisotropicRBF(scale_length=[0.4])", "kg_arbf_bare": "AnisotropicRBF(scale_length=[0.5, 0.2])",
+          "kg_vk": "1.1**2 * VonKarman(length_scale=0.7)"}
+    for tag, kern in kg.items():
+        Xc = Xk[:, :1] if tag == "kg_arbf1d" else Xk
+        K, dK = tg.eval_kernel(kern)(Xc, eval_gradient=True)
+        out.update({tag + "_kernel": kern, tag + "_K": K, tag + "_dK": dK})
+    out["kg_X"] = Xk
+    out["kg_tags"] = np.array(list(kg))
     np.savez(os.path.join(OUT, "g14_loglik_grad.npz"), **out)
 
 

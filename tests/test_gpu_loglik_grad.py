@@ -122,3 +122,20 @@ def test_gradient_against_the_oracle_at_ragged_sizes(n):
         g_amp, g_abc = O.loglik_grad_invlam(X, y, y_err, spec.amp, invLam, basis)
         ref = np.concatenate([[g_amp], g_abc])
         np.testing.assert_allclose(g4, ref, rtol=1e-8, atol=1e-8 * max(np.abs(ref).max(), 1.0), err_msg="n=%d nd=%d" % (n, nd))
+
+
+def test_kernel_call_with_eval_gradient_against_reference(golden):
+    """g14 kg_*: ``kernel(X, eval_gradient=True)`` through scikit-learn's Product with K from the device: AnisotropicRBF's
+    derivative (kernels.py:128-150), VonKarman's K * distance (kernels.py:278-288), and the errors of the other paths."""
+    g = golden("g14_loglik_grad.npz")
+    X = g["kg_X"]
+    for tag in g["kg_tags"]:
+        k = treegp.eval_kernel(str(g[tag + "_kernel"]))
+        K, dK = k(X[:, :1] if tag == "kg_arbf1d" else X, eval_gradient=True)
+        np.testing.assert_allclose(K, g[tag + "_K"], rtol=1e-12, atol=1e-14, err_msg=tag)
+        assert dK.shape == g[tag + "_dK"].shape
+        np.testing.assert_allclose(dK, g[tag + "_dK"], rtol=1e-11, atol=1e-13, err_msg=tag)
+    with pytest.raises(ValueError, match="can not be evaluated"):
+        treegp.eval_kernel("AnisotropicVonKarman(invLam=array([[2., 0.], [0., 3.]]))")(X, eval_gradient=True)
+    with pytest.raises(ValueError, match="only be evaluated when Y is None"):
+        treegp.eval_kernel("AnisotropicRBF(scale_length=[0.5, 0.2])")(X, Y=X, eval_gradient=True)

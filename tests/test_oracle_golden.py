@@ -261,3 +261,20 @@ def test_loglik_gradient_against_reference_kernel_derivative(golden):
         grad = J.dot(np.concatenate([[g_amp], g_abc]))
         ref = g[tag + "_grad"]
         np.testing.assert_allclose(grad, ref, rtol=1e-7, atol=1e-7 * np.abs(ref).max(), err_msg=tag)
+
+
+def test_kernel_derivative_host_arithmetic_against_reference(golden):
+    """g14 kg_*: kernel(X, eval_gradient=True) of the reference.  The product's classes take K from the device and form dK/dtheta on
+    the host; here the same host arithmetic is fed the reference's K (no GPU) and has to reproduce the reference's dK."""
+    import treegp_amd as treegp
+    g = golden("g14_loglik_grad.npz")
+    X = g["kg_X"]
+    k = treegp.eval_kernel(str(g["kg_arbf_bare_kernel"]))
+    np.testing.assert_allclose(k._gradient(X, g["kg_arbf_bare_K"]), g["kg_arbf_bare_dK"], rtol=1e-13, atol=1e-15)
+    k = treegp.eval_kernel(str(g["kg_arbf2d_kernel"]))                    # Product(ConstantKernel, AnisotropicRBF)
+    unit = g["kg_arbf2d_K"] / k.k1.constant_value
+    np.testing.assert_allclose(k.k1.constant_value * k.k2._gradient(X, unit), g["kg_arbf2d_dK"][:, :, 1:], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(g["kg_arbf2d_dK"][:, :, 0], g["kg_arbf2d_K"], rtol=1e-14)       # d/d log sigma^2
+    k = treegp.eval_kernel(str(g["kg_arbf1d_kernel"]))
+    unit = g["kg_arbf1d_K"] / k.k1.constant_value
+    np.testing.assert_allclose(k.k1.constant_value * k.k2._gradient(X[:, :1], unit), g["kg_arbf1d_dK"][:, :, 1:], rtol=1e-13, atol=1e-15)

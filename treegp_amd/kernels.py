@@ -107,14 +107,26 @@ class _CholeskyParametrised(StationaryKernelMixin, NormalizedKernelMixin, Kernel
 
     def __call__(self, X, Y=None, eval_gradient=False):
         X = np.atleast_2d(X)
-        if eval_gradient:
-            if Y is not None:
-                raise ValueError("Gradient can only be evaluated when Y is None.")
-            raise NotImplementedError("kernel gradients are outside the GPU hot path "
-                                      "(no treegp optimiser requests them: log_likelihood.py:57 passes no jac)")
+        if eval_gradient and Y is not None:
+            raise ValueError("Gradient can only be evaluated when Y is None.")
         if X.shape[1] != self.ndim:
             raise ValueError("X has %d columns, kernel has ndim=%d" % (X.shape[1], self.ndim))
-        return ops.kernel_matrix(self._spec(), X, None if Y is None else np.atleast_2d(Y))
+        K = ops.kernel_matrix(self._spec(), X, None if Y is None else np.atleast_2d(Y))
+        if not eval_gradient:
+            return K
+        return K, self._gradient(X, K)
+
+    def invLam_gradient(self):
+        """d invLam / d theta_k, shape (ntheta, ndim, ndim): dL L^T + L dL^T with dL the single-element matrices of
+        ``treegp/kernels.py:138-145`` (L_kk for the log-diagonal thetas, 1 for the strictly-lower ones)."""
+        dL = np.zeros((self.ntheta, self.ndim, self.ndim))
+        dL[(np.arange(self.ndim),) + self._d] = self._L[self._d]
+        dL[(np.arange(self.ndim, self.ntheta),) + self._t] = 1.0
+        half = np.dot(dL, self._L.T)
+        return half + np.transpose(half, (0, 2, 1))
+
+    def _gradient(self, X, K):
+        raise ValueError("Gradient can not be evaluated.")          # AnisotropicVonKarman, kernels.py:383-384
 
 
 class AnisotropicRBF(_CholeskyParametrised):
@@ -125,6 +137,21 @@ class AnisotropicRBF(_CholeskyParametrised):
     :param bounds:        bounds on theta, (2,) or (ntheta, 2).
     """
     _tgp_kind = _lib.TGP_ARBF
+
+    def _gradient(self, X, K):
+        """dK/dtheta_k = -1/2 K dX^T (d invLam/d theta_k) dX (kernels.py:128-150), from the device's K; host arithmetic on
+        (n, n) arrays, one per theta -- nothing on the fit's path asks for it (log_likelihood.py:57 passes no jac; the
+        likelihood gradient has its own device entry point, ops.gp_loglik_grad)."""
+        d = [X[:, None, a] - X[None, :, a] for a in range(self.ndim)]
+        out = np.empty(K.shape + (self.ntheta,))
+        for k, g in enumerate(self.invLam_gradient()):
+            q = np.zeros_like(K)
+            for a in range(self.ndim):
+                for b in range(self.ndim):
+                    if g[a, b] != 0.0:
+                        q += g[a, b] * d[a] * d[b]
+            out[:, :, k] = -0.5 * K * q
+        return out
 
 
 class AnisotropicVonKarman(_CholeskyParametrised):
@@ -159,11 +186,16 @@ class VonKarman(StationaryKernelMixin, NormalizedKernelMixin, Kernel):
 
     def __call__(self, X, Y=None, eval_gradient=False):
         X = np.atleast_2d(X)
-        if eval_gradient:
-            if Y is not None:
-                raise ValueError("Gradient can only be evaluated when Y is None.")
-            raise NotImplementedError("kernel gradients are outside the GPU hot path")
-        return ops.kernel_matrix(self._spec(), X, None if Y is None else np.atleast_2d(Y))
+        if eval_gradient and Y is not None:
+            raise ValueError("Gradient can only be evaluated when Y is None.")
+        K = ops.kernel_matrix(self._spec(), X, None if Y is None else np.atleast_2d(Y))
+        if not eval_gradient:
+            return K
+        # what the reference returns (kernels.py:278-288): K times the Euclidean distances -- not dK/d log l, reproduced as is
+        if self.hyperparameter_length_scale.fixed:
+            return K, np.empty((X.shape[0], X.shape[0], 0))
+        diff = X[:, None, :] - X[None, :, :]
+        return K, (K * np.sqrt(np.sum(diff * diff, axis=-1)))[:, :, np.newaxis]
 
     def __repr__(self):
         name = type(self).__name__
@@ -231,16 +263,9 @@ def spec_jacobian(kernel):
             return np.zeros((0, 4))
         return np.array([[1.0, 0.0, 0.0, 0.0]])
     if isinstance(kernel, AnisotropicRBF):
-        L, nd = kernel._L, kernel.ndim
+        nd = kernel.ndim
         rows = []
-        for k in range(kernel.ntheta):
-            dL = np.zeros((nd, nd))
-            if k < nd:
-                dL[k, k] = L[k, k]                          # theta_k = log L_kk
-            else:
-                dL[kernel._t[0][k - nd], kernel._t[1][k - nd]] = 1.0
-            half = dL.dot(L.T)
-            g = half + half.T
+        for g in kernel.invLam_gradient():
             rows.append([0.0, g[0, 0], g[0, 1] if nd == 2 else 0.0, g[1, 1] if nd == 2 else 0.0])
         return np.array(rows).reshape(kernel.ntheta, 4)
     if type(kernel) is RBF:
