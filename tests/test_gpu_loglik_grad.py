@@ -31,7 +31,7 @@ def test_gradient_against_reference_kernel_derivative(golden, tag):
     assert ll.log_likelihood(k) == pytest.approx(value, rel=1e-12)
 
 
-@pytest.mark.parametrize("n", [1000, 3000, 4096])
+@pytest.mark.parametrize("n", [1000, 3000, 4096, 16640])
 def test_gradient_against_central_differences_of_the_device_likelihood(n):
     rng = np.random.default_rng(n)
     X = rng.uniform(0, 1, (n, 2))
