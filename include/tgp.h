@@ -126,6 +126,10 @@ int tgp_gp_predict_cov_dense(tgp_ctx *ctx, tgp_factor *f, const double *HT, cons
  * (2/3 n^3 flops, two n x n buffers) and never leaves it.                                                             */
 int tgp_gp_loglik_grad(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel *k, const double *X, int64_t n,
                        const double *alpha, double *grad);
+/* K build + factorisation + solve + the gradient above in one call, for X (n, 2), y, yerr (may be NULL) that live on the
+ * device (tgp_dev_alloc / tgp_h2d): what one evaluation of a gradient-driven fit needs; the factor is not kept.        */
+int tgp_d_gp_solve_grad(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_y,
+                        const double *d_yerr, double *logdet, double *ydota, double *grad);
 
 /* ---- S4: binned scalar pair correlation, exact binning -----------------------------------
  * w == NULL: unit weights.  TwoD: nbins x nbins pixels over [-max_sep, max_sep]^2, outputs

@@ -139,3 +139,32 @@ def test_kernel_call_with_eval_gradient_against_reference(golden):
         treegp.eval_kernel("AnisotropicVonKarman(invLam=array([[2., 0.], [0., 3.]]))")(X, eval_gradient=True)
     with pytest.raises(ValueError, match="only be evaluated when Y is None"):
         treegp.eval_kernel("AnisotropicRBF(scale_length=[0.5, 0.2])")(X, Y=X, eval_gradient=True)
+
+
+def test_fused_resident_call_equals_the_two_step_route():
+    """tgp_d_gp_solve_grad (data on the device, factor back to the context's cache) = tgp_gp_solve(keep) + tgp_gp_loglik_grad,
+    bit for bit; repeated calls with other kernels reuse the cache; a failing factorisation raises as gp_solve does."""
+    rng = np.random.default_rng(9)
+    n = 900
+    X = rng.uniform(0, 1, (n, 2))
+    y = np.cos(4 * X[:, 0]) + 0.05 * rng.standard_normal(n)
+    y_err = 0.05 * rng.uniform(0.8, 1.2, n)
+    prob = ops.ResidentProblem(X, y, y_err)
+    try:
+        for kern in ("0.9**2 * AnisotropicRBF(invLam=array([[95., 21.], [21., 140.]]))", "1.4**2 * RBF(0.11)",
+                     "0.9**2 * AnisotropicRBF(invLam=array([[60., -5.], [-5., 80.]]))"):
+            spec = kernel_to_spec(treegp.eval_kernel(kern))
+            ld, chi2, g4 = ops.gp_solve_grad_resident(spec, prob)
+            alpha, ld2, chi22, fac = ops.gp_solve(spec, X, y, y_err, keep=True)
+            g4b = ops.gp_loglik_grad(spec, fac, X, alpha)
+            fac.free()
+            assert ld == ld2 and chi2 == chi22
+            assert np.array_equal(g4, g4b)
+        bad = ops.ResidentProblem(np.vstack([X[:5], X[:5]]), np.ones(10), None)       # duplicate points, no noise: singular
+        with pytest.raises(np.linalg.LinAlgError):
+            ops.gp_solve_grad_resident(spec, bad)
+        bad.close()
+        ld3, _, g4c = ops.gp_solve_grad_resident(spec, prob)                          # the context still works afterwards
+        assert ld3 == ld and np.array_equal(g4c, g4)
+    finally:
+        prob.close()

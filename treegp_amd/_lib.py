@@ -67,6 +67,7 @@ SIGNATURES = {
     "tgp_factor_solve": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "tgp_gp_predict_cov_dense": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "tgp_gp_loglik_grad": (C.c_int, [_vp, _vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp]),
+    "tgp_d_gp_solve_grad": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp, _dp, _dp, _vp]),
     "tgp_d_unpack_lower": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "tgp_debug_syrk_loop": (C.c_int, [_vp, _vp, _i64, C.c_int, _dp, _dp]),
     "tgp_debug_tilemap": (C.c_int, [_i64, _vp, _vp, _i64]),

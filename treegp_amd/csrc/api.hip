@@ -89,6 +89,22 @@ static int ensure_factor_cache(tgp_ctx *ctx, int64_t Np) {
     return 0;
 }
 
+int tgp_ensure_io(tgp_ctx *ctx, size_t bytes) { return ensure_io(ctx, bytes); }
+void *tgp_io_buffer(tgp_ctx *ctx) { return ext_of(ctx)->io.buf; }
+// a kept factor goes back to being the context's factor cache (the next tgp_d_gp_solve of the same size reuses its memory)
+void tgp_factor_release_to_cache(tgp_ctx *ctx, tgp_factor *f) {
+    if (!f) return;
+    tgp_ctx_ext *e = ext_of(ctx);
+    if (e->A_cache) (void)hipFree(e->A_cache);
+    if (e->W_cache) (void)hipFree(e->W_cache);
+    e->A_cache = f->d_A;
+    e->W_cache = f->d_W;
+    e->cache_Np = f->Np;
+    if (f->d_slabs) (void)hipFree(f->d_slabs);
+    if (f->d_slabs2) (void)hipFree(f->d_slabs2);
+    delete f;
+}
+
 extern "C" {
 
 const char *tgp_version(void) { return "treegp_amd libtgp 0.1 (gfx950)"; }

@@ -325,27 +325,18 @@ __global__ __launch_bounds__(256) void loglik_grad_reduce_kernel(const double *_
 }
 }  // namespace
 
-extern "C" int tgp_gp_loglik_grad(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel *k, const double *X, int64_t n, const double *alpha,
-                                  double *grad) {
-    TGP_ARG(f && k && X && alpha && grad && n == f->n);
-    if (kind_to_ke(k->kind) != KE_GAUSS) {
-        ctx->err = "tgp_gp_loglik_grad: analytic derivatives exist for the Gaussian kernels only (RBF, AnisotropicRBF), as in the "
-                   "reference (treegp/kernels.py:128-150)";
-        return -1;
-    }
-    TGP_HIP(hipSetDevice(ctx->device));
+// d_X (2 n) and d_alpha (n) on the device; grad: 4 doubles on the host.  Synchronises the stream.
+int launch_loglik_grad(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel *k, const double *d_X, const double *d_alpha, double *grad) {
     hipStream_t st = ctx->stream;
+    const int64_t n = f->n;
     CovPlan pl;
-    int rc = cov_plan(ctx, f, n, true, &pl);              // m = n: d_Bt (Np x Np) <- L^-T, d_C (Np x Np) <- -K^-1; d_Xs holds alpha
+    int rc = cov_plan(ctx, f, n, false, &pl);             // m = n: d_Bt (Np x Np) <- L^-T, d_C (Np x Np) <- -K^-1
     if (rc) return rc;
     const int64_t nrb = (n + 63) / 64;
     const int64_t nparts = nrb * pl.nP;
     rc = tgp_ensure_scratch2(ctx, (size_t)(nparts * 4 + 4) * sizeof(double) > (size_t)pl.Mp * 1024 * sizeof(double)
                                       ? (size_t)(nparts * 4 + 4) * sizeof(double) : (size_t)pl.Mp * 1024 * sizeof(double));
     if (rc) return rc;
-    TGP_HIP(hipEventRecord(ctx->ev[0], st));
-    TGP_HIP(hipMemcpyAsync(pl.d_X, X, 2 * n * 8, hipMemcpyHostToDevice, st));
-    TGP_HIP(hipMemcpyAsync(pl.d_Xs, alpha, n * 8, hipMemcpyHostToDevice, st));
     TGP_HIP(hipMemsetAsync(pl.d_Bt, 0, (size_t)pl.Mp * pl.Np * 8, st));
     TGP_HIP(hipMemsetAsync(pl.d_C, 0, (size_t)pl.Mp * pl.Mp * 8, st));
     ident_panels_kernel<<<(unsigned)(pl.Np / 256), 256, 0, st>>>(pl.d_Bt, pl.Mp, pl.Np);
@@ -354,14 +345,58 @@ extern "C" int tgp_gp_loglik_grad(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel 
     const int64_t mt = pl.Mp / TGP_TB;
     kinv_syrk_kernel<<<(unsigned)(mt * (mt + 1) / 2), 256, 0, st>>>(pl.d_C, pl.d_Bt, pl.Mp, pl.nP);
     double *partial = (double *)ctx->scratch2;             // the substitution's staging buffer is free again
-    loglik_grad_kernel<<<dim3((unsigned)pl.nP, (unsigned)nrb), 256, 0, st>>>(make_kparams(k), pl.d_X, pl.d_Xs, pl.d_C, pl.Mp, n, partial);
+    loglik_grad_kernel<<<dim3((unsigned)pl.nP, (unsigned)nrb), 256, 0, st>>>(make_kparams(k), d_X, d_alpha, pl.d_C, pl.Mp, n, partial);
     loglik_grad_reduce_kernel<<<1, 256, 0, st>>>(partial, nparts, partial + nparts * 4);
     TGP_HIP(hipGetLastError());
-    TGP_HIP(hipEventRecord(ctx->ev[1], st));
+    TGP_HIP(hipEventRecord(ctx->ev[4], st));
     TGP_HIP(hipMemcpyAsync(grad, partial + nparts * 4, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
     TGP_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+static int loglik_grad_kind_check(tgp_ctx *ctx, const tgp_kernel *k) {
+    if (kind_to_ke(k->kind) == KE_GAUSS) return 0;
+    ctx->err = "tgp_gp_loglik_grad: analytic derivatives exist for the Gaussian kernels only (RBF, AnisotropicRBF), as in the "
+               "reference (treegp/kernels.py:128-150)";
+    return -1;
+}
+
+extern "C" int tgp_gp_loglik_grad(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel *k, const double *X, int64_t n, const double *alpha,
+                                  double *grad) {
+    TGP_ARG(f && k && X && alpha && grad && n == f->n);
+    if (loglik_grad_kind_check(ctx, k)) return -1;
+    TGP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc = tgp_ensure_io(ctx, (size_t)3 * n * sizeof(double));          // coordinates and alpha: outside the scratch areas
+    if (rc) return rc;
+    double *d_X = (double *)tgp_io_buffer(ctx), *d_alpha = d_X + 2 * n;
+    TGP_HIP(hipEventRecord(ctx->ev[0], st));
+    TGP_HIP(hipMemcpyAsync(d_X, X, 2 * n * 8, hipMemcpyHostToDevice, st));
+    TGP_HIP(hipMemcpyAsync(d_alpha, alpha, n * 8, hipMemcpyHostToDevice, st));
+    rc = launch_loglik_grad(ctx, f, k, d_X, d_alpha, grad);
+    if (rc) return rc;
     float ms = 0.f;
-    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]));
     ctx->timings[3] = ms;
     return 0;
+}
+
+// K build + factorisation + solve + gradient for data that live on the device (tgp_d_gp_solve followed by the above, the
+// factor going back to the context's cache instead of through a handle): one call per evaluation of a gradient-driven fit.
+extern "C" int tgp_d_gp_solve_grad(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_y,
+                                   const double *d_yerr, double *logdet, double *ydota, double *grad) {
+    TGP_ARG(k && d_X && d_y && grad && n > 0);
+    if (loglik_grad_kind_check(ctx, k)) return -1;
+    TGP_HIP(hipSetDevice(ctx->device));
+    int rc = tgp_ensure_io(ctx, (size_t)n * sizeof(double));
+    if (rc) return rc;
+    double *d_alpha = (double *)tgp_io_buffer(ctx);
+    tgp_factor *f = nullptr;
+    rc = tgp_d_gp_solve(ctx, k, d_X, n, d_y, d_yerr, d_alpha, logdet, ydota, &f);
+    if (rc) return rc;                                      // > 0: not positive definite, nothing was kept
+    rc = launch_loglik_grad(ctx, f, k, d_X, d_alpha, grad);
+    float ms = 0.f;
+    if (!rc && hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->timings[3] = ms;
+    tgp_factor_release_to_cache(ctx, f);
+    return rc;
 }

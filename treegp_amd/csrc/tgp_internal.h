@@ -162,6 +162,10 @@ int launch_potrs(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np,
 int launch_potrs_128(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, double *d_b, bool forward_only);
 size_t vslab_bytes(int64_t Np, int S);
 int factor_slabs(tgp_ctx *ctx, tgp_factor *f, int want_S, int *S, const double **slabs);
+int tgp_ensure_io(tgp_ctx *ctx, size_t bytes);
+void *tgp_io_buffer(tgp_ctx *ctx);
+void tgp_factor_release_to_cache(tgp_ctx *ctx, tgp_factor *f);
+int launch_loglik_grad(tgp_ctx *ctx, tgp_factor *f, const tgp_kernel *k, const double *d_X, const double *d_alpha, double *grad);
 int launch_vslab_build(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_t Np, int S, double *slabs);
 // slabs being built on the side stream in chunks of `chunk` super-blocks while the forward sweep already runs: ready[c] is
 // recorded behind chunk c (chunk 0 is built on the sweep's own stream)

@@ -71,7 +71,7 @@ class log_likelihood(object):
             ll = -np.inf
         return ll
 
-    def log_likelihood_gradient(self, kernel, ctx=None):
+    def log_likelihood_gradient(self, kernel, ctx=None, resident=None):
         """(log L, d log L / d theta): 1/2 tr((alpha alpha^T - K^-1) dK/dtheta_k) with the kernel derivative of
         ``treegp/kernels.py:128-150``; K^-1 is formed on the device from the factor of the same solve
         (``ops.gp_loglik_grad``).  Failures give (-inf, zeros) as ``log_likelihood`` gives -inf."""
@@ -79,11 +79,14 @@ class log_likelihood(object):
         try:
             spec = kernel_to_spec(kernel)
             jac = spec_jacobian(kernel)
-            alpha, log_det, chi2, factor = ops.gp_solve(spec, self.X, self.y, self.y_err, keep=True, ctx=ctx)
-            try:
-                g4 = ops.gp_loglik_grad(spec, factor, self.X, alpha, ctx=ctx)
-            finally:
-                factor.free()
+            if resident is not None:
+                log_det, chi2, g4 = ops.gp_solve_grad_resident(spec, resident, ctx=ctx)
+            else:
+                alpha, log_det, chi2, factor = ops.gp_solve(spec, self.X, self.y, self.y_err, keep=True, ctx=ctx)
+                try:
+                    g4 = ops.gp_loglik_grad(spec, factor, self.X, alpha, ctx=ctx)
+                finally:
+                    factor.free()
             ll = -0.5 * chi2 - (0.5 * self.ndata) * np.log(2.0 * np.pi) - 0.5 * log_det
         except (np.linalg.LinAlgError, FloatingPointError, ValueError, ops._lib.TgpError):
             return -np.inf, np.zeros(ntheta)
@@ -107,7 +110,7 @@ class log_likelihood(object):
             return -self.log_likelihood(work, ctx=ctx, resident=resident)
 
         try:
-            best = self._minimise(cost, template)
+            best = self._minimise(cost, template, resident)
         finally:
             if resident is not None:
                 resident.close()
@@ -116,13 +119,13 @@ class log_likelihood(object):
         self._logL = self.log_likelihood(self._kernel)
         return fitted
 
-    def _minimise(self, cost, template):
+    def _minimise(self, cost, template, resident=None):
         if self.gradient == "analytic":
             work = template.clone_with_theta(template.theta)
 
             def cost_and_gradient(theta):
                 work.theta = theta
-                ll, grad = self.log_likelihood_gradient(work)
+                ll, grad = self.log_likelihood_gradient(work, resident=resident)
                 return -ll, -grad
 
             best = optimize.minimize(cost_and_gradient, template.theta, jac=True, method="L-BFGS-B")["x"]

@@ -182,6 +182,21 @@ def gp_solve_resident(spec, problem, ctx=None):
     return logdet.value, ydota.value
 
 
+def gp_solve_grad_resident(spec, problem, ctx=None):
+    """(logdet, y.K^-1.y, d logL / d (log amp, a, b, c)) for a ResidentProblem in one call (``tgp_d_gp_solve_grad``):
+    one evaluation of a gradient-driven maximum-likelihood fit.  Gaussian kernels only."""
+    ctx = ctx or _lib.get_ctx()
+    lib = _lib.load_library()
+    logdet, ydota = C.c_double(0.0), C.c_double(0.0)
+    grad = np.empty(4)
+    rc = lib.tgp_d_gp_solve_grad(ctx, C.byref(spec.to_c()), problem.d_X, problem.n, problem.d_y, problem.d_e,
+                                 C.byref(logdet), C.byref(ydota), ptr(grad))
+    check(ctx, rc, "tgp_d_gp_solve_grad")
+    if rc > 0:
+        raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % rc)
+    return logdet.value, ydota.value, grad
+
+
 def gp_predict(spec, X, alpha, Xs, ctx=None):
     """ys = k(Xs, X) @ alpha without materialising the cross kernel (gp_interp.py:177,183)."""
     ctx = ctx or _lib.get_ctx()
