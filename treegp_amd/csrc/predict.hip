@@ -86,7 +86,8 @@ __device__ __forceinline__ double exp2_neg(double s) {        // 2^(-s), s >= 0
 
 // Where its rate comes from: the inner loop is 22 fp64 VALU instructions per pair (13 fma of the polynomial, 3 add, 2 fmac, rndne,
 // cvt, ldexp, mul) and nothing else but one ds_read_b128 per 1.3 pairs, i.e. 256 CUs x 4 SIMDs x 16 lanes x f / 22 pairs/s:
-// 1.79e12 at 2.4 GHz, 1.49e12 at the ~2.0 GHz the chip holds under back-to-back fp64 FMAs; measured 1.38 - 1.43e12.  Two
+// 1.79e12 at 2.4 GHz, 1.64e12 at the 2.2 GHz (1.25 kW) the chip settles at under this kernel; measured back to back 1.50e12
+// (tools/predict_clock.py), 1.38 - 1.43e12 as one launch of a bench step.  Two
 // queries per thread (half the LDS reads per pair) changed nothing (3.10 vs 3.14 ms at N = 32 768, M = 131 072): issue-bound.
 __global__ __launch_bounds__(256) void predict_gauss_fast_kernel(const double *__restrict__ U, int64_t n,
                                                                  const double *__restrict__ alpha,
