@@ -291,6 +291,9 @@ def main():
             pr_tf = 30.0 * m_rank * n * K / (acc["predict_ms"] * 1e-3) / 1e12
             out["roofline_predict"] = {"bound": "valu", "achieved": pr_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": pr_tf / 78.6,
                                        "pairs_per_sec": m_rank * n * K / (acc["predict_ms"] * 1e-3),
+                                       # the loop is 22 fp64 VALU instructions per pair and nothing else (csrc/predict.hip):
+                                       # fraction of 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz / 22 (the chip holds 2.2 GHz here)
+                                       "valu_issue_frac_at_2p4ghz": m_rank * n * K / (acc["predict_ms"] * 1e-3) * 22 / (256 * 4 * 16 * 2.4e9),
                                        "kernel": "predict_gauss_fast_kernel", "avg_ms": acc["predict_ms"] / K}
             out["phases_ms_per_step"] = {k: acc[k] / K for k in ("kbuild_ms", "chol_ms", "trsv_ms", "predict_ms", "syrk_ms")}
         if world == 1 and args.cpu_sample > 0:
