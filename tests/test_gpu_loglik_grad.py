@@ -168,3 +168,25 @@ def test_fused_resident_call_equals_the_two_step_route():
         assert ld3 == ld and np.array_equal(g4c, g4)
     finally:
         prob.close()
+
+
+def test_auto_mode_uses_the_exact_gradient_above_the_side_by_side_range(monkeypatch):
+    """n = 16 640 > 16 384: the default fit calls tgp_d_gp_solve_grad (one solve + one gradient per evaluation instead of
+    ntheta + 1 solves) and ends at a likelihood no lower than where it started, at a stationary point of the exact gradient."""
+    monkeypatch.delenv("TGP_ML_GRADIENT", raising=False)
+    rng = np.random.default_rng(3)
+    n = 16640
+    X = rng.uniform(0, 1, (n, 2))
+    y = np.sin(6 * X[:, 0]) * np.cos(4 * X[:, 1]) + 0.05 * rng.standard_normal(n)
+    calls = []
+    real = ops.gp_solve_grad_resident
+    monkeypatch.setattr(ops, "gp_solve_grad_resident", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    gp = treegp.GPInterpolation(kernel="0.7**2 * AnisotropicRBF(invLam=array([[60., 0.], [0., 60.]]))", optimizer="log-likelihood",
+                                normalize=True)
+    gp.initialize(X, y, y_err=0.05 * np.ones(n))
+    l0 = gp.return_log_likelihood()
+    gp.solve()
+    assert len(calls) >= 3
+    assert gp._optimizer._logL > l0
+    _, grad = gp._optimizer.log_likelihood_gradient(gp.kernel)
+    assert np.abs(grad).max() < 1e-3 * abs(gp._optimizer._logL)

@@ -333,3 +333,24 @@ def test_two_pcf_host_pieces_against_reference(golden, monkeypatch):
                 np.testing.assert_allclose(np.ravel(fit.alpha), alpha, rtol=1e-9)
             else:
                 assert got == np.inf
+
+
+def test_ml_gradient_mode_selection(monkeypatch):
+    """log_likelihood.gradient: "auto" keeps the reference's finite differences where their evaluations run side by side and
+    switches to the exact gradient above 16 384 points for kernels that have one; "analytic" insists; "fd" never."""
+    import sys
+    mod = sys.modules["treegp_amd.log_likelihood"]
+    small, big = np.zeros((100, 2)), np.zeros((mod._PARALLEL_MAX_N + 1, 2))
+    gauss = tg.eval_kernel("1.0**2 * AnisotropicRBF(scale_length=[0.3, 0.2])")
+    vk = tg.eval_kernel("1.0**2 * VonKarman(length_scale=0.3)")
+    monkeypatch.delenv("TGP_ML_GRADIENT", raising=False)
+    assert mod.log_likelihood(small, None, None).gradient == "auto"
+    assert not mod.log_likelihood(small, None, None)._use_exact_gradient(gauss)
+    assert mod.log_likelihood(big, None, None)._use_exact_gradient(gauss)
+    assert not mod.log_likelihood(big, None, None)._use_exact_gradient(vk)
+    monkeypatch.setenv("TGP_ML_GRADIENT", "analytic")
+    assert mod.log_likelihood(small, None, None)._use_exact_gradient(gauss)
+    with pytest.raises(NotImplementedError, match="no analytic derivative"):
+        mod.log_likelihood(small, None, None)._use_exact_gradient(vk)
+    monkeypatch.setenv("TGP_ML_GRADIENT", "fd")
+    assert not mod.log_likelihood(big, None, None)._use_exact_gradient(gauss)
