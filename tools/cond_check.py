@@ -1,13 +1,12 @@
 import os, sys, numpy as np
 sys.path.insert(0, '/root/repo' if os.path.exists('/root/repo/treegp_amd') else os.environ.get('GRAFT_REPO_ROOT','.'))
 from treegp_amd import _lib, ops
-from oracle import gp_oracle as O
 rng = np.random.default_rng(0)
 for n, ell, noise in ((3000, 0.05, 3e-2), (3000, 0.1, 1e-3), (3000, 0.2, 1e-4), (5000, 0.3, 1e-4), (5000, 0.3, 1e-5)):
     X = rng.uniform(0, 1, (n, 2)); y = np.sin(5*X[:,0])*np.cos(3*X[:,1]) + noise*rng.standard_normal(n)
     ye = np.full(n, noise)
     spec = ops.KernelSpec(_lib.TGP_RBF, amp=1.0, a=1/ell**2, b=0.0, c=1/ell**2)
-    K = O.kernel_matrix("gauss", X, amp=1.0, a=1/ell**2, b=0.0, c=1/ell**2) + np.diag(ye**2)
+    K = ops.kernel_matrix(spec, X) + np.diag(ye**2)           # the library's own K (seam S1); SciPy solves it below
     res = {}
     for tag, env in (("chain", "0"), ("big", "256")):
         os.environ["TGP_POTRS_BIG_FROM"] = env

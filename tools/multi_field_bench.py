@@ -37,8 +37,7 @@ print("N=%d, %d fields: %d independent solves %.1f ms; one factorisation %.1f ms
       "build; second call %.1f ms); max rel diff %.1e" % (n, k, k, t_indep * 1e3, t_factor * 1e3, t_solve * 1e3, dev_ms, t_solve2 * 1e3,
                                                           np.abs(got - ref).max() / np.abs(ref).max()))
 if n <= 16384:
-    from oracle import gp_oracle as O
-    K = O.kernel_matrix("gauss", X, amp=1.0, a=iL[0, 0], b=iL[0, 1], c=iL[1, 1])
+    K = ops.kernel_matrix(spec, X)                 # a caller-evaluated matrix (here: the library's own S1 output)
     ops.gp_solve_dense(K, Y[0], y_err)
     t0 = time.perf_counter()
     a = ops.gp_solve_dense(K, Y[0], y_err)[0]
