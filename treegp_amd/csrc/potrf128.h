@@ -130,6 +130,40 @@ __device__ __forceinline__ void gauss_jordan16(double (&t)[16], double (&ls)[16]
     gj16_all(t, ls, i, fail, std::make_integer_sequence<int, 16>{});
 }
 
+// ---- the same over all four DPP rows of the wave (gen_gj16s.py) -------------------------------------------------------------
+// lane (r, i): s[] = row i of the Schur / Cholesky columns (replicated in the four rows), w[k] = column 4 k + r of the inverse,
+// unscaled until the end.  On exit w[k] = (L^-1)[i][4 k + r], ls[c] = L[i][c] (every DPP row holds all of ls).
+#include "gj16s_dpp.h"
+template <int J>
+__device__ __forceinline__ void gj16s_column(double (&s)[16], double (&w)[4], double (&ls)[16], double &myinv, const int i, const int r,
+                                             int &fail) {
+    const double pj = bcast16<J>(s[J]);
+    if (!(pj > 0.0) && fail < 0) fail = J;
+    const double inv = rsqrt_nr(pj);
+    const double d = pj * inv;
+    const double li = s[J] * inv;                         // L[i][J] for the rows below the pivot
+    const double nl = (i > J) ? -li : 0.0;                // rows <= J are finished: multiplier 0
+    const double nl2 = nl * inv;                          // times (L^-1)[J][C] = inv * (row J's unscaled entry)
+    const double nl2m = (r < (J & 3)) ? nl2 : 0.0;        // slot J / 4 holds a column < J only in the DPP rows r < J % 4
+    gj16s_update<J>(s, w, li, nl, nl2, nl2m);
+    // column J of the inverse is born in DPP row J % 4, slot J / 4: -L[i][J] / L[J][J]^2 below the diagonal, 1 (unscaled) on it
+    const double born = (i == J) ? 1.0 : nl2;
+    w[J >> 2] = (r == (J & 3)) ? born : w[J >> 2];
+    myinv = (i == J) ? inv : myinv;
+    ls[J] = (i > J) ? li : ((i == J) ? d : 0.0);
+}
+template <int... Js>
+__device__ __forceinline__ void gj16s_all(double (&s)[16], double (&w)[4], double (&ls)[16], double &myinv, const int i, const int r,
+                                          int &fail, std::integer_sequence<int, Js...>) {
+    (gj16s_column<Js>(s, w, ls, myinv, i, r, fail), ...);
+}
+__device__ __forceinline__ void gauss_jordan16s(double (&s)[16], double (&w)[4], double (&ls)[16], const int i, const int r, int &fail) {
+    double myinv = 1.0;
+    gj16s_all(s, w, ls, myinv, i, r, fail, std::make_integer_sequence<int, 16>{});
+#pragma clang loop unroll(full)
+    for (int k = 0; k < 4; ++k) w[k] *= myinv;
+}
+
 // acc += A[ra.., ca..ca+31] (16 x 32) * B[rb.., cb..cb+31]^T (16 x 32), both row-major in T
 // (splitting these products over two accumulator chains was tried and is slower: the extra adds and LDS
 //  traffic cost more than the dependent-MFMA latency they hide)
@@ -190,10 +224,40 @@ __device__ __forceinline__ void diag16(double *T, double *A, int lda, int q, int
     }
 }
 
+// the same with the Gauss-Jordan sweep laid out over the four DPP rows of the wave (gauss_jordan16s): 3333 against 5026 clock ticks
+// per block for load + sweep + store on an otherwise idle chip (tools/probes/gj16_probe.hip)
+__device__ __forceinline__ void diag16s(double *T, double *A, int lda, int q, int lane, int *info, int base) {
+    const int i = lane & 15, r = lane >> 4;
+    double s[16], w[4] = {0.0, 0.0, 0.0, 0.0}, ls[16];
+#pragma clang loop unroll(full)
+    for (int c = 0; c < 16; ++c) {
+        const double v = T[taddr(q + i, q + c)];
+        s[c] = (c <= i) ? v : 0.0;
+    }
+    int fail = -1;
+    gauss_jordan16s(s, w, ls, i, r, fail);
+    if (fail >= 0 && lane == 0) atomicCAS(info, 0, base + q + fail + 1);
+#pragma clang loop unroll(full)
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * k + r;
+        T[taddr(q + i, q + c)] = (c <= i) ? w[k] : 0.0;                  // D replaces the block: every DPP row its own columns
+    }
+    if (r == 0) {
+#pragma clang loop unroll(full)
+        for (int c = 0; c < 16; ++c)
+            if (c <= i) A[(int64_t)(q + i) * lda + q + c] = ls[c];       // L is final
+    }
+}
+
 // Register budget: at most 264 VGPRs (arch + acc), so that a wave of this kernel fits on a SIMD next to one wave of
 // the trailing update (248 of 512) -- with more it has to wait for an EMPTY compute unit during the look-ahead
 // (measured: 268 VGPRs cost 25 ms of exposed panel time at N = 65536).  The initial load is batched in two halves
 // for that reason; tools/check_potrf_regs.sh (run by the build) fails if the budget is exceeded.
+#ifdef TGP_GJ16_ONE_ROW          // A/B: the sweep on the 16 lanes of one DPP row (round 1)
+#define DIAG16_STEP diag16
+#else
+#define DIAG16_STEP diag16s
+#endif
 template <bool DIAG16>
 __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, double *W, int *info, int base) {
     __shared__ double T[T_ELEMS + BLK_ELEMS];
@@ -233,7 +297,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
         POTRF_STAMP(1 + 3 * jb);
         if (DIAG16 && wave == 0) {
             // whole wave, no workgroup barrier: LDS operations of one wave execute in program order
-            diag16(T, A, lda, r0, lane, info, base);
+            DIAG16_STEP(T, A, lda, r0, lane, info, base);
             const d4v x = mma_nt16(T, r0 + 16, r0, r0, r0, l15, l4);                   // L21 = A21 D11^T
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -243,7 +307,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
             const d4v p = mma_nt16(T, r0 + 16, r0, r0 + 16, r0, l15, l4);              // A22 -= L21 L21^T
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[taddr(r0 + 16 + l4 + 4 * r, r0 + 16 + l15)] -= p[r];
-            diag16(T, A, lda, r0 + 16, lane, info, base);
+            DIAG16_STEP(T, A, lda, r0 + 16, lane, info, base);
             const d4v s = mma_nn16(T, r0 + 16, r0, r0, r0, l15, l4);                   // S = L21 D11
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[taddr(r0 + 16 + l4 + 4 * r, r0 + l15)] = s[r];
