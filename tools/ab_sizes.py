@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""Cholesky time and rate at a list of sizes (best of 4), for A/B runs of two builds: TGP_LIB_PATH=... python tools/ab_sizes.py [N ...]"""
 import sys, time, numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 from treegp_amd import _lib, ops
 from treegp_amd.synthetic import star_field, headline_invlam
 iL = headline_invlam(); spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=iL[0,0], b=iL[0,1], c=iL[1,1])

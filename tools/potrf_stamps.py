@@ -36,6 +36,14 @@ for b in range(first, min(first + count, nblk)):
     print("%5d  %9.1f %8.1f  | " % (b, (s[b, 0] - t0) / 100.0, (s[b, 16] - s[b, 0]) / 100.0) + " ".join("%6.0f" % v for v in d) +
           "   xcc %d se %d cu %d" % (where >> 8, (where >> 5) & 7, where & 15))
 
+if hasattr(raw, "tgp_debug_potrf_fine"):
+    fine = (C.c_ulonglong * (1024 * 8))()
+    raw.tgp_debug_potrf_fine(fine)
+    f = np.array(fine[:], dtype=np.float64).reshape(1024, 8)
+    print("inside the diagonal step of 32-column block 1, shader-clock ticks: sweep 1 | L21 = A21 D11^T + stores | A22 -= L21 L21^T | sweep 2 | S = L21 D11 | D21 = -D22 S")
+    for b in range(first, min(first + 4, nblk)):
+        print("%5d   " % b + " ".join("%6.0f" % v for v in np.diff(f[b, :7])))
+
 # one panel GEMM of the chain (gemm_col_kernel<0> with TGP_STAMP_GRID workgroups): when and where each workgroup ran
 grid = int(os.environ.get("TGP_STAMP_GRID", "0"))
 if grid:

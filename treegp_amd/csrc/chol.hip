@@ -947,6 +947,9 @@ extern "C" int tgp_debug_queue_stamps(unsigned long long *out, int T) {
     if (T > 0) return (int)hipMemcpyToSymbol(HIP_SYMBOL(tgp_queue_stamp_T), &T, sizeof(int));
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_queue_stamps), 1024 * 4 * sizeof(unsigned long long));
 }
+extern "C" int tgp_debug_potrf_fine(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_potrf_fine), 1024 * 8 * sizeof(unsigned long long));      // [block][sub-step]
+}
 extern "C" int tgp_debug_potrf_stamps(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_potrf_stamps), 1024 * 20 * sizeof(unsigned long long));   // [block][stamp]
 }

@@ -23,7 +23,11 @@
 // one row of stamps per diagonal block of the factorisation (row = base / 128), so that every call can be looked at in situ
 __device__ unsigned long long tgp_potrf_stamps[1024 * 20];
 #define POTRF_STAMP(i) do { if (threadIdx.x == 0) tgp_potrf_stamps[((base >> 7) & 1023) * 20 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// inside the diagonal step of 32-column block 1 (wave 0): shader-clock stamps between its sub-steps
+__device__ unsigned long long tgp_potrf_fine[1024 * 8];
+#define POTRF_FINE(k) do { if (jb == 1 && threadIdx.x == 0) tgp_potrf_fine[((base >> 7) & 1023) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define POTRF_FINE(k) do { } while (0)
 #define POTRF_STAMP(i) do { } while (0)
 #endif
 
@@ -226,38 +230,53 @@ __device__ __forceinline__ void diag16(double *T, double *A, int lda, int q, int
 
 // the same with the Gauss-Jordan sweep laid out over the four DPP rows of the wave (gauss_jordan16s): 3333 against 5026 clock ticks
 // per block for load + sweep + store on an otherwise idle chip (tools/probes/gj16_probe.hip)
-__device__ __forceinline__ void diag16s(double *T, double *A, int lda, int q, int lane, int *info, int base) {
+// blk: the 16x16 block inside its 32x32 LDS block (row stride BS); Ag: the same block in global memory (row stride lda); pos: its
+// global row / column for the failure report.  All addresses are one base plus compile-time offsets: with taddr() per element
+// the sweep cost 4800 clock ticks in situ against the probe's 3333, the difference being integer address arithmetic and
+// sixteen separately predicated global stores (the upper triangle of ls is zero anyway: it is stored as such).
+__device__ __forceinline__ void diag16s(double *blk, double *Ag, int lda, int lane, int *info, int pos) {
     const int i = lane & 15, r = lane >> 4;
     double s[16], w[4] = {0.0, 0.0, 0.0, 0.0}, ls[16];
+    const double *row = blk + i * BS;
 #pragma clang loop unroll(full)
-    for (int c = 0; c < 16; ++c) {
-        const double v = T[taddr(q + i, q + c)];
-        s[c] = (c <= i) ? v : 0.0;
-    }
+    for (int c = 0; c < 16; ++c) s[c] = row[c];
+#pragma clang loop unroll(full)
+    for (int c = 0; c < 16; ++c) s[c] = (c <= i) ? s[c] : 0.0;
     int fail = -1;
     gauss_jordan16s(s, w, ls, i, r, fail);
-    if (fail >= 0 && lane == 0) atomicCAS(info, 0, base + q + fail + 1);
+    if (fail >= 0 && lane == 0) atomicCAS(info, 0, pos + fail + 1);
+    double *wrow = blk + i * BS + r;                                     // D replaces the block: every DPP row its own columns
 #pragma clang loop unroll(full)
-    for (int k = 0; k < 4; ++k) {
-        const int c = 4 * k + r;
-        T[taddr(q + i, q + c)] = (c <= i) ? w[k] : 0.0;                  // D replaces the block: every DPP row its own columns
-    }
-    if (r == 0) {
+    for (int k = 0; k < 4; ++k) wrow[4 * k] = (4 * k + r <= i) ? w[k] : 0.0;
+    if (r == 0) {                                                        // L is final (zeros above the diagonal of the block)
+        double *grow = Ag + (int64_t)i * lda;
 #pragma clang loop unroll(full)
-        for (int c = 0; c < 16; ++c)
-            if (c <= i) A[(int64_t)(q + i) * lda + q + c] = ls[c];       // L is final
+        for (int c = 0; c < 16; ++c) grow[c] = ls[c];
     }
+}
+// 16-deep products with both operands inside one 32x32 LDS block B (row stride BS): offsets are compile-time
+template <int RA, int CA, int RB, int CB>
+__device__ __forceinline__ d4v blk_nt16(const double *B, int l15, int l4) {      // A[RA.., CA..CA+15] * B[RB.., CB..CB+15]^T
+    d4v acc = {0.0, 0.0, 0.0, 0.0};
+    const double *a = B + (RA + l15) * BS + CA + l4, *b = B + (RB + l15) * BS + CB + l4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * ks], b[4 * ks], acc, 0, 0, 0);
+    return acc;
+}
+template <int RA, int CA, int RB, int CB>
+__device__ __forceinline__ d4v blk_nn16(const double *B, int l15, int l4) {      // A[RA.., CA..CA+15] * B[RB..RB+15, CB..]
+    d4v acc = {0.0, 0.0, 0.0, 0.0};
+    const double *a = B + (RA + l15) * BS + CA + l4, *b = B + (RB + l4) * BS + CB + l15;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * ks], b[4 * ks * BS], acc, 0, 0, 0);
+    return acc;
 }
 
 // Register budget: at most 264 VGPRs (arch + acc), so that a wave of this kernel fits on a SIMD next to one wave of
 // the trailing update (248 of 512) -- with more it has to wait for an EMPTY compute unit during the look-ahead
 // (measured: 268 VGPRs cost 25 ms of exposed panel time at N = 65536).  The initial load is batched in two halves
 // for that reason; tools/check_potrf_regs.sh (run by the build) fails if the budget is exceeded.
-#ifdef TGP_GJ16_ONE_ROW          // A/B: the sweep on the 16 lanes of one DPP row (round 1)
-#define DIAG16_STEP diag16
-#else
-#define DIAG16_STEP diag16s
-#endif
+// -DTGP_GJ16_ONE_ROW: A/B build with the sweep on the 16 lanes of one DPP row and taddr() addressing (round 1)
 template <bool DIAG16>
 __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, double *W, int *info, int base) {
     __shared__ double T[T_ELEMS + BLK_ELEMS];
@@ -297,23 +316,58 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
         POTRF_STAMP(1 + 3 * jb);
         if (DIAG16 && wave == 0) {
             // whole wave, no workgroup barrier: LDS operations of one wave execute in program order
-            DIAG16_STEP(T, A, lda, r0, lane, info, base);
+            POTRF_FINE(0);
+#ifdef TGP_GJ16_ONE_ROW
+            diag16(T, A, lda, r0, lane, info, base);
+            POTRF_FINE(1);
             const d4v x = mma_nt16(T, r0 + 16, r0, r0, r0, l15, l4);                   // L21 = A21 D11^T
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 T[taddr(r0 + 16 + l4 + 4 * r, r0 + l15)] = x[r];
                 A[(int64_t)(r0 + 16 + l4 + 4 * r) * lda + r0 + l15] = x[r];
             }
+            POTRF_FINE(2);
             const d4v p = mma_nt16(T, r0 + 16, r0, r0 + 16, r0, l15, l4);              // A22 -= L21 L21^T
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[taddr(r0 + 16 + l4 + 4 * r, r0 + 16 + l15)] -= p[r];
-            DIAG16_STEP(T, A, lda, r0 + 16, lane, info, base);
+            POTRF_FINE(3);
+            diag16(T, A, lda, r0 + 16, lane, info, base);
+            POTRF_FINE(4);
             const d4v s = mma_nn16(T, r0 + 16, r0, r0, r0, l15, l4);                   // S = L21 D11
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[taddr(r0 + 16 + l4 + 4 * r, r0 + l15)] = s[r];
+            POTRF_FINE(5);
             const d4v w = mma_nn16(T, r0 + 16, r0 + 16, r0 + 16, r0, l15, l4);         // D21 = -D22 S
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[taddr(r0 + 16 + l4 + 4 * r, r0 + l15)] = -w[r];
+#else
+            double *B = T + taddr(r0, r0);                      // the 32x32 diagonal block of this step, row stride BS
+            double *Ag = A + (int64_t)r0 * lda + r0;            // the same block in global memory
+            diag16s(B, Ag, lda, lane, info, base + r0);
+            POTRF_FINE(1);
+            double *b21 = B + (16 + l4) * BS + l15;             // C fragment of the lower-left 16x16 block: rows 16 + l4 + 4 r
+            const d4v x = blk_nt16<16, 0, 0, 0>(B, l15, l4);                           // L21 = A21 D11^T
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                b21[4 * r * BS] = x[r];
+                Ag[(int64_t)(16 + l4 + 4 * r) * lda + l15] = x[r];
+            }
+            POTRF_FINE(2);
+            const d4v p = blk_nt16<16, 0, 16, 0>(B, l15, l4);                          // A22 -= L21 L21^T
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b21[4 * r * BS + 16] -= p[r];
+            POTRF_FINE(3);
+            diag16s(B + 16 * BS + 16, Ag + (int64_t)16 * lda + 16, lda, lane, info, base + r0 + 16);
+            POTRF_FINE(4);
+            const d4v s = blk_nn16<16, 0, 0, 0>(B, l15, l4);                           // S = L21 D11
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b21[4 * r * BS] = s[r];
+            POTRF_FINE(5);
+            const d4v w = blk_nn16<16, 16, 16, 0>(B, l15, l4);                         // D21 = -D22 S
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b21[4 * r * BS] = -w[r];
+#endif
+            POTRF_FINE(6);
         }
         if (!DIAG16 && wave == 0 && lane < 32) {
             const int i = lane;
