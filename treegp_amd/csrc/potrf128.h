@@ -272,6 +272,34 @@ __device__ __forceinline__ d4v blk_nn16(const double *B, int l15, int l4) {     
     return acc;
 }
 
+// phase 2 of potrf128, one off-diagonal 32x32 block of W = L^-1:  W_IB,CB = -D_IB sum_{k = CB}^{IB-1} L_IB,k W_k,CB, this wave's
+// 16x16 tile (rt, ct) of it.  The sum goes to the spare block SC (all four waves), then D_IB SC replaces L_IB,CB in place.
+__device__ __forceinline__ constexpr int blk_origin(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * BLK_ELEMS; }
+template <int IB, int CB>
+__device__ __forceinline__ void phase2_pair(double *T, double *SC, int rt, int ct, int l15, int l4) {
+    const int aoff = (16 * rt + l15) * BS + l4;        // A fragment: row 16 rt + l15, column 4 ks + l4 of a block
+    const int boff = l4 * BS + 16 * ct + l15;          // B fragment: row 4 ks + l4, column 16 ct + l15
+    const int coff = (16 * rt + l4) * BS + 16 * ct + l15;      // C fragment: rows 16 rt + l4 + 4 r
+    d4v s = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = CB; kb < IB; ++kb) {
+        const double *a = T + blk_origin(IB, kb) + aoff, *b = T + blk_origin(kb, CB) + boff;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) s = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * ks], b[4 * ks * BS], s, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) SC[coff + 4 * r * BS] = s[r];
+    __syncthreads();
+    d4v w = {0.0, 0.0, 0.0, 0.0};
+    const double *a = T + blk_origin(IB, IB) + aoff, *b = SC + boff;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) w = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * ks], b[4 * ks * BS], w, 0, 0, 0);
+    double *c = T + blk_origin(IB, CB) + coff;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[4 * r * BS] = -w[r];
+    __syncthreads();
+}
+
 // Register budget: at most 264 VGPRs (arch + acc), so that a wave of this kernel fits on a SIMD next to one wave of
 // the trailing update (248 of 512) -- with more it has to wait for an EMPTY compute unit during the look-ahead
 // (measured: 268 VGPRs cost 25 ms of exposed panel time at N = 65536).  The initial load is batched in two halves
@@ -462,28 +490,17 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
 
     POTRF_STAMP(14);
     // ---- phase 2: W = L^-1 in place, block column by block column ----------------------------------
+    // All six (block row, block column) pairs spelled out with compile-time block origins: with taddr() on run-time block indices
+    // the integer address arithmetic of a 32-deep product (sixteen operand addresses before its first MFMA) took as long as
+    // its eight MFMAs -- 7.2 us for the phase against 3.4 us of MFMA issue.
     const int rt = wave >> 1, ct = wave & 1;           // this wave's 16x16 tile of a 32x32 block
     double *SC = T + T_ELEMS;                          // one spare 32x32 block: S goes there, so W can be written in place
-#pragma unroll 1
-    for (int cb = 0; cb < 3; ++cb) {
-#pragma unroll 1
-        for (int ib = cb + 1; ib < 4; ++ib) {
-            d4v s = zero4;
-            for (int kb = cb; kb < ib; ++kb)            // S = sum_k L_ik W_k,cb
-                s = mma_nn32(T, 32 * ib + 16 * rt, 32 * kb, 32 * kb, 32 * cb + 16 * ct, s, l15, l4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) SC[(16 * rt + l4 + 4 * r) * BS + 16 * ct + l15] = s[r];
-            __syncthreads();
-            d4v w = zero4;                              // D_i S
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                w = __builtin_amdgcn_mfma_f64_16x16x4f64(T[taddr(32 * ib + 16 * rt + l15, 32 * ib + 4 * ks + l4)],
-                                                         SC[(4 * ks + l4) * BS + 16 * ct + l15], w, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) T[taddr(32 * ib + 16 * rt + l4 + 4 * r, 32 * cb + 16 * ct + l15)] = -w[r];
-            __syncthreads();
-        }
-    }
+    phase2_pair<1, 0>(T, SC, rt, ct, l15, l4);
+    phase2_pair<2, 0>(T, SC, rt, ct, l15, l4);
+    phase2_pair<3, 0>(T, SC, rt, ct, l15, l4);
+    phase2_pair<2, 1>(T, SC, rt, ct, l15, l4);
+    phase2_pair<3, 1>(T, SC, rt, ct, l15, l4);
+    phase2_pair<3, 2>(T, SC, rt, ct, l15, l4);
     POTRF_STAMP(15);
 #pragma unroll
     for (int it = 0; it < 32; ++it) {
