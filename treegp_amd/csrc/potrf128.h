@@ -275,6 +275,7 @@ __device__ __forceinline__ d4v blk_nn16(const double *B, int l15, int l4) {     
 // phase 2 of potrf128, one off-diagonal 32x32 block of W = L^-1:  W_IB,CB = -D_IB sum_{k = CB}^{IB-1} L_IB,k W_k,CB, this wave's
 // 16x16 tile (rt, ct) of it.  The sum goes to the spare block SC (all four waves), then D_IB SC replaces L_IB,CB in place.
 __device__ __forceinline__ constexpr int blk_origin(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * BLK_ELEMS; }
+__device__ __forceinline__ constexpr int blk_row(int b) { return b < 1 ? 0 : (b < 3 ? 1 : (b < 6 ? 2 : 3)); }      // block row of lower block b
 template <int IB, int CB>
 __device__ __forceinline__ void phase2_pair(double *T, double *SC, int rt, int ct, int l15, int l4) {
     const int aoff = (16 * rt + l15) * BS + l4;        // A fragment: row 16 rt + l15, column 4 ks + l4 of a block
@@ -307,32 +308,36 @@ __device__ __forceinline__ void phase2_pair(double *T, double *SC, int rt, int c
 // -DTGP_GJ16_ONE_ROW: A/B build with the sweep on the 16 lanes of one DPP row and taddr() addressing (round 1)
 template <bool DIAG16>
 __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, double *W, int *info, int base) {
-    __shared__ double T[T_ELEMS + BLK_ELEMS];
+    __shared__ __attribute__((aligned(16))) double T[T_ELEMS + BLK_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const d4v zero4 = {0.0, 0.0, 0.0, 0.0};
     TGP_CHAIN_PRIO();
     POTRF_STAMP(0);
 
-    {   // the block comes in with all its loads in flight at once (two columns per thread, coalesced rows);
-        // only the 10 lower 32x32 blocks are fetched
+    // block-wise copies between global memory and the LDS image: a pass of the 256 threads covers 16 rows x 16 column pairs = half a
+    // 32x32 block, so block and half are compile-time and every address is one per-thread base plus a constant
+    const int lrow = tid >> 4, lpair = tid & 15;
+    double *tbase = T + lrow * BS + 2 * lpair;
+    {   // the 10 lower blocks come in with all 20 loads of a thread in flight at once (one memory round trip), 16-byte LDS writes;
+        // the diagonal blocks are masked to their lower triangles
+        const double *gbase = A + (int64_t)lrow * lda + 2 * lpair;
+        double2 v[20];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            double2 v[16];
+        for (int u = 0; u < 20; ++u) {
+            const int bi = blk_row(u >> 1), bj = (u >> 1) - bi * (bi + 1) / 2, h = u & 1;
+            v[u] = *reinterpret_cast<const double2 *>(gbase + (int64_t)(32 * bi + 16 * h) * lda + 32 * bj);
+        }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int idx = tid + 256 * (16 * half + u), i = idx >> 6, c = (idx & 63) * 2;
-                v[u] = make_double2(0.0, 0.0);
-                if ((c >> 5) <= (i >> 5)) v[u] = *reinterpret_cast<const double2 *>(A + (int64_t)i * lda + c);
+        for (int u = 0; u < 20; ++u) {
+            const int bi = blk_row(u >> 1), bj = (u >> 1) - bi * (bi + 1) / 2, h = u & 1;
+            double2 x = v[u];
+            if (bi == bj) {
+                const int row = lrow + 16 * h, c = 2 * lpair;
+                x.x = (c <= row) ? x.x : 0.0;
+                x.y = (c + 1 <= row) ? x.y : 0.0;
             }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int idx = tid + 256 * (16 * half + u), i = idx >> 6, c = (idx & 63) * 2;
-                if ((c >> 5) <= (i >> 5)) {
-                    T[taddr(i, c)] = (c <= i) ? v[u].x : 0.0;
-                    T[taddr(i, c + 1)] = (c + 1 <= i) ? v[u].y : 0.0;
-                }
-            }
+            *reinterpret_cast<double2 *>(tbase + (u >> 1) * BLK_ELEMS + 16 * h * BS) = x;
         }
     }
     __syncthreads();
@@ -502,13 +507,25 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
     phase2_pair<3, 1>(T, SC, rt, ct, l15, l4);
     phase2_pair<3, 2>(T, SC, rt, ct, l15, l4);
     POTRF_STAMP(15);
+    {   // W leaves block by block: lower blocks from the LDS image (diagonal ones masked), zeros above
+        double *wbase = W + lrow * 128 + 2 * lpair;
 #pragma unroll
-    for (int it = 0; it < 32; ++it) {
-        const int idx = tid + 256 * it, i = idx >> 6, c = (idx & 63) * 2;
-        double2 v;
-        v.x = (c <= i) ? T[taddr(i, c)] : 0.0;
-        v.y = (c + 1 <= i) ? T[taddr(i, c + 1)] : 0.0;
-        *reinterpret_cast<double2 *>(W + i * 128 + c) = v;
+        for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double2 x = make_double2(0.0, 0.0);
+                    if (bj <= bi) {
+                        x = *reinterpret_cast<const double2 *>(tbase + blk_origin(bi, bj) + 16 * h * BS);
+                        if (bi == bj) {
+                            const int row = lrow + 16 * h, c = 2 * lpair;
+                            x.x = (c <= row) ? x.x : 0.0;
+                            x.y = (c + 1 <= row) ? x.y : 0.0;
+                        }
+                    }
+                    *reinterpret_cast<double2 *>(wbase + (32 * bi + 16 * h) * 128 + 32 * bj) = x;
+                }
     }
     POTRF_STAMP(16);
 #ifdef TGP_POTRF_STAMPS
