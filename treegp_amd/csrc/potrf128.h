@@ -421,21 +421,24 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
         const int r1 = r0 + 32;
         const int nr16 = (128 - r1) / 16;
         // rows below: X = A_panel D_j^T, one 16-row strip (two 16x16 tiles) per wave at a time
+        // (operands: one base per 16-row strip / 16x16 tile -- a strip or tile never straddles a 32x32 block -- plus constants)
+        const double *Dj = T + taddr(r0, r0) + l15 * BS + l4;                  // D_j, B fragment rows l15 / 16 + l15
         for (int rt = wave; rt < nr16; rt += 4) {
             const int rb = r1 + 16 * rt;
+            double *strip = T + taddr(rb, r0);
+            const double *a = strip + l15 * BS + l4;
             d4v x0 = zero4, x1 = zero4;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const double a = T[taddr(rb + l15, r0 + 4 * ks + l4)];
-                const double b0 = T[taddr(r0 + l15, r0 + 4 * ks + l4)];
-                const double b1 = T[taddr(r0 + 16 + l15, r0 + 4 * ks + l4)];
-                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, x0, 0, 0, 0);
-                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, x1, 0, 0, 0);
+                const double av = a[4 * ks];
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Dj[4 * ks], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Dj[16 * BS + 4 * ks], x1, 0, 0, 0);
             }
+            double *dst = strip + l4 * BS + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                T[taddr(rb + l4 + 4 * r, r0 + l15)] = x0[r];
-                T[taddr(rb + l4 + 4 * r, r0 + 16 + l15)] = x1[r];
+                dst[4 * r * BS] = x0[r];
+                dst[4 * r * BS + 16] = x1[r];
             }
         }
         __syncthreads();
@@ -448,20 +451,22 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
         const int ntile = nr16 * (nr16 + 1) / 2;
         if (wave == 0) {
             if (nr16 >= 2) {
+                const double *x = T + taddr(r1, r0) + l15 * BS + l4;           // X rows r1 + l15 and r1 + 16 + l15 (one block)
                 d4v p00 = zero4, p10 = zero4, p11 = zero4;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    const double x0 = T[taddr(r1 + l15, r0 + 4 * ks + l4)];
-                    const double x1 = T[taddr(r1 + 16 + l15, r0 + 4 * ks + l4)];
+                    const double x0 = x[4 * ks];
+                    const double x1 = x[16 * BS + 4 * ks];
                     p00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, p00, 0, 0, 0);
                     p10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, p10, 0, 0, 0);
                     p11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, p11, 0, 0, 0);
                 }
+                double *c = T + taddr(r1, r1) + l4 * BS + l15;                 // the next diagonal block
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    T[taddr(r1 + l4 + 4 * r, r1 + l15)] -= p00[r];
-                    T[taddr(r1 + 16 + l4 + 4 * r, r1 + l15)] -= p10[r];
-                    T[taddr(r1 + 16 + l4 + 4 * r, r1 + 16 + l15)] -= p11[r];
+                    c[4 * r * BS] -= p00[r];
+                    c[(16 + 4 * r) * BS] -= p10[r];
+                    c[(16 + 4 * r) * BS + 16] -= p11[r];
                 }
             }
         } else {
@@ -469,9 +474,13 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
                 int ti = 0;
                 while ((ti + 1) * (ti + 2) / 2 <= tt) ++ti;
                 const int tj = tt - ti * (ti + 1) / 2;
-                const d4v p = mma_nt32(T, r1 + 16 * ti, r0, r1 + 16 * tj, r0, zero4, l15, l4);
+                const double *a = T + taddr(r1 + 16 * ti, r0) + l15 * BS + l4, *b = T + taddr(r1 + 16 * tj, r0) + l15 * BS + l4;
+                d4v p = zero4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) T[taddr(r1 + 16 * ti + l4 + 4 * r, r1 + 16 * tj + l15)] -= p[r];
+                for (int ks = 0; ks < 8; ++ks) p = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * ks], b[4 * ks], p, 0, 0, 0);
+                double *c = T + taddr(r1 + 16 * ti, r1 + 16 * tj) + l4 * BS + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c[4 * r * BS] -= p[r];
             }
         }
     }
