@@ -88,12 +88,17 @@ __device__ __forceinline__ double bcast16(double x) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x150 + N, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-// 1/sqrt(p) to ~1 ulp: hardware estimate + two Newton steps (the pivot chain is the critical path)
+// 1/sqrt(p) to ~1 ulp: hardware estimate + two Newton steps (the pivot chain is the critical path).  Measured with
+// tools/probes/gj16_probe.hip: v_rsq_f64 alone leaves 6e-8 in L, one step 2.2e-15 (five times the two-step error, for 5 % of a
+// sweep): a backward error ten times larger is ten times the forward error at cond(K) ~ 1e6, where 1e-10 is the budget.
+#ifndef TGP_RSQ_NR
+#define TGP_RSQ_NR 2
+#endif
 __device__ __forceinline__ double rsqrt_nr(double p) {
     double y = __builtin_amdgcn_rsq(p);
     const double hp = 0.5 * p;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < TGP_RSQ_NR; ++it) {
         const double e = __builtin_fma(-hp * y, y, 0.5);
         y = __builtin_fma(y, e, y);
     }
