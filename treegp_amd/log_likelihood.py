@@ -150,7 +150,8 @@ class log_likelihood(object):
             ntheta = len(template.theta)
             ctxs = _contexts(ntheta + 1)
             works = [template.clone_with_theta(template.theta) for _ in range(ntheta + 1)]
-            pool = ThreadPoolExecutor(max_workers=ntheta + 1)
+            # evaluations in flight at once: all ntheta + 1 by default; TGP_ML_MAX_CONCURRENT caps it (the rest queue up)
+            pool = ThreadPoolExecutor(max_workers=min(ntheta + 1, int(os.environ.get("TGP_ML_MAX_CONCURRENT", ntheta + 1))))
 
             def cost_and_gradient(theta):
                 # SciPy's 2-point scheme for L-BFGS-B (approx_derivative, abs_step = eps): x_i + h, df / actual dx
