@@ -428,6 +428,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
         // rows below: X = A_panel D_j^T, one 16-row strip (two 16x16 tiles) per wave at a time
         // (operands: one base per 16-row strip / 16x16 tile -- a strip or tile never straddles a 32x32 block -- plus constants)
         const double *Dj = T + taddr(r0, r0) + l15 * BS + l4;                  // D_j, B fragment rows l15 / 16 + l15
+        // (dealing the 16x16 tiles instead of whole strips to the waves needs a barrier before the in-place write: no gain)
         for (int rt = wave; rt < nr16; rt += 4) {
             const int rb = r1 + 16 * rt;
             double *strip = T + taddr(rb, r0);
@@ -448,12 +449,23 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
         }
         __syncthreads();
         POTRF_STAMP(3 + 3 * jb);
-        // Schur complement: lower 16x16 tiles of T[r1:, r1:] -= X X^T.  Tiles 0..2 are the NEXT diagonal
-        // 32x32 block: wave 0 takes exactly those (three interleaved accumulator chains) and goes straight on
-        // to factor that block; waves 1..3 share the rest and meet wave 0 again at the barrier after the
-        // diagonal step -- the bulk of the update is off the critical path.  No barrier here: what wave 0
-        // touches next (the diagonal block of step jb+1) is disjoint from what the others still read and write.
+        // Schur complement: lower 16x16 tiles of T[r1:, r1:] -= X X^T.  Tiles 0..2 are the NEXT diagonal 32x32 block, the only
+        // ones on the critical path: the bulk of the update runs beside the next diagonal step (what wave 0 touches there is
+        // disjoint from what the others still read and write) and meets it at the barrier after that step.
         const int ntile = nr16 * (nr16 + 1) / 2;
+        auto schur_tile = [&](int tt) {
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= tt) ++ti;
+            const int tj = tt - ti * (ti + 1) / 2;
+            const double *a = T + taddr(r1 + 16 * ti, r0) + l15 * BS + l4, *b = T + taddr(r1 + 16 * tj, r0) + l15 * BS + l4;
+            d4v p = zero4;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) p = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * ks], b[4 * ks], p, 0, 0, 0);
+            double *c = T + taddr(r1 + 16 * ti, r1 + 16 * tj) + l4 * BS + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[4 * r * BS] -= p[r];
+        };
+#ifdef TGP_POTRF_SCHUR_SOLO          // A/B: wave 0 alone on the three tiles of the next diagonal block, no barrier (round 1)
         if (wave == 0) {
             if (nr16 >= 2) {
                 const double *x = T + taddr(r1, r0) + l15 * BS + l4;           // X rows r1 + l15 and r1 + 16 + l15 (one block)
@@ -475,19 +487,18 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
                 }
             }
         } else {
-            for (int tt = 3 + (wave - 1); tt < ntile; tt += 3) {
-                int ti = 0;
-                while ((ti + 1) * (ti + 2) / 2 <= tt) ++ti;
-                const int tj = tt - ti * (ti + 1) / 2;
-                const double *a = T + taddr(r1 + 16 * ti, r0) + l15 * BS + l4, *b = T + taddr(r1 + 16 * tj, r0) + l15 * BS + l4;
-                d4v p = zero4;
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) p = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * ks], b[4 * ks], p, 0, 0, 0);
-                double *c = T + taddr(r1 + 16 * ti, r1 + 16 * tj) + l4 * BS + l15;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) c[4 * r * BS] -= p[r];
-            }
+            for (int tt = 3 + (wave - 1); tt < ntile; tt += 3) schur_tile(tt);
         }
+#else
+        // The three tiles of the next diagonal block go to three waves (one 8-MFMA chain each instead of three on wave 0's SIMD),
+        // the fourth wave starts on the rest; after one barrier wave 0 factors that block while waves 1..3 finish the update.
+        if (ntile > 0) {
+            if (wave < ntile && wave < 4) schur_tile(wave);
+            __syncthreads();
+            if (wave > 0)
+                for (int tt = 4 + (wave - 1); tt < ntile; tt += 3) schur_tile(tt);
+        }
+#endif
     }
     __syncthreads();
 
