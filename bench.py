@@ -56,6 +56,8 @@ def cpu_baseline(n_s, m_s, n_headline):
     except Exception:
         pass
     gf = n_s ** 3 / 3 / med["cholesky"] / 1e9
+    # cores the baseline really had: a cgroup quota below the thread count is what binds (16 CPUs on this pool's boxes)
+    eff = min([float(threads)] + [float(v) for v in (host["cgroup_quota"], host["affinity"]) if v])
     r3, r2 = (n_headline / n_s) ** 3, (n_headline / n_s) ** 2
     m_h = 4 * n_headline
     ext = {"kbuild": med["kbuild"] * r2, "cholesky": med["cholesky"] * r3, "cho_solve": med["cho_solve"] * r2,
@@ -63,13 +65,14 @@ def cpu_baseline(n_s, m_s, n_headline):
            "matvec": med["matvec"] * (m_h * n_headline) / (m_s * n_s)}
     ext_total = sum(ext.values())
     return {
-        "value": (n_s + m_s) / med["total"], "unit": "points/s", "cores": int(threads), "kind": "port",
+        "value": (n_s + m_s) / med["total"], "unit": "points/s", "cores": max(int(round(eff)), 1), "blas_threads": int(threads),
+        "kind": "port",
         "sample": "configs[1] in full: same star-field recipe at N=%d train / M=%d predict; the reference's SciPy calls "
                   "(oracle/cpu_reference_path.py), 1 warm-up + %d timed passes, median per phase: pdist+exp+squareform "
-                  "%.2fs (single-thread), dpotrf %.3fs = %.0f GFLOP/s on %d BLAS threads, cho_solve %.3fs, cdist+exp "
+                  "%.2fs (single-thread), dpotrf %.3fs = %.0f GFLOP/s on %d BLAS threads (%g effective cores), cho_solve %.3fs, cdist+exp "
                   "%.2fs (single-thread); host: %s, %d logical / %s physical CPUs, cgroup quota %s, %s; the O(N^3) "
                   "factorisation makes points/s size-dependent -- compare with the GPU at the same N, not with `value`"
-                  % (n_s, m_s, npass, med["kbuild"], med["cholesky"], gf, threads, med["cho_solve"], med["cross_kernel"],
+                  % (n_s, m_s, npass, med["kbuild"], med["cholesky"], gf, threads, eff, med["cho_solve"], med["cross_kernel"],
                      host["model"], host["logical"], host["physical"], host["cgroup_quota"], blas),
         "passes": npass, "blas_threads_probe_gflops": {str(k): round(v, 1) for k, v in probe.items()},
         "dpotrf_gflops": gf,
@@ -127,6 +130,100 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def configs_measured(lib, ctx, ops, _lib):
+    """configs[1] and configs[2] of BASELINE.json on this GPU, right after the headline's timed region (a few seconds in
+    all): the numbers README / DESIGN quote for them, now on the driver's own line."""
+    import treegp_amd
+    from treegp_amd.synthetic import star_field, headline_invlam
+    out = []
+    iL = headline_invlam()
+    # (i) configs[1]: 2-D AnisotropicRBF N = 8192, predict 32768 -- the ML-fit regime
+    n, m, reps = 8192, 32768, 5
+    X, y, y_err, Xs = star_field(n, m)
+    spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=iL[0, 0], b=iL[0, 1], c=iL[1, 1])
+    kc = spec.to_c()
+    bufs = [ops.DeviceBuffer.from_array(ctx, a) for a in (X, y - y.mean(), y_err, Xs)]
+    da, dys = ops.DeviceBuffer(ctx, n * 8), ops.DeviceBuffer(ctx, m * 8)
+    ld, yd = C.c_double(), C.c_double()
+    acc = {}
+    lib.tgp_set_profiling(ctx, 1)
+    for it in range(reps + 1):
+        t0 = time.perf_counter()
+        rc = lib.tgp_d_gp_solve(ctx, C.byref(kc), bufs[0].ptr, n, bufs[1].ptr, bufs[2].ptr, da.ptr, C.byref(ld), C.byref(yd), None)
+        if rc != 0:
+            raise RuntimeError("configs[1] solve rc=%d" % rc)
+        tm = _lib.timings(ctx)
+        lib.tgp_d_gp_predict(ctx, C.byref(kc), bufs[0].ptr, n, da.ptr, bufs[3].ptr, m, dys.ptr)
+        tp = _lib.timings(ctx)[3]
+        wall = (time.perf_counter() - t0) * 1e3
+        if it == 0:
+            continue                                       # warm-up (workspace allocation)
+        for k, v in (("kbuild_ms", tm[0]), ("chol_ms", tm[1]), ("trsv_ms", tm[2]), ("predict_ms", tp), ("wall_ms", wall),
+                     ("syrk_ms", tm[5]), ("syrk_flops", tm[7])):
+            acc[k] = acc.get(k, 0.0) + v / reps
+    # likelihood-only evaluations (no alpha): what one step of an ML fit costs
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lib.tgp_d_gp_solve(ctx, C.byref(kc), bufs[0].ptr, n, bufs[1].ptr, bufs[2].ptr, None, C.byref(ld), C.byref(yd), None)
+    lik_ms = (time.perf_counter() - t0) * 1e3 / reps
+    npad = (n + 255) // 256 * 256
+    chol_tf = n ** 3 / 3.0 / (acc["chol_ms"] * 1e-3) / 1e12
+    out.append({"config": "configs[1]: 2-D AnisotropicRBF N=8192, predict 32768, one GPU", "reps": reps,
+                "ms": acc["wall_ms"], "phases_ms": {k: acc[k] for k in ("kbuild_ms", "chol_ms", "trsv_ms", "predict_ms")},
+                "gp_solves_per_sec": 1e3 / (acc["kbuild_ms"] + acc["chol_ms"] + acc["trsv_ms"]),
+                "likelihood_evaluations_per_sec": 1e3 / lik_ms,
+                "cholesky_tflops_fp64": chol_tf, "cholesky_frac_mfma_peak": chol_tf / FP64_MFMA_PEAK_TFLOPS,
+                "trsv_frac_hbm": (4.0 * npad * (npad + 1)) / (acc["trsv_ms"] * 1e-3) / 8e12,
+                "predict_pairs_per_sec": float(m) * n / (acc["predict_ms"] * 1e-3),
+                "predict_points_per_sec": m / (acc["predict_ms"] * 1e-3)})
+    for b in bufs + [da, dys]:
+        b.free()
+    # (ii) configs[2]: 2-D VonKarman N = 32768 with the two-pcf hyper-parameter fit
+    n = 32768
+    X, y, y_err, Xs = star_field(n, n)
+    vk = ops.KernelSpec(_lib.TGP_VK, amp=1.0, ell=0.1)
+    dX, de = ops.DeviceBuffer.from_array(ctx, X), ops.DeviceBuffer.from_array(ctx, y_err)
+    dA = ops.DeviceBuffer(ctx, lib.tgp_panel_elems(n) * 8)
+    best = 1e9
+    for _ in range(4):
+        _lib.check(ctx, lib.tgp_d_kbuild_lower(ctx, C.byref(vk.to_c()), dX.ptr, n, de.ptr, dA.ptr), "kbuild")
+        best = min(best, _lib.timings(ctx)[0])
+    for b in (dX, de, dA):
+        b.free()
+    VK_CEILING, LDS_ATOMIC_CEILING = 1.745e11, 1.04e11      # profiles/r02_vk_ceiling.txt, r02_lds_atomic_ceiling.txt
+    elems = n * (n + 1) / 2.0
+    gp = treegp_amd.GPInterpolation(kernel="1.0**2 * VonKarman(length_scale=0.1)", optimizer="two-pcf", nbins=20, normalize=True)
+    gp.initialize(X, y, y_err)
+    gp.solve()                                              # warm-up
+    gp.initialize(X, y, y_err)
+    t0 = time.perf_counter()
+    gp.solve()
+    fit_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    gp.predict(Xs)
+    solve_predict_ms = (time.perf_counter() - t0) * 1e3
+    k = y - y.mean()
+    w = 1.0 / y_err ** 2
+    ops.kk_log(X[:, 0], X[:, 1], k, w, 1.0 / np.sqrt(n), 0.7, 20)
+    ops.kk_log(X[:, 0], X[:, 1], k, w, 1.0 / np.sqrt(n), 0.7, 20)
+    kk_ms = _lib.timings(ctx)[4]
+    rng = np.random.default_rng(610639139)
+    idx = np.stack([rng.integers(0, n - 1, size=n) for _ in range(444)])
+    ops.kk_twod_bootstrap(X[:, 0], X[:, 1], y, y_err, idx, 0.0, 0.15, 21)
+    t0 = time.perf_counter()
+    ops.kk_twod_bootstrap(X[:, 0], X[:, 1], y, y_err, idx, 0.0, 0.15, 21)
+    boot_wall = (time.perf_counter() - t0) * 1e3
+    boot_dev = _lib.timings(ctx)[4]
+    out.append({"config": "configs[2]: 2-D VonKarman N=32768, two-pcf fit (nbins=20), one GPU",
+                "kbuild_ms": best, "kbuild_elements_per_sec": elems / (best * 1e-3),
+                "kbuild_frac_of_vk_ceiling": elems / (best * 1e-3) / VK_CEILING,
+                "two_pcf_fit_ms": fit_ms, "solve_plus_predict_32768_ms": solve_predict_ms,
+                "kk_log_ms_incl_copies": kk_ms, "kk_log_pairs_per_sec": n * (n - 1) / 2.0 / (kk_ms * 1e-3),
+                "kk_log_frac_of_lds_atomic_ceiling": n * (n - 1) / 2.0 / (kk_ms * 1e-3) / LDS_ATOMIC_CEILING,
+                "bootstrap_444_resamples_21x21_ms": {"device_incl_copies": boot_dev, "wall": boot_wall}})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +232,9 @@ def main():
     ap.add_argument("--ntrain", dest="n", type=int, default=65536, help="training points (default: headline 65536)")
     ap.add_argument("--mpredict", dest="m", type=int, default=0, help="prediction points (default 4 n)")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="N of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--meanify", action="store_true", help="configs[4]'s recipe: mean-function table (KNN-4) under the field")
+    ap.add_argument("--api", action="store_true", help="one GPU: step through GPInterpolation too (always so with --gpus > 1)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs[1] / configs[2] measurements of the one-GPU line")
     args = ap.parse_args()
     n = args.n
     m = args.m or 4 * n
@@ -147,18 +247,28 @@ def main():
         sys.exit(self_launch(args))                   # before anything below initialises HIP in this process
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ["TGP_DEVICE"] = str(local_rank)         # the process-wide context of this rank (KNN mean function, ...)
 
     from treegp_amd import _lib, ops
-    from treegp_amd.synthetic import star_field, headline_invlam
+    from treegp_amd.synthetic import star_field, star_field_with_mean, headline_invlam, headline_kernel_string
 
     lib = _lib.load_library()
     ctx = _lib.get_ctx(device=local_rank)
-    X, y, y_err, Xs = star_field(n, m)
+    api = world > 1 or args.api or args.meanify
+    fits = None
+    if args.meanify:
+        import tempfile
+        from treegp_amd.fits_io import write_bintable_row
+        X, y, y_err, Xs, X0, y0 = star_field_with_mean(n, m)
+        fits = os.path.join(tempfile.mkdtemp(), "mean_rank%d.fits" % rank)
+        write_bintable_row(fits, {"COORDS0": X0, "PARAMS0": y0})      # the wire format of treegp/meanify.py:139-165
+    else:
+        X, y, y_err, Xs = star_field(n, m)
     iL = headline_invlam()
     spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=iL[0, 0], b=iL[0, 1], c=iL[1, 1])
     ymean = y.mean()
 
-    dist_solver = None
+    engine = None
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -176,8 +286,8 @@ def main():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-        from treegp_amd.dist import DistributedGP
-        dist_solver = DistributedGP(ctx, spec, X, y - ymean, y_err, Xs, profile=True)
+        from treegp_amd import dist as tdist
+        engine = tdist.enable(profile=True, min_n=0)
 
         def barrier():
             dist.barrier()
@@ -188,7 +298,7 @@ def main():
             lib.tgp_sync(ctx)
 
     lib.tgp_set_profiling(ctx, 1)
-    if world == 1:
+    if not api:
         dX = ops.DeviceBuffer.from_array(ctx, X)
         dy = ops.DeviceBuffer.from_array(ctx, y - ymean)
         de = ops.DeviceBuffer.from_array(ctx, y_err)
@@ -211,11 +321,31 @@ def main():
                          ("syrk_ms", tm[5]), ("syrk_launches", tm[6]), ("syrk_flops", tm[7]), ("kbuild_bytes", tm[8])):
                 acc[k] = acc.get(k, 0.0) + v
     else:
+        # the drop-in API itself (treegp/gp_interp.py:196-227, 143-194): initialize() takes the data -- mean function at
+        # the stars, mean, noise -- and predict() builds K, factorises, solves and predicts; with --gpus > 1 on the
+        # multi-GPU route (treegp_amd.dist: row-block-cyclic Cholesky, query points sharded), every rank the same calls
+        import treegp_amd
+        gp = treegp_amd.GPInterpolation(kernel=headline_kernel_string(), optimizer="none", normalize=True, white_noise=0.0,
+                                        average_fits=fits, backend="dist" if world > 1 else "single")
+
         def step(acc):
-            dist_solver.step(acc)
+            t0 = time.perf_counter()
+            gp.initialize(X, y, y_err)
+            t1 = time.perf_counter()
+            gp.predict(Xs)
+            t2 = time.perf_counter()
+            acc["api_initialize_ms"] = acc.get("api_initialize_ms", 0.0) + (t1 - t0) * 1e3
+            acc["api_predict_ms"] = acc.get("api_predict_ms", 0.0) + (t2 - t1) * 1e3
+            if engine is None:
+                tm = _lib.timings(ctx)       # of the last calls on the process-wide context: the solve, then the predict
+                for k, v in (("kbuild_ms", tm[0]), ("chol_ms", tm[1]), ("trsv_ms", tm[2]), ("predict_ms", tm[3]),
+                             ("syrk_ms", tm[5]), ("syrk_launches", tm[6]), ("syrk_flops", tm[7]), ("kbuild_bytes", tm[8])):
+                    acc[k] = acc.get(k, 0.0) + v
 
     for _ in range(args.warmup):
         step({})
+    if engine is not None:
+        engine.acc.clear()
     barrier()
     t0 = time.perf_counter()
     acc = {}
@@ -223,32 +353,57 @@ def main():
         step(acc)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        acc.update(engine.acc)
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        seen = torch.ones(1, dtype=torch.float64, device=t.device)
+        seen = torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(seen)
         ranks_seen = int(seen.item())
+        # per-rank diagnostics (ms per step): where each rank's factorisation time went
+        names = ("chol_ms", "syrk_ms", "chain_ms", "gather_wait_ms", "trsv_ms", "predict_ms", "bytes_received")
+        mine = torch.zeros(world * len(names), dtype=torch.float64, device=dev)
+        for i, k in enumerate(names):
+            mine[rank * len(names) + i] = acc.get(k, 0.0) / args.steps
+        dist.all_reduce(mine)
+        tab = mine.cpu().numpy().reshape(world, len(names))
+        per_rank = {("bulk_ms" if k == "syrk_ms" else k): [float(v) for v in tab[:, i]] for i, k in enumerate(names)}
     else:
         ranks_seen = 1
 
     if rank == 0:
         K = args.steps
         ms_step = dt / K * 1e3
+        recipe = "configs[4] recipe (mean-function table by KNN-4 + y_err noise diagonal)" if args.meanify else \
+                 "configs[3] problem (y_err noise diagonal)"
         out = {
             "metric": "GP solve+predict throughput, 2-D AnisotropicRBF N=%d" % n,
             "value": (n + m) * K / dt, "unit": "points/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "ranks_seen": ranks_seen,
-            "config": {"workload": "configs[3] problem (2-D AnisotropicRBF star field, N=%d training points, "
-                                   "y_err noise diagonal) solved end to end + fused predict of M=%d points; "
-                                   "%s" % (n, m, "one GPU" if world == 1 else "row-block-cyclic over %d GPUs" % world),
+            "config": {"workload": "%s: 2-D AnisotropicRBF star field, N=%d training points, solved end to end + fused "
+                                   "predict of M=%d points; %s; %s"
+                                   % (recipe, n, m, "one GPU" if world == 1 else "row-block-cyclic over %d GPUs" % world,
+                                      "through treegp_amd.GPInterpolation (initialize + predict)" if api else
+                                      "device-resident C-ABI calls (tgp_d_gp_solve + tgp_d_gp_predict)"),
                        "n_train": n, "m_predict": m, "kernel": "1.0**2 * AnisotropicRBF(invLam=inv(L(0.05,0.2,0.1)))",
-                       "parallelism": "single" if world == 1 else "rowcyclic%d" % world},
+                       "parallelism": "single" if world == 1 else "rowcyclic%d" % world, "through_api": bool(api),
+                       "meanify": bool(args.meanify)},
         }
+        if per_rank is not None:
+            np_ = (n + 255) // 256 * 256
+            out["per_rank_ms_per_step"] = per_rank
+            out["bytes_received_expected"] = 4.0 * np_ * np_ * (world - 1) / world
+            out["per_rank_note"] = ("chol_ms = factorisation wall on the rank's main stream; bulk_ms = its trailing-update kernels; "
+                                    "chain_ms = its look-ahead stream (diagonal blocks, broadcasts, local solves, all-gathers, strips); "
+                                    "gather_wait_ms = main stream stalled behind the chain between two bulk updates")
+        if "api_predict_ms" in acc:
+            out["api_ms_per_step"] = {"initialize": acc["api_initialize_ms"] / K, "predict": acc["api_predict_ms"] / K}
         if acc.get("syrk_ms", 0) > 0:
             ach = acc["syrk_flops"] / (acc["syrk_ms"] * 1e-3) / 1e12          # per GPU (rank 0's share when N > 1)
             launches = max(acc["syrk_launches"], 1)
@@ -271,31 +426,33 @@ def main():
             out["cholesky_tflops_fp64"] = (n ** 3 / 3.0) * K / (acc["chol_ms"] * 1e-3) / 1e12
             out["gp_solves_per_sec"] = K / ((acc["kbuild_ms"] + acc["chol_ms"] + acc["trsv_ms"]) * 1e-3)
             out["predict_points_per_sec"] = m * K / (acc["predict_ms"] * 1e-3)
-            if "kbuild_bytes" in acc:
-                out["kbuild_GBps"] = acc["kbuild_bytes"] / (acc["kbuild_ms"] * 1e-3) / 1e9
+            npad = (n + 255) // 256 * 256
+            if world == 1:
+                kb_bytes = K * (8.0 * (npad * (npad + 1) / 2.0) + 16.0 * npad)
+                out["kbuild_GBps"] = kb_bytes / (acc["kbuild_ms"] * 1e-3) / 1e9
                 # K build is HBM-write bound, 8 Np(Np+1)/2 + 16 Np algorithmic bytes per launch
-                kb_t, kb_src = measured_traffic(n, "kbuild_write_bytes") if world == 1 else (None, "")
+                kb_t, kb_src = measured_traffic(n, "kbuild_write_bytes")
                 out["roofline_kbuild"] = {"bound": "hbm", "achieved": out["kbuild_GBps"], "peak": 8000.0, "unit": "GB/s",
                                           "frac": out["kbuild_GBps"] / 8000.0, "traffic": kb_t, "traffic_source": kb_src,
-                                          "algorithmic_bytes": acc["kbuild_bytes"] / K,
+                                          "algorithmic_bytes": kb_bytes / K,
                                           "kernel": "kbuild_slab_kernel<GAUSS>", "avg_launch_ms": acc["kbuild_ms"] / K}
-            # both triangular sweeps read the packed factor once each, ~8 Np^2 bytes per solve
-            npad = (n + 255) // 256 * 256
-            tr_bytes = 2 * 8.0 * (npad * (npad + 1) / 2.0)
+            # SURVEY 8(d) prices the solves at two reads of the packed factor (forward + backward sweep, ~8 Np^2 B).  From
+            # round 3 the right-hand side rides through the factorisation as an extra matrix row (L^-1 y comes out of it), so
+            # only the backward sweep is left: ONE read of L, ~4 Np^2 B, is the algorithmic traffic of what runs here
+            tr_bytes = (1 if acc.get("sweeps_per_solve", 2) == 1 else 2) * 8.0 * (npad * (npad + 1) / 2.0)
             tr_rate = tr_bytes * K / (acc["trsv_ms"] * 1e-3) / 1e9
             out["roofline_trsv"] = {"bound": "hbm", "achieved": tr_rate, "peak": 8000.0, "unit": "GB/s", "frac": tr_rate / 8000.0,
-                                    "traffic": None, "algorithmic_bytes": tr_bytes, "kernel": "potrs: forward + backward sweep",
-                                    "avg_ms": acc["trsv_ms"] / K}
+                                    "traffic": None, "algorithmic_bytes": tr_bytes,
+                                    "kernel": "potrs: forward + backward sweep", "avg_ms": acc["trsv_ms"] / K}
             # the fused predict is fp64-VALU-bound, 30 algorithmic flops per (query, training point) pair
             m_rank = m if world == 1 else -(-m // world)
             pr_tf = 30.0 * m_rank * n * K / (acc["predict_ms"] * 1e-3) / 1e12
             out["roofline_predict"] = {"bound": "valu", "achieved": pr_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": pr_tf / 78.6,
                                        "pairs_per_sec": m_rank * n * K / (acc["predict_ms"] * 1e-3),
-                                       # the loop is 22 fp64 VALU instructions per pair and nothing else (csrc/predict.hip):
-                                       # fraction of 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz / 22 (the chip holds 2.2 GHz here)
-                                       "valu_issue_frac_at_2p4ghz": m_rank * n * K / (acc["predict_ms"] * 1e-3) * 22 / (256 * 4 * 16 * 2.4e9),
                                        "kernel": "predict_gauss_fast_kernel", "avg_ms": acc["predict_ms"] / K}
             out["phases_ms_per_step"] = {k: acc[k] / K for k in ("kbuild_ms", "chol_ms", "trsv_ms", "predict_ms", "syrk_ms")}
+        if world == 1 and not args.no_configs:
+            out["configs_measured"] = configs_measured(lib, ctx, ops, _lib)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 4 * args.cpu_sample, n)
         print(json.dumps(out), flush=True)

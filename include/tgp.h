@@ -90,6 +90,10 @@ int tgp_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n,
                  const double *y, const double *yerr, double *alpha, double *logdet,
                  double *ydota, tgp_factor **keep);
 void tgp_factor_free(tgp_ctx *ctx, tgp_factor *f);
+/* a handle on a factor in the CALLER's device memory (d_A: tgp_panel_elems(Np) packed doubles, d_W: Np x 128, as
+ * tgp_d_potrf leaves them) -- the multi-GPU driver's replicated factor; tgp_factor_free never frees d_A / d_W of it.
+ * Serves the same reference lines as a kept factor: gp_interp.py:184-192 (covariance), README.rst:28 (several fields). */
+int tgp_factor_borrow(tgp_ctx *ctx, double *d_A, double *d_W, int64_t n, tgp_factor **out);
 
 /* ---- S2b: the same for a kernel matrix the CALLER evaluated ---------------------------------
  * For scikit-learn kernel trees tgp_kernel cannot describe (Sum, WhiteKernel, Matern, ...): the

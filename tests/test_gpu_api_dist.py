@@ -1,0 +1,216 @@
+"""The multi-GPU route BEHIND the drop-in API (SURVEY 8e through treegp/gp_interp.py:143-194, 196-227, 229-243):
+``GPInterpolation(backend="dist")`` / ``treegp_amd.dist.enable()`` on configs[4]'s recipe -- mean-function table,
+non-uniform y_err, white noise, normalize -- with 2, 4 and 8 virtual ranks on one GPU (threads, own tgp_ctx each, the
+real kernels), and the same script as real processes over gloo.  Compared with the single-GPU API result and the oracle."""
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def _recipe(n, m, tmp_path, seed=5):
+    from treegp_amd.fits_io import write_bintable_row
+    from treegp_amd.synthetic import star_field_with_mean, headline_kernel_string
+    X, y, y_err, Xs, X0, y0 = star_field_with_mean(n, m, seed=seed)
+    fits = os.path.join(str(tmp_path), "mean.fits")
+    write_bintable_row(fits, {"COORDS0": X0, "PARAMS0": y0})
+    kw = dict(kernel=headline_kernel_string(), optimizer="none", normalize=True, white_noise=0.004, average_fits=fits)
+    return X, y, y_err, Xs, X0, y0, kw
+
+
+def _oracle_predict(X, y, y_err, Xs, X0, y0, white_noise):
+    """configs[4]'s recipe restated with the oracle: KNN-4 mean function, mean of the residual, noise in quadrature"""
+    from oracle import gp_oracle as O
+    from treegp_amd.synthetic import headline_invlam
+    iL = headline_invlam()
+    kw = dict(amp=1.0, a=iL[0, 0], b=iL[0, 1], c=iL[1, 1])
+    avg = O.knn_mean(X0, y0, X, 4)
+    mean = np.mean(y - avg)
+    sigma = np.sqrt(y_err ** 2 + white_noise ** 2)
+    alpha, logdet = O.gp_solve(O.kernel_matrix("gauss", X, **kw), y - mean - avg, sigma)
+    return O.gp_predict(O.kernel_matrix("gauss", Xs, X, **kw), alpha) + mean + O.knn_mean(X0, y0, Xs, 4)
+
+
+def _virtual_ranks(G, fn):
+    """run fn(rank) on G threads, each with its own context and a thread-local engine over an in-process communicator"""
+    import torch
+    from treegp_amd import _lib, dist
+    from _dist_helpers import ThreadComm
+    shared = ThreadComm.Shared(G)
+    results, errors = [None] * G, []
+    dev = torch.device("cuda", 0)
+
+    def run(rank):
+        try:
+            _lib.set_thread_ctx(_lib.new_ctx(0))
+            dist.enable(comm=ThreadComm(shared, rank), device=dev, min_n=10 ** 9, thread_local=True)
+            try:
+                results[rank] = fn(rank)
+            finally:
+                dist.disable()
+                _lib.set_thread_ctx(None)
+        except BaseException as e:            # noqa: BLE001 - surface any failure of a virtual rank
+            errors.append(e)
+            try:
+                shared.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("G,n,group", [(2, 12000, 2), (4, 12000, 4), (8, 12000, 2), (8, 5000, 4)])
+def test_config5_recipe_through_the_api_virtual_ranks(G, n, group, tmp_path, monkeypatch):
+    import treegp_amd
+    monkeypatch.setenv("TGP_DIST_GROUP", str(group))
+    m = 3000
+    X, y, y_err, Xs, X0, y0, kw = _recipe(n, m, tmp_path)
+    one = treegp_amd.GPInterpolation(**kw)
+    one.initialize(X, y, y_err)
+    ref = one.predict(Xs)
+    ll_ref = one.return_log_likelihood()
+    _, cov_ref = one.predict(Xs[:150], return_cov=True)
+    ora = _oracle_predict(X, y, y_err, Xs, X0, y0, kw["white_noise"]) if n <= 6000 else None
+
+    def rank_fn(rank):
+        gp = treegp_amd.GPInterpolation(backend="dist", **kw)
+        gp.initialize(X, y, y_err)
+        yp = gp.predict(Xs)
+        assert gp._alpha is not None
+        yp_again = gp.predict(Xs)                              # the cached alpha: no second factorisation
+        _, cov = gp.predict(Xs[:150], return_cov=True)
+        return yp, yp_again, cov, gp.return_log_likelihood()
+
+    scale = np.abs(ref).max()
+    for yp, yp_again, cov, ll in _virtual_ranks(G, rank_fn):
+        np.testing.assert_allclose(yp, ref, rtol=0, atol=1e-10 * scale)
+        np.testing.assert_array_equal(yp, yp_again)
+        np.testing.assert_allclose(cov, cov_ref, rtol=0, atol=1e-9 * np.abs(cov_ref).max())
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-11)
+        if ora is not None:
+            np.testing.assert_allclose(yp, ora, rtol=0, atol=1e-10 * np.abs(ora).max())
+
+
+def test_threshold_route_fields_and_errors_virtual_ranks(tmp_path):
+    """An enabled engine takes objects that name no backend once they reach its size threshold and leaves smaller ones
+    alone; ``predict_fields`` solves every field against the replicated factor; a matrix that is not positive definite
+    raises LinAlgError on every rank; ``backend="single"`` never leaves the rank's own GPU."""
+    import treegp_amd
+    from treegp_amd import dist
+    n, m, G = 3000, 800, 3
+    X, y, y_err, Xs, X0, y0, kw = _recipe(n, m, tmp_path, seed=9)
+    rng = np.random.default_rng(2)
+    Y = np.stack([y, y[::-1].copy(), y + 0.1 * rng.standard_normal(n)])
+    one = treegp_amd.GPInterpolation(**kw)
+    one.initialize(X, y, y_err)
+    ref, ref_fields = one.predict(Xs), one.predict_fields(Y, Xs)
+
+    def rank_fn(rank):
+        eng = dist.engine_for(10 ** 9)                        # the thread's engine (min_n = 1e9 so far)
+        assert dist.engine_for(n) is None
+        eng.min_n = 2000
+        assert dist.engine_for(n) is eng and dist.engine_for(1999) is None
+        gp = treegp_amd.GPInterpolation(**kw)                 # no backend named: the threshold decides
+        gp.initialize(X, y, y_err)
+        solves = []
+        orig = eng.gp_solve
+        eng.gp_solve = lambda *a, **k: (solves.append(1), orig(*a, **k))[1]
+        yp = gp.predict(Xs)
+        fields = gp.predict_fields(Y, Xs)
+        assert len(solves) == 2
+        single = treegp_amd.GPInterpolation(backend="single", **kw)
+        single.initialize(X, y, y_err)
+        ys = single.predict(Xs)
+        assert len(solves) == 2                               # that one stayed on the single-GPU path
+        bad = treegp_amd.GPInterpolation(kernel=kw["kernel"], optimizer="none", backend="dist")
+        Xd = X.copy()
+        Xd[1] = Xd[0]
+        bad.initialize(Xd, y, np.zeros(n))
+        with pytest.raises(np.linalg.LinAlgError):
+            bad.predict(Xs[:10])
+        return yp, fields, ys
+
+    scale = np.abs(ref).max()
+    for yp, fields, ys in _virtual_ranks(G, rank_fn):
+        np.testing.assert_allclose(yp, ref, rtol=0, atol=1e-10 * scale)
+        np.testing.assert_allclose(ys, ref, rtol=0, atol=1e-12 * scale)
+        np.testing.assert_allclose(fields, ref_fields, rtol=0, atol=1e-10 * np.abs(ref_fields).max())
+
+
+def test_ml_fit_and_two_pcf_through_the_api_virtual_ranks():
+    """``solve()`` with the likelihood optimiser and with the 2-pcf optimiser on the multi-GPU route: every likelihood
+    evaluation is one distributed factorisation, the pair binning is sharded over the same ranks (ops.set_pair_comm by
+    the same switch); the fitted kernels equal the single-GPU fits."""
+    import treegp_amd
+    from treegp_amd.synthetic import star_field
+    n = 1500
+    X, y, y_err, Xs = star_field(n, 100, seed=3, noise=0.05)
+    kern = "0.5**2 * AnisotropicRBF(invLam=array([[300., 20.], [20., 500.]]))"
+    fits = {}
+    for opt in ("log-likelihood", "two-pcf"):
+        gp = treegp_amd.GPInterpolation(kernel=kern if opt == "log-likelihood" else "0.5**2 * RBF(0.1)", optimizer=opt,
+                                        normalize=True, min_sep=0.0, max_sep=0.3, nbins=12)
+        gp.initialize(X, y, y_err)
+        gp.solve()
+        fits[opt] = (gp.kernel.theta.copy(), gp.predict(Xs))
+
+    def rank_fn(rank):
+        out = {}
+        for opt in ("log-likelihood", "two-pcf"):
+            gp = treegp_amd.GPInterpolation(kernel=kern if opt == "log-likelihood" else "0.5**2 * RBF(0.1)", optimizer=opt,
+                                            normalize=True, min_sep=0.0, max_sep=0.3, nbins=12, backend="dist")
+            gp.initialize(X, y, y_err)
+            gp.solve()
+            out[opt] = (gp.kernel.theta.copy(), gp.predict(Xs))
+        return out
+
+    for out in _virtual_ranks(2, rank_fn):
+        # the 2-pcf fit sees the same binned sums to 1e-12 and ends at the same kernel; the likelihood fit walks through the
+        # same finite-difference iterates up to the solves' rounding (the reference tolerates 0.5-0.7 in theta here)
+        np.testing.assert_allclose(out["two-pcf"][0], fits["two-pcf"][0], rtol=1e-6)
+        np.testing.assert_allclose(out["log-likelihood"][0], fits["log-likelihood"][0], atol=2e-2)
+        sc = np.abs(fits["two-pcf"][1]).max()
+        np.testing.assert_allclose(out["two-pcf"][1], fits["two-pcf"][1], rtol=0, atol=1e-6 * sc)
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_api_script_as_real_processes_gloo(G):
+    """tests/_api_dist_script.py under torch.distributed.run: G processes sharing this box's one GPU over gloo -- the
+    launch a multi-GPU node makes with nccl = RCCL and one rank per device."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, TGP_DIST_BACKEND="gloo", TGP_ONE_DEVICE="1", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TGP_DIST"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(G), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(HERE, "_api_dist_script.py"), "3000", "1500"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "api dist ok: world %d" % G in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_api_script_on_rccl_world_of_one():
+    """the same script on the real nccl (RCCL) backend with one rank: every torch.distributed call of the API route"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("TGP_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_api_dist_script.py"), "2500", "700"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "api dist ok: world 1" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -224,6 +224,31 @@ def test_bench_self_launch_rehearsal(G):
     out = json.loads(lines[0])
     assert out["n_gpus"] == G and out["ranks_seen"] == G and out["steps"] == 2
     assert out["value"] > 0 and out["unit"] == "points/s" and out["scaling"] == "strong"
+    # the N > 1 step goes through the drop-in API on the multi-GPU route, and the line explains itself per rank
+    assert out["config"]["through_api"] is True and "api_ms_per_step" in out
+    pr = out["per_rank_ms_per_step"]
+    for key in ("chol_ms", "bulk_ms", "chain_ms", "gather_wait_ms", "trsv_ms", "predict_ms", "bytes_received"):
+        assert len(pr[key]) == G and all(v >= 0 for v in pr[key]), key
+    assert all(v > 0 for v in pr["chain_ms"]) and all(v > 0 for v in pr["bulk_ms"])
+    # every rank receives the panels it does not own: ~ 4 N^2 (G-1)/G bytes (+ the diagonal-block broadcasts, + padding)
+    exp = out["bytes_received_expected"]
+    assert all(0.8 * exp < v < 1.6 * exp for v in pr["bytes_received"]), (pr["bytes_received"], exp)
+
+
+def test_bench_meanify_recipe_through_api_rehearsal():
+    """`bench.py --gpus 2 --meanify`: configs[4]'s recipe (mean-function table + y_err) through GPInterpolation on the
+    multi-GPU route, rehearsed with gloo on one GPU."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TGP_DIST_BACKEND="gloo", TGP_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--ntrain", "5000", "--meanify", "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["config"]["meanify"] is True and out["config"]["through_api"] is True and out["n_gpus"] == 2
 
 
 def test_bench_line_schema_single_gpu():
@@ -254,8 +279,18 @@ def test_bench_line_schema_single_gpu():
     for sub in ("roofline_kbuild", "roofline_trsv"):
         assert out[sub]["bound"] == "hbm" and out[sub]["unit"] == "GB/s" and 0 < out[sub]["frac"] < 1
     cb = out["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample", "passes", "phases_s"):
+    for key in ("value", "unit", "cores", "blas_threads", "kind", "sample", "passes", "phases_s"):
         assert key in cb, key
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["passes"] >= 3
+    assert cb["kind"] == "port" and 1 <= cb["cores"] <= cb["blas_threads"] and cb["passes"] >= 3
+    # configs[1] and configs[2] ride on the same line
+    c1, c2 = out["configs_measured"]
+    for key in ("ms", "gp_solves_per_sec", "likelihood_evaluations_per_sec", "cholesky_tflops_fp64", "cholesky_frac_mfma_peak",
+                "trsv_frac_hbm", "predict_pairs_per_sec", "phases_ms"):
+        assert key in c1, key
+    assert "N=8192" in c1["config"] and 0 < c1["cholesky_frac_mfma_peak"] < 1 and 0 < c1["trsv_frac_hbm"] < 1
+    for key in ("kbuild_elements_per_sec", "kbuild_frac_of_vk_ceiling", "two_pcf_fit_ms", "kk_log_pairs_per_sec",
+                "kk_log_frac_of_lds_atomic_ceiling", "bootstrap_444_resamples_21x21_ms", "solve_plus_predict_32768_ms"):
+        assert key in c2, key
+    assert "N=32768" in c2["config"] and c2["two_pcf_fit_ms"] > 0
     assert any(k.startswith("extrapolated_n") for k in cb)
     np.testing.assert_allclose(out["value"], (24576 + 4 * 24576) / (out["ms_per_step"] * 1e-3), rtol=1e-9)

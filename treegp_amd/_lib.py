@@ -38,6 +38,7 @@ SIGNATURES = {
     "tgp_kernel_matrix": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _i64, _vp]),
     "tgp_gp_solve": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp, _vp, _dp, _dp, C.POINTER(_vp)]),
     "tgp_factor_free": (None, [_vp, _vp]),
+    "tgp_factor_borrow": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(_vp)]),
     "tgp_gp_predict": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp, _i64, _vp]),
     "tgp_gp_predict_cov": (C.c_int, [_vp, _vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _i64, _vp]),
     "tgp_kk_twod": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp]),
@@ -150,8 +151,19 @@ class TgpError(RuntimeError):
     pass
 
 
+_thread = threading.local()
+
+
+def set_thread_ctx(ctx):
+    """This thread's default context (None = back to the process-wide one).  A context serves one caller at a time, so
+    threads that compute side by side -- the virtual ranks of the multi-GPU tests -- each bring their own."""
+    _thread.ctx = ctx
+
+
 def get_ctx(device=None):
     """One context per (process, device).  Raises if there is no HIP device -- by design."""
+    if device is None and getattr(_thread, "ctx", None) is not None:
+        return _thread.ctx
     lib = load_library()
     if device is None:
         device = int(os.environ.get("TGP_DEVICE", os.environ.get("LOCAL_RANK", "0")))

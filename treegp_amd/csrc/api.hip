@@ -94,6 +94,7 @@ void *tgp_io_buffer(tgp_ctx *ctx) { return ext_of(ctx)->io.buf; }
 // a kept factor goes back to being the context's factor cache (the next tgp_d_gp_solve of the same size reuses its memory)
 void tgp_factor_release_to_cache(tgp_ctx *ctx, tgp_factor *f) {
     if (!f) return;
+    if (f->borrowed) { tgp_factor_free(ctx, f); return; }
     tgp_ctx_ext *e = ext_of(ctx);
     if (e->A_cache) (void)hipFree(e->A_cache);
     if (e->W_cache) (void)hipFree(e->W_cache);
@@ -471,11 +472,27 @@ void tgp_factor_free(tgp_ctx *ctx, tgp_factor *f) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    if (f->d_A) (void)hipFree(f->d_A);
-    if (f->d_W) (void)hipFree(f->d_W);
+    if (f->d_A && !f->borrowed) (void)hipFree(f->d_A);
+    if (f->d_W && !f->borrowed) (void)hipFree(f->d_W);
     if (f->d_slabs) (void)hipFree(f->d_slabs);
     if (f->d_slabs2) (void)hipFree(f->d_slabs2);
     delete f;
+}
+
+// A handle on a factor that lives in the CALLER's device memory (packed panels d_A + inverted diagonal blocks d_W, as
+// tgp_d_potrf leaves them): what the multi-GPU driver's replicated factor is.  Everything that takes a tgp_factor
+// (tgp_factor_solve, tgp_gp_predict_cov, tgp_gp_loglik_grad) then works on it; tgp_factor_free releases the handle and
+// the slabs it built, never d_A / d_W.
+int tgp_factor_borrow(tgp_ctx *ctx, double *d_A, double *d_W, int64_t n, tgp_factor **out) {
+    TGP_ARG(d_A && d_W && out && n > 0);
+    tgp_factor *f = new tgp_factor();
+    f->n = n;
+    f->Np = padded_n(n);
+    f->d_A = d_A;
+    f->d_W = d_W;
+    f->borrowed = true;
+    *out = f;
+    return 0;
 }
 
 // ---- S3 ---------------------------------------------------------------------------------------

@@ -59,6 +59,7 @@ struct tgp_factor {
     int slab_S = 0;               // the step they were built for
     double *d_slabs2 = nullptr;   // slabs of another step for the block substitution of cov.hip (factor_slabs)
     int slab2_S = 0;
+    bool borrowed = false;        // tgp_factor_borrow: d_A / d_W belong to the caller (multi-GPU driver's replicated factor)
 };
 
 #define TGP_HIP(call)                                                                   \

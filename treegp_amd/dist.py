@@ -165,13 +165,32 @@ def agree_replicate(comm, vote, env_rank0=None):
     return t.item() == 0.0
 
 
+class RankStreams(object):
+    """The two extra streams of a rank -- high-priority look-ahead stream for the panel chain, a third one for the copies
+    into the replicated factor -- each with the tgp_ctx whose kernels run on it."""
+
+    def __init__(self, device):
+        import torch
+        from . import _lib
+        lib = _lib.load_library()
+        idx = device.index if device.index is not None else 0
+        self.side_stream = torch.cuda.Stream(device=device, priority=-1)
+        self.ctx_side = _lib.new_ctx(idx)
+        lib.tgp_set_stream(self.ctx_side, C.c_void_p(self.side_stream.cuda_stream))
+        self.keep_stream = torch.cuda.Stream(device=device)
+        self.ctx_keep = _lib.new_ctx(idx)
+        lib.tgp_set_stream(self.ctx_keep, C.c_void_p(self.keep_stream.cuda_stream))
+
+
 class HipLocalOps(object):
     """Local arithmetic of one rank on its GPU through the tgp_dd_* entry points."""
 
-    def __init__(self, ctx, spec, n, G, g, device, replicate=None):
+    def __init__(self, ctx, spec, n, G, g, device, replicate=None, streams=None):
         """``replicate``: keep a full copy of the factor on this rank for communication-free solves.  With more than
         one rank it MUST be the value ``agree_replicate`` returned (the same on every rank: the solve branches on it and
-        a mixed decision would pair collectives with no partner); None = decide locally (world of one)."""
+        a mixed decision would pair collectives with no partner); None = decide locally (world of one: its own share IS
+        the whole factor, in the single-GPU layout, so it is "replicated" without a copy unless TGP_DIST_REPLICATE=0).
+        ``streams``: a ``RankStreams`` to reuse (the engine behind the API builds one solver per problem size)."""
         import torch
         from . import _lib
         self.torch, self._lib, self.lib = torch, _lib, _lib.load_library()
@@ -190,22 +209,24 @@ class HipLocalOps(object):
         self.main_stream = torch.cuda.current_stream(device)
         self.lib.tgp_set_stream(ctx, C.c_void_p(self.main_stream.cuda_stream))
         # panel chain (diagonal block, broadcast, local solves, all-gather) runs on a second stream
-        # with its own context, concurrently with the bulk trailing update on the main stream
-        self.side_stream = torch.cuda.Stream(device=device, priority=-1)
-        self.ctx_side = _lib.new_ctx(device.index if device.index is not None else 0)
-        self.lib.tgp_set_stream(self.ctx_side, C.c_void_p(self.side_stream.cuda_stream))
-        # a third stream (own context) for the copies that build the replicated factor: they only need a gather to have
+        # with its own context, concurrently with the bulk trailing update on the main stream; a third stream (own
+        # context) carries the copies that build the replicated factor: they only need a gather to have
         # landed and its buffer not to be reused yet -- off the panel chain, where they cost up to 0.3 ms per panel
-        self.keep_stream = torch.cuda.Stream(device=device)
-        self.ctx_keep = _lib.new_ctx(device.index if device.index is not None else 0)
-        self.lib.tgp_set_stream(self.ctx_keep, C.c_void_p(self.keep_stream.cuda_stream))
+        st = streams or RankStreams(device)
+        self.side_stream, self.ctx_side, self.keep_stream, self.ctx_keep = st.side_stream, st.ctx_side, st.keep_stream, st.ctx_keep
         # replicated factor for the solves: every panel is seen by every rank anyway (broadcast + all-gather); kept
         # in the single-GPU packed layout it lets the triangular sweeps run locally, without their 2 N/256 collectives
         self.Afull = None
-        if replicate is None:
-            replicate = local_replicate_vote(self.lib, self.Np, G, device)
-        if replicate:
-            self.Afull = torch.empty(int(self.lib.tgp_panel_elems(self.Np)), dtype=torch.float64, device=device)
+        self.keep_copies = False              # factorize() copies the panels it sees into Afull
+        if G == 1 and replicate is None and os.environ.get("TGP_DIST_REPLICATE") != "0":
+            # a world of one holds every block row: its share is the single-GPU packed factor already
+            self.Afull = self.A[:int(self.lib.tgp_panel_elems(self.Np))]
+        else:
+            if replicate is None:
+                replicate = local_replicate_vote(self.lib, self.Np, G, device)
+            if replicate:
+                self.Afull = torch.empty(int(self.lib.tgp_panel_elems(self.Np)), dtype=torch.float64, device=device)
+                self.keep_copies = True
 
     def _chk(self, rc, what, ctx=None):
         self._lib.check(ctx or self.ctx, rc, what)
@@ -375,6 +396,9 @@ class DistributedCholesky(object):
         self.update_ms = 0.0          # local trailing-update kernel time of the last factorize()
         self.update_flops = 0.0       # algorithmic flops of this rank's share
         self.update_launches = 0
+        self.chain_ms = 0.0           # side stream: panel chains (diagonal blocks, broadcasts, local solves, gathers, strips)
+        self.wait_ms = 0.0            # main stream: stalled behind the chain / the gathers between two bulk updates
+        self.bytes_received = 0       # broadcast + all-gather payload this rank received (expected ~ 4 N^2 B (G-1)/G)
 
     def _local_update_flops(self, k):
         """2 * 256 flops per lower-triangle element of this rank's block rows > k"""
@@ -396,9 +420,10 @@ class DistributedCholesky(object):
         Per-tile fixed costs of the update (C read + write, pipeline fill) fall from 13 % at depth 256 to 6.8 %
         at 512 and 3.5 % at 1024 -- the single-GPU driver's schedule, with collectives."""
         ops, comm, G, g, nB, GS = self.ops, self.comm, self.G, self.g, self.nB, self.group
-        events = []
-        self.update_flops, self.update_launches = 0.0, 0
-        keep = bool(getattr(ops, "replicated", False))           # also build the replicated factor for the solves
+        events, chain_events, wait_events = [], [], []
+        self.update_flops, self.update_launches, self.bytes_received = 0.0, 0, 0
+        # also build the replicated factor for the solves (a world of one's share already is that factor: no copies)
+        keep = bool(getattr(ops, "replicated", False)) and bool(getattr(ops, "keep_copies", True))
 
         def factor_and_gather(k, buf):
             """panel k on the side stream: diagonal block on its owner, broadcast, local solves, all-gather"""
@@ -406,6 +431,8 @@ class DistributedCholesky(object):
             if g == owner:
                 ops.factor_diag(k)
             comm.broadcast(ops.bcast, owner)
+            if g != owner:
+                self.bytes_received += 8 * BCAST_ELEMS
             if keep:
                 ops.keep_diag(k)
             ops.trsm(k)
@@ -413,6 +440,7 @@ class DistributedCholesky(object):
             if rem == 0:
                 return None, 0
             cmax = -(-rem // G)                                  # most blocks > k any rank holds
+            self.bytes_received += 8 * (G - 1) * cmax * BLK * BLK
             send = ops.panel_send_view(k, cmax)
             return comm.all_gather_start(buf[:G * cmax * BLK * BLK], send), cmax     # the handle knows where the panel lands
 
@@ -420,6 +448,18 @@ class DistributedCholesky(object):
 
         def side_group(k, bufs):
             """panels k .. k+GS-1 (those that exist) on the side stream; returns [(gather handle, cmax)] per panel"""
+            if self.timer is not None:
+                c0 = self.timer()
+                c0.record()                                      # on the side stream (the caller's `with ops.on_side()`)
+            try:
+                return _side_group(k, bufs)
+            finally:
+                if self.timer is not None:
+                    c1 = self.timer()
+                    c1.record()
+                    chain_events.append((c0, c1))
+
+        def _side_group(k, bufs):
             if keep:
                 ops.side_wait_keeps(keep_events.pop(id(bufs[0]), None))     # these buffers were last read two groups ago
             out = []
@@ -480,8 +520,15 @@ class DistributedCholesky(object):
         while k + GS < nB:
             cur = self.gathered[flip * GS:(flip + 1) * GS]
             nxt = self.gathered[(1 - flip) * GS:(2 - flip) * GS]
+            if self.timer is not None:
+                w0 = self.timer()
+                w0.record()
             for w, _ in cur_w:
                 w.wait()                                         # main stream: the whole group is on every rank
+            if self.timer is not None:
+                w1 = self.timer()
+                w1.record()
+                wait_events.append((w0, w1))
             cm = [c for _, c in cur_w]
             cur = [w.tensor for w, _ in cur_w]                   # where each gathered panel of the group is (see _Done / _Work)
             timed(lambda: ops.update_group(k, cur, cm, 0, 2 * GS))           # Ua: the next group's columns
@@ -507,6 +554,8 @@ class DistributedCholesky(object):
         big = 1e18
         mine = ops.info()                                        # synchronises the stream
         self.update_ms = sum(a.elapsed_time(b) for a, b in events) if events else 0.0
+        self.chain_ms = sum(a.elapsed_time(b) for a, b in chain_events) if chain_events else 0.0
+        self.wait_ms = sum(a.elapsed_time(b) for a, b in wait_events) if wait_events else 0.0
         t = ops.zeros(1)
         t[0] = -(float(mine) if mine > 0 else big)
         comm.all_reduce_max(t)
@@ -641,3 +690,218 @@ class DistributedGP(object):
             mine[:hi - lo].copy_(self.dys[:hi - lo])
         self.comm.all_gather(buf, mine)
         return buf[:self.m]
+
+
+# ---- the multi-GPU route behind the drop-in API ---------------------------------------------------------------------
+# SPMD use: every rank runs the same script on the same data (``torchrun``), exactly as it would on one GPU.  With the
+# engine enabled, ``ops.gp_solve`` / ``ops.gp_predict`` -- and through them ``GPInterpolation.predict`` /
+# ``return_gp_predict`` (treegp/gp_interp.py:143-194), ``log_likelihood.log_likelihood`` (treegp/log_likelihood.py:21-41),
+# ``predict_fields`` and the kept-factor calls (posterior covariance, gp_interp.py:184-192) -- factorise with
+# ``DistributedCholesky`` and shard the query points; everything around them (normalize, white noise, mean function,
+# ``_alpha`` cache, LinAlgError on every rank) is the single-GPU host code, untouched.
+import threading as _threading
+
+_tls = _threading.local()
+_process_engine = None
+DEFAULT_MIN_N = 32768            # below this one GPU finishes a solve before eight have exchanged their panels
+
+
+class DistEngine(object):
+    """One rank's end of the distributed GP solve / predict.  ``comm``: TorchComm (default when torch.distributed is
+    initialised), SelfComm, or any object with the same five collectives (the tests' in-process communicator)."""
+
+    def __init__(self, comm=None, device=None, min_n=None, profile=False):
+        import torch
+        from . import _lib
+        self.torch, self._lib, self.lib = torch, _lib, _lib.load_library()
+        if comm is None:
+            import torch.distributed as dist
+            comm = TorchComm() if dist.is_available() and dist.is_initialized() else SelfComm()
+        self.comm = comm
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = device
+        self.min_n = int(os.environ.get("TGP_DIST_MIN_N", DEFAULT_MIN_N)) if min_n is None else int(min_n)
+        self.profile = bool(profile)
+        self.ctx = _lib.new_ctx(device.index if device.index is not None else 0)     # never the process-wide context:
+        self.streams = RankStreams(device)                                           # its stream follows torch's
+        self._solver = None                   # (n, HipLocalOps, DistributedCholesky) of the last problem size
+        self.acc = {}                         # profile=True: phase times (ms, this rank) summed over calls; reset by the caller
+
+    # -- plumbing -------------------------------------------------------------------------------------------------
+    def _solver_for(self, spec, n):
+        torch = self.torch
+        G, g = self.comm.size, self.comm.rank
+        if self._solver is not None and self._solver[0] == n:
+            ops, chol = self._solver[1], self._solver[2]
+            ops.spec, ops.kc = spec, spec.to_c()
+        else:
+            self._solver = None               # release the previous size's buffers before allocating
+            Np = int(self.lib.tgp_padded_n(n))
+            replicate = None
+            if G > 1:
+                replicate = agree_replicate(self.comm, lambda env: local_replicate_vote(self.lib, Np, G, self.device, env))
+            ops = HipLocalOps(self.ctx, spec, n, G, g, self.device, replicate=replicate, streams=self.streams)
+            timer = (lambda: torch.cuda.Event(enable_timing=True)) if self.profile else None
+            chol = DistributedCholesky(ops, self.comm, timer=timer)
+            self._solver = (n, ops, chol)
+        ops.main_stream = torch.cuda.current_stream(self.device)
+        self.lib.tgp_set_stream(self.ctx, C.c_void_p(ops.main_stream.cuda_stream))
+        return ops, chol
+
+    def _add(self, name, v):
+        self.acc[name] = self.acc.get(name, 0.0) + v
+
+    # -- seams S2 / S3 (include/tgp.h) on G GPUs --------------------------------------------------------------------
+    def gp_solve(self, spec, X, y, y_err=None, keep=False, want_alpha=True):
+        """(alpha, logdet, y.alpha, factor|None) like ``ops.gp_solve``, every rank returning the same values.  ``keep``
+        hands out the replicated factor (an ``ops.Factor`` on borrowed memory) for the kept-factor calls."""
+        from . import ops as _ops
+        from ._lib import as_xy, f64
+        torch = self.torch
+        X2 = as_xy(X)
+        n = X2.shape[0]
+        y = f64(y)
+        o, chol = self._solver_for(spec, n)
+        dX = o.to_device(X2)
+        de = o.to_device(np.zeros(n) if y_err is None else f64(y_err))
+        ypad = np.zeros(o.Np)
+        ypad[:n] = y
+        dy = o.to_device(ypad)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.profile else None
+        if ev: ev[0].record()
+        o.kbuild(dX, de)
+        if ev: ev[1].record()
+        info = chol.factorize()                              # all-reduced: the same verdict on every rank
+        if info != 0:
+            raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % info)
+        if ev: ev[2].record()
+        alpha = chol.solve(dy)
+        logdet = chol.logdet()
+        if ev: ev[3].record()
+        a = alpha.cpu().numpy()[:n].copy()                   # synchronises
+        logdet = float(logdet[0])
+        if ev:
+            for name, i, j in (("kbuild_ms", 0, 1), ("chol_ms", 1, 2), ("trsv_ms", 2, 3)):
+                self._add(name, ev[i].elapsed_time(ev[j]))
+            for name, v in (("syrk_ms", chol.update_ms), ("syrk_flops", chol.update_flops), ("syrk_launches", chol.update_launches),
+                            ("chain_ms", chol.chain_ms), ("gather_wait_ms", chol.wait_ms), ("bytes_received", chol.bytes_received),
+                            ("solves", 1)):
+                self._add(name, v)
+        factor = None
+        if keep:
+            if not o.replicated:
+                raise NotImplementedError("kept-factor calls (posterior covariance, several fields, likelihood gradient) need "
+                                          "the replicated factor, which does not fit on this GPU (or TGP_DIST_REPLICATE=0)")
+            h = C.c_void_p()
+            self._lib.check(self.ctx, self.lib.tgp_factor_borrow(self.ctx, o._p(o.Afull), o._p(o.W), n, C.byref(h)),
+                            "tgp_factor_borrow")
+            factor = _ops.Factor(self.ctx, h, n, keepalive=(o.A, o.Afull, o.W))
+            self._solver = None                              # the buffers now belong to the handle
+        return (a if want_alpha else None), logdet, float(np.dot(y, a)), factor
+
+    def gp_predict(self, spec, X, alpha, Xs):
+        """ys (m,) = k(Xs, X) alpha on every rank: the query points in contiguous shards, one all-gather of the results."""
+        from ._lib import as_xy, f64
+        torch = self.torch
+        G, g = self.comm.size, self.comm.rank
+        X2, Xs2 = as_xy(X), as_xy(Xs)
+        n, m = X2.shape[0], Xs2.shape[0]
+        self.lib.tgp_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        per = -(-m // G)
+        lo, hi = min(g * per, m), min((g + 1) * per, m)
+        mine = torch.zeros(max(per, 1), dtype=torch.float64, device=self.device)
+        if hi > lo:
+            dX = torch.from_numpy(X2).to(self.device)
+            da = torch.from_numpy(f64(alpha)).to(self.device)
+            dXs = torch.from_numpy(np.ascontiguousarray(Xs2[lo:hi])).to(self.device)
+            kc = spec.to_c()
+            rc = self.lib.tgp_d_gp_predict(self.ctx, C.byref(kc), C.c_void_p(dX.data_ptr()), n, C.c_void_p(da.data_ptr()),
+                                           C.c_void_p(dXs.data_ptr()), hi - lo, C.c_void_p(mine.data_ptr()))
+            self._lib.check(self.ctx, rc, "tgp_d_gp_predict")
+            if self.profile:
+                self._add("predict_ms", self._lib.timings(self.ctx)[3])
+                self._add("predict_points", hi - lo)
+        if G == 1:
+            return mine[:m].cpu().numpy()
+        buf = torch.empty(per * G, dtype=torch.float64, device=self.device)
+        self.comm.all_gather(buf, mine)
+        return buf[:m].cpu().numpy()
+
+
+def enable(comm=None, device=None, min_n=None, profile=False, thread_local=False):
+    """Switch the multi-GPU route on for this process (or, ``thread_local``, this thread: the tests' virtual ranks) and
+    shard the pair binning of ``two_pcf`` over the same ranks.  Problems below ``min_n`` training points (default
+    TGP_DIST_MIN_N or 32768) stay on the single-GPU path unless a ``GPInterpolation(backend="dist")`` asks otherwise.
+    Collective: every rank must call it.  Returns the engine (``.acc`` holds phase timings with ``profile=True``)."""
+    global _process_engine
+    from . import ops as _ops
+    eng = DistEngine(comm=comm, device=device, min_n=min_n, profile=profile)
+    if thread_local:
+        _tls.engine = eng
+    else:
+        _process_engine = eng
+    _ops.set_pair_comm(eng.comm)
+    return eng
+
+
+def disable():
+    global _process_engine
+    from . import ops as _ops
+    if getattr(_tls, "engine", None) is not None:
+        _tls.engine = None
+    else:
+        _process_engine = None
+    _ops.set_pair_comm(None)
+
+
+def _current_engine():
+    global _process_engine
+    eng = getattr(_tls, "engine", None) or _process_engine
+    if eng is None and os.environ.get("TGP_DIST") == "1":
+        import sys
+        td = sys.modules.get("torch.distributed")
+        if td is None or not (td.is_available() and td.is_initialized()):
+            raise RuntimeError("TGP_DIST=1 but torch.distributed is not initialised in this process "
+                               "(init_process_group first, or call treegp_amd.dist.enable(comm))")
+        eng = enable()
+    return eng
+
+
+class scope(object):
+    """``with dist.scope("dist")``: every solve inside takes the multi-GPU route whatever its size (an engine must be
+    enabled or torch.distributed initialised); ``"single"``: none does; ``None``: the engine's size threshold decides."""
+
+    def __init__(self, mode):
+        if mode not in (None, "dist", "single"):
+            raise ValueError("backend must be None, 'dist' or 'single'; got %r" % (mode,))
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "mode", None)
+        if self.mode is not None:
+            _tls.mode = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _tls.mode = self.prev
+        return False
+
+
+def engine_for(n):
+    """The engine a solve with n training points should go through, or None for the single-GPU path."""
+    mode = getattr(_tls, "mode", None)
+    if mode == "single":
+        return None
+    if mode == "dist":
+        eng = _current_engine()
+        if eng is None:
+            import sys
+            td = sys.modules.get("torch.distributed")
+            if td is not None and td.is_available() and td.is_initialized():
+                eng = enable()
+            else:
+                raise RuntimeError('backend="dist" needs treegp_amd.dist.enable(comm) or an initialised torch.distributed')
+        return eng
+    eng = _current_engine()
+    return eng if (eng is not None and n >= eng.min_n) else None

@@ -29,11 +29,19 @@ class GPInterpolation(object):
     :param average_fits:  FITS table (meanify output) holding the mean function. [default None]
     :param indice_meanify: column of the mean function to use when it has several.
     :param nbins, min_sep, max_sep: binning of the 2-point correlation function.
+    :param backend:       not in the reference.  None: one GPU, unless the multi-GPU route is enabled
+                          (``treegp_amd.dist.enable()`` or TGP_DIST=1 under ``torchrun``) and the problem is at least its
+                          size threshold; "dist": always the multi-GPU route (row-block-cyclic Cholesky over the ranks of
+                          torch.distributed, query points sharded; every rank makes the same calls with the same data and
+                          gets the same results); "single": always this rank's GPU alone.
     """
 
     def __init__(self, kernel="RBF(1)", optimizer="two-pcf", normalize=True, p0=[3000.0, 0.0, 0.0],
                  white_noise=0.0, n_neighbors=4, average_fits=None, indice_meanify=None, nbins=20,
-                 min_sep=None, max_sep=None):
+                 min_sep=None, max_sep=None, backend=None):
+        if backend not in (None, "dist", "single"):
+            raise ValueError("backend must be None, 'dist' or 'single'. Current value: %s" % (backend,))
+        self.backend = backend
         self.normalize, self.optimizer, self.white_noise = normalize, optimizer, white_noise
         self.n_neighbors, self.indice_meanify = n_neighbors, indice_meanify
         self.nbins, self.min_sep, self.max_sep = nbins, min_sep, max_sep
@@ -55,6 +63,14 @@ class GPInterpolation(object):
             self._X0, self._y0 = table["COORDS0"], table["PARAMS0"]
         self._alpha = None
         self._factor = self._factor_key = None
+
+    def _scope(self):
+        """the backend choice of this object, in force for the solves made inside (treegp_amd.dist.scope)"""
+        if self.backend is None:
+            import contextlib
+            return contextlib.nullcontext()
+        from . import dist
+        return dist.scope(self.backend)
 
     # -- hyper-parameter fit ---------------------------------------------------------------------
     def _fit(self, kernel, X, y, y_err):
@@ -98,8 +114,9 @@ class GPInterpolation(object):
         """Interpolated values (and optionally the posterior covariance) at X (n_samples, 1 or 2).
         gp_interp.py:143-166: the GP acts on y - mean - mean function; both are added back."""
         residual = self._y - self._mean - self._spatial_average
-        y_star, y_cov = self.return_gp_predict(residual, self._X, X, self.kernel, y_err=self._y_err,
-                                               return_cov=return_cov)
+        with self._scope():
+            y_star, y_cov = self.return_gp_predict(residual, self._X, X, self.kernel, y_err=self._y_err,
+                                                   return_cov=return_cov)
         y_star = y_star + (self._mean + self._build_average_meanify(X))
         return (y_star, y_cov) if return_cov else y_star
 
@@ -171,18 +188,19 @@ class GPInterpolation(object):
             spec = kernel_to_spec(self.kernel)
         except NotImplementedError:
             spec = None
-        if spec is not None:
-            _, _, _, factor = ops.gp_solve(spec, self._X, R[0], sigma, keep=True, want_alpha=False)
-        else:
-            _, _, _, factor = ops.gp_solve_dense(self.kernel(self._X), R[0], sigma, keep=True, want_alpha=False)
-        try:
-            alphas = ops.factor_solve(factor, R)
-        finally:
-            factor.free()
-        if spec is not None:
-            pred = np.stack([ops.gp_predict(spec, self._X, a, X) for a in alphas])
-        else:
-            pred = alphas.dot(self.kernel(X, Y=self._X).T)
+        with self._scope():
+            if spec is not None:
+                _, _, _, factor = ops.gp_solve(spec, self._X, R[0], sigma, keep=True, want_alpha=False)
+            else:
+                _, _, _, factor = ops.gp_solve_dense(self.kernel(self._X), R[0], sigma, keep=True, want_alpha=False)
+            try:
+                alphas = ops.factor_solve(factor, R)
+            finally:
+                factor.free()
+            if spec is not None:
+                pred = np.stack([ops.gp_predict(spec, self._X, a, X) for a in alphas])
+            else:
+                pred = alphas.dot(self.kernel(X, Y=self._X).T)
         return pred + means[:, None] + self._build_average_meanify(X)[None, :]
 
     # -- data ------------------------------------------------------------------------------------
@@ -227,7 +245,8 @@ class GPInterpolation(object):
         """Fit the hyper-parameters if an optimizer was requested (gp_interp.py:245-258); the starting theta
         is kept in ``_init_theta``."""
         self._init_theta = [copy.deepcopy(self.kernel).theta]
-        self.kernel = self._fit(self.kernel, self._X, self._residual(), self._y_err)
+        with self._scope():
+            self.kernel = self._fit(self.kernel, self._X, self._residual(), self._y_err)
 
     def return_2pcf(self):
         """xi, xi_weight, distance, coord, mask of the measured 2-point correlation function
@@ -243,7 +262,8 @@ class GPInterpolation(object):
         kernel = copy.deepcopy(self.kernel)
         if theta is not None:
             kernel = kernel.clone_with_theta(theta)
-        return log_likelihood(self._X, self._residual(), self._y_err).log_likelihood(kernel)
+        with self._scope():
+            return log_likelihood(self._X, self._residual(), self._y_err).log_likelihood(kernel)
 
     def plot_fitted_kernel(self):
         raise NotImplementedError("plotting (treegp/gp_interp.py:293-377) is outside the GPU hot path")

@@ -43,7 +43,10 @@ class log_likelihood(object):
     def __init__(self, X, y, y_err):
         self.X, self.y, self.y_err = X, y, y_err
         self.ndata = len(X[:, 0])
-        self.parallel_fd = os.environ.get("TGP_ML_PARALLEL", "1") != "0" and self.ndata <= _PARALLEL_MAX_N
+        # the multi-GPU route (treegp_amd.dist) takes every evaluation by itself: all ranks factorise one K together
+        self.distributed = ops._dist_engine(self.ndata, None) is not None
+        self.parallel_fd = (os.environ.get("TGP_ML_PARALLEL", "1") != "0" and self.ndata <= _PARALLEL_MAX_N
+                            and not self.distributed)
         # "fd": the reference's fit (SciPy differentiates numerically, log_likelihood.py:57).  "analytic": L-BFGS-B is given
         # the exact gradient instead (log_likelihood_gradient; Gaussian kernels only) -- a different path through theta-space
         # to the same optimum.  "auto" (default): finite differences, the reference's iterates, wherever their ntheta + 1
@@ -100,7 +103,9 @@ class log_likelihood(object):
         """L-BFGS-B on -log L over theta (log_likelihood.py:43-62)."""
         template = kernel
         # X, y, y_err do not change during the fit: they go to the device once, every evaluation sends only theta
-        resident = ops.ResidentProblem(self.X, self.y, self.y_err) if os.environ.get("TGP_ML_RESIDENT", "1") != "0" else None
+        resident = None
+        if os.environ.get("TGP_ML_RESIDENT", "1") != "0" and not self.distributed:
+            resident = ops.ResidentProblem(self.X, self.y, self.y_err)
 
         def cost(theta, ctx=None, work=None):
             # `work`: a kernel object owned by this evaluation slot whose theta is set in place -- what clone_with_theta
@@ -134,7 +139,8 @@ class log_likelihood(object):
                 raise NotImplementedError("TGP_ML_GRADIENT=analytic: %r has no analytic derivative (Gaussian kernels only, as in "
                                           "the reference: treegp/kernels.py:128-150)" % (template,))
             return True
-        return gaussian and self.ndata > _PARALLEL_MAX_N
+        # (on the multi-GPU route K^-1 would be formed by every rank on its replicated factor: not a saving there)
+        return gaussian and self.ndata > _PARALLEL_MAX_N and not self.distributed
 
     def _minimise(self, cost, template, resident=None):
         if self._use_exact_gradient(template):

@@ -5,7 +5,7 @@ A kernel is described by ``KernelSpec`` -- the plain numbers the device needs --
 ``treegp_amd.kernels.kernel_to_spec`` derives from a scikit-learn kernel object.
 """
 import ctypes as C
-
+import os
 import threading
 
 import numpy as np
@@ -30,13 +30,15 @@ class KernelSpec(object):
 class Factor(object):
     """Device-resident Cholesky factor handle (tgp_factor*), freed with the object."""
 
-    def __init__(self, ctx, handle, n):
+    def __init__(self, ctx, handle, n, keepalive=None):
         self._ctx, self._h, self.n = ctx, handle, n
+        self._keepalive = keepalive          # a borrowed handle (tgp_factor_borrow): the tensors that own its memory
 
     def free(self):
         if self._h:
             _lib.load_library().tgp_factor_free(self._ctx, self._h)
             self._h = None
+        self._keepalive = None
 
     def __del__(self):
         try:
@@ -64,10 +66,27 @@ def kernel_matrix(spec, X, Y=None, ctx=None):
     return out
 
 
+def _dist_engine(n, ctx):
+    """The multi-GPU engine this call should go through (treegp_amd.dist.enable / TGP_DIST=1 / backend="dist"), or None.
+    A caller that names its own context stays on that context's GPU."""
+    if ctx is not None:
+        return None
+    import sys
+    d = sys.modules.get("treegp_amd.dist")
+    if d is None:
+        if os.environ.get("TGP_DIST") != "1":
+            return None
+        from . import dist as d
+    return d.engine_for(n)
+
+
 def gp_solve(spec, X, y, y_err=None, keep=False, want_alpha=True, ctx=None):
     """(alpha, logdet, y.alpha, factor|None) for K = amp k(X) + diag(y_err^2).
     Raises numpy.linalg.LinAlgError when K is not positive definite, as scipy.linalg.cholesky
     does at treegp/gp_interp.py:181."""
+    eng = _dist_engine(len(X), ctx)
+    if eng is not None:
+        return eng.gp_solve(spec, X, y, y_err, keep=keep, want_alpha=want_alpha)
     ctx = ctx or _lib.get_ctx()
     lib = _lib.load_library()
     X2 = as_xy(X)
@@ -199,6 +218,9 @@ def gp_solve_grad_resident(spec, problem, ctx=None):
 
 def gp_predict(spec, X, alpha, Xs, ctx=None):
     """ys = k(Xs, X) @ alpha without materialising the cross kernel (gp_interp.py:177,183)."""
+    eng = _dist_engine(len(X), ctx)
+    if eng is not None:
+        return eng.gp_predict(spec, X, alpha, Xs)
     ctx = ctx or _lib.get_ctx()
     lib = _lib.load_library()
     X2, Xs2 = as_xy(X), as_xy(Xs)
@@ -211,7 +233,7 @@ def gp_predict(spec, X, alpha, Xs, ctx=None):
 
 def gp_predict_cov(spec, factor, X, Xs, ctx=None):
     """Posterior covariance k(Xs,Xs) - HT K^-1 HT^T (gp_interp.py:184-192) from a kept factor."""
-    ctx = ctx or _lib.get_ctx()
+    ctx = ctx or factor._ctx
     lib = _lib.load_library()
     X2, Xs2 = as_xy(X), as_xy(Xs)
     m = Xs2.shape[0]
@@ -225,7 +247,7 @@ def gp_loglik_grad(spec, factor, X, alpha, ctx=None):
     """1/2 sum_ij (alpha_i alpha_j - [K^-1]_ij) dK_ij/dp for p = (log amp, a, b, c), from the factor and alpha of one
     ``gp_solve(..., keep=True)`` (include/tgp.h, seam S2d).  Gaussian kernels only; ``kernels.spec_jacobian`` maps the four
     numbers to d logL / d theta."""
-    ctx = ctx or _lib.get_ctx()
+    ctx = ctx or factor._ctx
     lib = _lib.load_library()
     X2 = as_xy(X)
     alpha = f64(alpha)

@@ -34,3 +34,29 @@ def star_field(n, m, seed=20240613, noise=0.03, nmodes=8):
 def headline_invlam():
     """invLam of the headline kernel 1.0**2 * AnisotropicRBF(inv(L(0.05, 0.2, 0.1)))."""
     return np.linalg.inv(correlation_length_matrix(0.05, 0.2, 0.1))
+
+
+HEADLINE_KERNEL = "1.0**2 * AnisotropicRBF(invLam=array(%r))"
+
+
+def headline_kernel_string():
+    """The headline kernel as the string ``GPInterpolation(kernel=...)`` takes."""
+    return HEADLINE_KERNEL % (headline_invlam().tolist(),)
+
+
+def mean_table(side=50):
+    """configs[4]'s mean function: X0 = side x side grid of bin centres on the unit square, y0 = 0.02 + 0.2 r^2
+    from the centre -- the (COORDS0, PARAMS0) content of a meanify file (treegp/meanify.py:139-165)."""
+    c = (np.arange(side) + 0.5) / side
+    u, v = np.meshgrid(c, c)
+    X0 = np.column_stack([u.ravel(), v.ravel()])
+    y0 = 0.02 + 0.2 * ((X0[:, 0] - 0.5) ** 2 + (X0[:, 1] - 0.5) ** 2)
+    return X0, y0
+
+
+def star_field_with_mean(n, m, seed=20240613, noise=0.03):
+    """configs[4]'s data: the star field plus the smooth mean function evaluated at the stars.  Returns X, y, y_err, Xs, X0, y0."""
+    X, y, y_err, Xs = star_field(n, m, seed=seed, noise=noise)
+    X0, y0 = mean_table()
+    y = y + 0.02 + 0.2 * ((X[:, 0] - 0.5) ** 2 + (X[:, 1] - 0.5) ** 2)
+    return X, y, y_err, Xs, X0, y0
