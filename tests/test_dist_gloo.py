@@ -18,9 +18,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, out_dir):
+def _worker(rank, world, port, n, out_dir, group=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if group is not None:
+        os.environ["TGP_DIST_GROUP"] = str(group)
+    torch.set_num_threads(1)
+    lean = group is not None                 # the many-rank cases: one pass with the replicated factor, no side checks
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import sys
@@ -34,16 +38,21 @@ def _worker(rank, world, port, n, out_dir):
         y = rng.standard_normal(n)
         comm = TorchComm()
         ref = np.linalg.solve(K, y)
-        for replicated in (False, True):          # distributed sweeps / sweeps on the replicated factor
+        for replicated in ((True,) if lean else (False, True)):          # distributed sweeps / sweeps on the replicated factor
             ops = NumpyLocalOps(K, n, world, rank, replicated=replicated)
             ch = DistributedCholesky(ops, comm)
+            assert group is None or ch.group == group
             assert ch.factorize() == 0
+            assert world == 1 or ch.bytes_received > 0
             ypad = torch.zeros(ops.Np, dtype=torch.float64)
             ypad[:n] = torch.from_numpy(y)
             alpha = ch.solve(ypad).numpy()[:n]
             logdet = float(ch.logdet()[0])
             np.testing.assert_allclose(alpha, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
             np.testing.assert_allclose(logdet, np.linalg.slogdet(K)[1], rtol=1e-11)
+        if lean:
+            open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+            return
         # the replicate decision is a collective one: rank 0's environment setting wins over the others',
         # and one rank without room for the copy makes every rank fall back to the distributed sweeps
         from treegp_amd.dist import agree_replicate
@@ -64,9 +73,23 @@ def _worker(rank, world, port, n, out_dir):
         dist.destroy_process_group()
 
 
+@pytest.fixture(autouse=True)
+def _one_blas_thread_per_rank(monkeypatch):
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        monkeypatch.setenv(var, "1")         # the ranks share this box's few CPUs: one BLAS thread each
+
+
 @pytest.mark.parametrize("world,n", [(2, 1100), (3, 1300)])
 def test_distributed_cholesky_gloo(tmp_path, world, n):
     mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
+
+
+@pytest.mark.parametrize("world,n,group", [(4, 1900, 4), (8, 2100, 4)])
+def test_distributed_cholesky_gloo_groups_of_four(tmp_path, world, n, group):
+    """the schedule the headline size runs (groups of four panels, look-ahead, replicated factor) with 4 and 8 REAL
+    processes: more ranks than panels per group, ranks that own no block of a group, a short last group"""
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path), group), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
 
 
