@@ -196,6 +196,7 @@ int tgp_h2d(tgp_ctx *ctx, void *d_dst, const void *src, int64_t bytes);
 int tgp_d2h(tgp_ctx *ctx, void *dst, const void *d_src, int64_t bytes);
 int tgp_sync(tgp_ctx *ctx);
 void *tgp_stream(tgp_ctx *ctx);          /* the hipStream_t every kernel is launched on */
+int tgp_mem_info(tgp_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);   /* device memory of the context's GPU */
 
 /* d_X (n,2), d_y, d_yerr, d_alpha (n): resident inputs/outputs */
 int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,

@@ -66,3 +66,25 @@ def test_error_codes_do_not_poison_the_context():
     X = rng.uniform(0, 1, (50, 2))
     alpha, _, _, _ = ops.gp_solve(spec, X, rng.standard_normal(50), 0.1 * np.ones(50))
     assert np.all(np.isfinite(alpha))
+
+
+@pytest.mark.parametrize("n", [300, 3000])
+def test_nan_coordinate_or_parameter_is_not_positive_definite(n):
+    """A NaN coordinate (or NaN invLam) must poison K and stop the factorisation -- scipy.linalg.cholesky's check_finite
+    raises at treegp/gp_interp.py:181 -- instead of silently counting the point as uncorrelated (the clamp of
+    the K build's exponential dropped NaN); a wildly indefinite invLam must not wrap the exponent field into garbage."""
+    _lib, ops, spec = _spec()
+    rng = np.random.default_rng(n)
+    X = rng.uniform(0, 1, (n, 2)); y = rng.standard_normal(n); e = rng.uniform(0.05, 0.2, n)
+    Xn = X.copy()
+    Xn[n // 2, 1] = np.nan
+    with pytest.raises(np.linalg.LinAlgError):
+        ops.gp_solve(spec, Xn, y, e)
+    with pytest.raises(np.linalg.LinAlgError):
+        ops.gp_solve(ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=np.nan, b=0.0, c=1.0), X, y, e)
+    with pytest.raises(np.linalg.LinAlgError):
+        ops.gp_solve(ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=-1e6, b=0.0, c=-1e6), X, y, e)
+    K = ops.kernel_matrix(spec, Xn[:64])
+    assert np.isnan(K[n // 2 if n // 2 < 64 else 0]).any() or n // 2 >= 64
+    alpha, _, _, _ = ops.gp_solve(spec, X, y, e)                  # and the context is fine afterwards
+    assert np.isfinite(alpha).all()

@@ -1,28 +1,47 @@
 #!/usr/bin/env python3
-"""List the dispatches of the LAST of `reps` identical runs in a rocprofv3 results .db (kernel trace): start (us), duration,
-stream, workgroups, kernel.  usage: trace_list.py results.db [reps=3] [first] [count]"""
+"""List the dispatches of the LAST solve in a `rocprofv3 --kernel-trace --output-format csv` run of tools/one_solve.py:
+start (us, from the first dispatch of that solve), duration, stream/queue, workgroups, kernel -- and per-kernel totals.
+usage: trace_list.py <dir with *kernel_trace.csv> [max lines]"""
+import csv
+import glob
 import re
-import sqlite3
 import sys
+from collections import defaultdict
 
-
-def main():
-    c = sqlite3.connect(sys.argv[1])
-    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    count = int(sys.argv[4]) if len(sys.argv) > 4 else 100
-    rows = c.execute("select name,start,end,stream_id,grid_x,workgroup_x from kernels order by start").fetchall()
-    n = len(rows) // reps
-    last = rows[(reps - 1) * n:]
-    t0 = last[0][1]
-
-    def short(nm):
-        m = re.search(r"(\w+)(<[^(]*>)?\(", nm)
-        return (m.group(1) + (m.group(2) or ""))[:44] if m else nm[:44]
-    print("run of %d dispatches, span %.3f ms" % (len(last), (max(r[2] for r in last) - t0) / 1e6))
-    for name, s, e, st, gx, wx in last[first:first + count]:
-        print("%9.1f  %7.1f us  s%d  wg %6d  %s" % ((s - t0) / 1e3, (e - s) / 1e3, st, gx // wx, short(name)))
-
-
-if __name__ == "__main__":
-    main()
+files = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)
+rows = []
+for fn in files:
+    for r in csv.DictReader(open(fn)):
+        name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+        name = re.sub(r"^void ", "", name).split("(")[0]
+        name = re.sub(r"potrf_v2::", "", name)
+        wg = 1
+        for ax in "XYZ":
+            g, w = int(r.get("Grid_Size_" + ax, 1) or 1), int(r.get("Workgroup_Size_" + ax, 1) or 1)
+            wg *= max(g // max(w, 1), 1)
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Stream_Id") or r.get("Queue_Id"), wg, name))
+rows.sort()
+# solves are separated by host round trips: split at gaps > 300 us and keep the last run with more than 50 dispatches
+runs, cur = [], [rows[0]]
+for a, b in zip(rows, rows[1:]):
+    if b[0] - a[1] > 300000:
+        runs.append(cur)
+        cur = []
+    cur.append(b)
+runs.append(cur)
+big = [r for r in runs if len(r) > 50]
+run = big[-1] if big else runs[-1]
+t0 = run[0][0]
+print("# run of %d dispatches, span %.3f ms" % (len(run), (run[-1][1] - t0) / 1e6))
+streams = {}
+limit = int(sys.argv[2]) if len(sys.argv) > 2 else 10 ** 9
+tot = defaultdict(lambda: [0, 0.0])
+for i, (s, e, q, wg, name) in enumerate(run):
+    sid = streams.setdefault(q, "s%d" % (len(streams) + 1))
+    tot[name][0] += 1
+    tot[name][1] += (e - s) / 1e3
+    if i < limit:
+        print("%9.1f %8.1f us  %s  wg %6d  %s" % ((s - t0) / 1e3, (e - s) / 1e3, sid, wg, name))
+print("# totals (us) of that run")
+for name, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+    print("# %8.1f us  %4d x  %s" % (us, c, name))

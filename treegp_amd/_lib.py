@@ -54,6 +54,7 @@ SIGNATURES = {
     "tgp_d2h": (C.c_int, [_vp, _vp, _vp, _i64]),
     "tgp_sync": (C.c_int, [_vp]),
     "tgp_stream": (_vp, [_vp]),
+    "tgp_mem_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "tgp_d_gp_solve": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp, _vp, _dp, _dp, C.POINTER(_vp)]),
     "tgp_d_gp_predict": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp, _i64, _vp]),
     "tgp_panel_off": (_i64, [_i64, _i64]),

@@ -55,6 +55,15 @@ int tgp_ensure_side_stream(tgp_ctx *ctx) {
     return 0;
 }
 
+int tgp_ensure_rest_stream(tgp_ctx *ctx) {
+    if (ctx->rest_stream) return 0;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    TGP_HIP(hipStreamCreateWithPriority(&ctx->rest_stream, hipStreamNonBlocking, hi));
+    for (auto &e : ctx->ev_df) TGP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return 0;
+}
+
 int tgp_ensure_scratch2(tgp_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->scratch2_bytes) return 0;
     if (ctx->scratch2) TGP_HIP(hipFree(ctx->scratch2));
@@ -161,6 +170,9 @@ void tgp_destroy(tgp_ctx *ctx) {
     for (auto &ev : ctx->prof_events) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->rest_stream) (void)hipStreamDestroy(ctx->rest_stream);
+    for (auto &ev : ctx->ev_df)
+        if (ev) (void)hipEventDestroy(ev);
     delete static_cast<tgp_ctx_full *>(ctx);
 }
 
@@ -214,6 +226,15 @@ int tgp_sync(tgp_ctx *ctx) {
     return 0;
 }
 void *tgp_stream(tgp_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int tgp_mem_info(tgp_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes) {
+    TGP_ARG(free_bytes && total_bytes);
+    TGP_HIP(hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    TGP_HIP(hipMemGetInfo(&f, &t));
+    *free_bytes = (int64_t)f;
+    *total_bytes = (int64_t)t;
+    return 0;
+}
 
 // ---- building blocks ---------------------------------------------------------------------
 int tgp_d_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_yerr,

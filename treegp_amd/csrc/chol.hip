@@ -66,6 +66,18 @@ __global__ __launch_bounds__(256, 2) void panel_tall_kernel(double *rows0, const
     gemm_tile_128<0, TGP_TB, TGP_TB>(rows + TGP_TB, W1, rows + TGP_TB);
 }
 
+// The same on the latency tile: 16-row slices, eight workgroups per 128 rows (the diagonal-first schedule's rows below the
+// next diagonal block, when a panel has only a few dozen tiles and the chip is otherwise idle).
+__global__ __launch_bounds__(256) void panel_tall_small_kernel(double *rows0, const double *W0, const double *L10, const double *W1) {
+    double *rows = rows0 + (int64_t)blockIdx.x * 16 * TGP_PW;
+    TGP_CHAIN_PRIO();
+    nt_small_tile<0, TGP_TB, 1>(rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
+    __syncthreads();
+    nt_small_tile<1, TGP_TB, 1>(rows, TGP_PW, L10, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
+    __syncthreads();
+    nt_small_tile<0, TGP_TB, 1>(rows + TGP_TB, TGP_PW, W1, TGP_TB, rows + TGP_TB, TGP_PW, nullptr, nullptr);
+}
+
 // rows 128..255 of a 256 x 256 diagonal block between its two potrf128 calls, one workgroup, one launch:
 // L10 = A10 W0^T, then A11 -= L10 L10^T
 __global__ __launch_bounds__(256, 2) void diag_mid_kernel(double *R1, const double *W0) {
@@ -162,10 +174,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void syrk_dtv_kernel(doub
 // way (twice the workgroups, still at most two rounds up to T = 128) the panel chain waits about half as long for it.
 template <int NSEG>
 __global__ __launch_bounds__(256, 2) void syrk_strip64_kernel(double *Abase, int64_t Np, int ob, int T, int strip, const double *P0,
-                                                              const double *P1) {
+                                                              const double *P1, int ti_min = 0) {
     const int tj = (int)(blockIdx.x % strip);        // 128-column tile
-    const int th = (int)(blockIdx.x / strip);        // 64-row half tile
-    const int ti = th >> 1;
+    const int th = (int)(blockIdx.x / strip) + 2 * ti_min;        // 64-row half tile (ti_min: skip the first tile rows -- the
+    const int ti = th >> 1;                                       // diagonal block somebody else updates)
     if (ti < tj || ti >= T) return;
     TGP_CHAIN_PRIO();
     const int64_t pj = ob + (tj >> 1);
@@ -587,6 +599,122 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     int nqueue = 0;
     if (Np / TGP_TB - 8 > small_t_pairs)      // some step can take the queued form (T3 = Np/128 - 8 at the first pair)
         TGP_HIP(hipMemsetAsync(ctx->d_queue, 0, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned), st));
+    // ---- diagonal-first schedule (chain-bound steps: TGP_CHOL_MODE=4, and the tail of the pair-wise schedule) ----------
+    // What the next diagonal block needs is taken out of everything else.  Three streams:
+    //   C  (side stream, high priority): the critical chain of panel k -- potrf128 of tile (0,0); the two products of its
+    //      column-half update on rows 128..511 only (the second diagonal tile and the rows of the NEXT diagonal block);
+    //      potrf128 of tile (1,1); X = R W1^T on the next block's 256 rows; the depth-256 update of the next diagonal block
+    //      with those rows.  Sixteen-row slices throughout (8 - 32 workgroups per launch).
+    //   R1 (rest stream): the other rows of panel k (one fused launch) and the update of panel k+1's columns below its
+    //      diagonal block (needed by the chain one cycle later).
+    //   B  (main stream): panel k's update of block column k+2, then of everything right of it.
+    // Per 256 columns the chain is ~125 us instead of ~230 us in the pair-wise schedule, where every panel GEMM runs over
+    // all rows and both strip updates sit on the chain (rocprofv3 trace at N = 8192, profiles/r03_trace_n8192_*).
+    // Entry state: every panel < kstart applied to everything, all work joined into the main stream.
+    static const int df_small_tall = [] { const char *e = getenv("TGP_DF_SMALL_TALL"); return e ? atoi(e) : 48; }();
+    auto run_diagfirst = [&](int kstart) -> int {
+        int rc = tgp_ensure_rest_stream(ctx);
+        if (rc) return rc;
+        hipStream_t sc = ctx->side_stream, sr = ctx->rest_stream;
+        hipEvent_t evP2 = ctx->ev_df[0], evTn = ctx->ev_df[1], evTr = ctx->ev_df[2], evUa1 = ctx->ev_df[3], evFar = ctx->ev_df[4],
+                   evJoin = ctx->ev_df[5];
+        TGP_HIP(hipEventRecord(evJoin, st));
+        TGP_HIP(hipStreamWaitEvent(sc, evJoin, 0));
+        TGP_HIP(hipStreamWaitEvent(sr, evJoin, 0));
+        bool have_prev = false;
+        for (int k = kstart; k < nP; ++k) {
+            const int64_t mk = Np - (int64_t)TGP_PW * k;
+            double *Pk = panel(k), *W0 = Wk(k), *W1 = W0 + TGP_TB * TGP_TB;
+            const int T = (int)((mk - TGP_PW) / TGP_TB);             // tile rows from block k+1 on
+            const int Tb = T - 4;                                      // tile rows of the bulk update (from block k+3)
+            const bool queued = Tb <= queue_t && Tb > small_t_pairs && nqueue < TGP_NQUEUE;
+            const bool excl = queued || T <= 4;                        // free compute units are guaranteed
+            if (mk == TGP_PW) {                                        // last panel: nothing below, nothing to the right
+                if (have_prev) TGP_HIP(hipStreamWaitEvent(sc, evUa1, 0));
+                factor_panel(sc, Pk, mk, W0, ctx->d_info, k * TGP_PW, excl, n_data);
+                break;
+            }
+            double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                // row 128 of the panel
+            double *Rn = Pk + (int64_t)TGP_PW * TGP_PW;                // row 256: the next diagonal block's rows
+            // ---- C: the critical chain
+            run_potrf128(sc, Pk, TGP_PW, W0, ctx->d_info, k * TGP_PW, excl);
+            if (have_prev) TGP_HIP(hipStreamWaitEvent(sc, evUa1, 0));   // panel k-1 applied to the rows below this diagonal block
+            gemm_col_small_kernel<0, TGP_TB><<<24, 256, 0, sc>>>(R1, W0, R1);              // rows 128..511: X0 = R0 W0^T
+            TGP_HIP(hipEventRecord(evP2, sc));                          // ("evM0": W0 and L10 are final)
+            gemm_col_small_kernel<1, TGP_PW><<<24, 256, 0, sc>>>(R1, R1, R1 + TGP_TB);     //                R1 -= X0 X0d^T
+            run_potrf128(sc, R1 + TGP_TB, TGP_PW, W1, ctx->d_info, k * TGP_PW + TGP_TB, excl);
+            gemm_col_small_kernel<0, TGP_TB><<<16, 256, 0, sc>>>(Rn + TGP_TB, W1, Rn + TGP_TB);   // next block's rows: X1 = R1 W1^T
+            TGP_HIP(hipEventRecord(evTn, sc));
+            // ---- R1: the rows below the next diagonal block: the two products that need only W0 and L10 start under the
+            // chain's second diagonal tile, the third (W1) follows it
+            TGP_HIP(hipStreamWaitEvent(sr, evP2, 0));
+            const int ntail = T - 2;                                   // 128-row tiles from block k+2 on
+            double *Rt = Pk + (int64_t)2 * TGP_PW * TGP_PW;
+            if (ntail > 0) {
+                if (ntail <= df_small_tall) {
+                    gemm_col_small_kernel<0, TGP_TB><<<ntail * 8, 256, 0, sr>>>(Rt, W0, Rt);
+                    gemm_col_small_kernel<1, TGP_PW><<<ntail * 8, 256, 0, sr>>>(Rt, R1, Rt + TGP_TB);
+                } else {
+                    gemm_col_kernel<0, TGP_TB><<<ntail, 256, 0, sr>>>(Rt, W0, Rt);
+                    gemm_col_kernel<1, TGP_PW><<<ntail, 256, 0, sr>>>(Rt, R1, Rt + TGP_TB);
+                }
+            }
+            TGP_HIP(hipStreamWaitEvent(sr, evTn, 0));
+            if (ntail > 0) {
+                if (ntail <= df_small_tall) gemm_col_small_kernel<0, TGP_TB><<<ntail * 8, 256, 0, sr>>>(Rt + TGP_TB, W1, Rt + TGP_TB);
+                else gemm_col_kernel<0, TGP_TB><<<ntail, 256, 0, sr>>>(Rt + TGP_TB, W1, Rt + TGP_TB);
+            }
+            TGP_HIP(hipEventRecord(evTr, sr));
+            // ---- B: block column k+2 first (the chain needs it one cycle from now), then the bulk
+            const double *P0 = Rn;                                     // panel k's row of the first trailing row
+            TGP_HIP(hipStreamWaitEvent(st, evTr, 0));
+            if (T > 2) {
+                const int Tf = T - 2;
+                const double *Pf = P0 + (int64_t)2 * TGP_TB * TGP_PW;
+                const int strip = Tf < 2 ? Tf : 2;
+                syrk_strip64_kernel<1><<<(unsigned)((int64_t)2 * Tf * strip), 256, 0, st>>>(d_A, Np, k + 2, Tf, strip, Pf, nullptr);
+            }
+            // ---- R1: panel k+1's columns below its diagonal block (the previous panel's far strip touched them last)
+            if (have_prev) TGP_HIP(hipStreamWaitEvent(sr, evFar, 0));
+            if (T > 2) syrk_strip64_kernel<1><<<(unsigned)((int64_t)2 * (T - 2) * 2), 256, 0, sr>>>(d_A, Np, k + 1, T, 2, P0, nullptr, 2);
+            // ---- C: the next diagonal block (panel k-1's far strip touched it last)
+            if (have_prev) TGP_HIP(hipStreamWaitEvent(sc, evFar, 0));
+            syrk_small_kernel<1><<<dim3(16u, 2u), 256, 0, sc>>>(d_A, Np, k + 1, 2, P0, nullptr);
+            TGP_HIP(hipEventRecord(evUa1, sr));
+            TGP_HIP(hipEventRecord(evFar, st));
+            if (Tb > 0) {
+                const double m = (double)Tb * TGP_TB;
+                const double *Pb = P0 + (int64_t)4 * TGP_TB * TGP_PW;
+                rc = timed([&] {
+                    if (queued) {
+                        int nres = 1;
+                        if (queue_res > 0) {
+                            nres = queue_res > 3 ? 3 : queue_res;
+                        } else {
+                            const int64_t tiles = (int64_t)Tb * (Tb + 1) / 2;
+                            for (int r = 3; r > 1; --r) {
+                                const int64_t slots = 512 - 64 * r;
+                                if ((tiles + slots - 1) / slots * 65 <= 250) { nres = r; break; }
+                            }
+                        }
+                        syrk_dtv_queue_kernel<1><<<512 + 8, 256, 0, st>>>(d_A, Np, k + 3, Tb, (unsigned)(tilemap_grid(Tb) / 8), nres,
+                                                                       ctx->d_queue + TGP_QUEUE_WORDS * nqueue, Pb, nullptr);
+                        ++nqueue;
+                    } else {
+                        launch_syrk<1>(st, d_A, Np, k + 3, Tb, 0, Pb, nullptr);
+                    }
+                }, (double)TGP_PW * m * (m + 1.0));
+                if (rc) return rc;
+            }
+            have_prev = true;
+        }
+        TGP_HIP(hipEventRecord(evP2, sc));
+        TGP_HIP(hipEventRecord(evTr, sr));
+        TGP_HIP(hipStreamWaitEvent(st, evP2, 0));
+        TGP_HIP(hipStreamWaitEvent(st, evTr, 0));
+        return 0;
+    };
+    static const int df_t = [] { const char *e = getenv("TGP_DF_T"); return e ? atoi(e) : 0; }();      // hand-over of the pairs (tile rows)
     auto run_pairs = [&](int kstart, bool pairs_from_scratch) -> int {
         hipStream_t sd = ctx->side_stream;
         auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false) {       // F(k), U1(k), F(k+1)
@@ -602,6 +730,11 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             const int T2 = (int)((Np - (int64_t)TGP_PW * (k + 2)) / TGP_TB);       // tiles from block k+2
             const double *P0 = panel(k) + (int64_t)2 * TGP_PW * TGP_PW;
             const double *P1 = panel(k + 1) + (int64_t)TGP_PW * TGP_PW;
+            if (df_t > 0 && T2 <= df_t) {
+                // hand-over: this pair applied to everything right of it in one launch, then the diagonal-first schedule
+                launch_syrk<2>(st, d_A, Np, k + 2, T2, 0, P0, P1);
+                return run_diagfirst(k + 2);
+            }
             {   // U2a: tile columns 0..3 (panels k+2, k+3)
                 const double rows = (double)T2 * TGP_TB, w = (T2 < 4 ? T2 : 4) * (double)TGP_TB;
                 const double elems = w * (rows - w) + w * (w + 1.0) / 2.0;
@@ -750,6 +883,9 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
         }
     } else if (mode == 2) {
         int rc = run_pairs(0, true);
+        if (rc) return rc;
+    } else if (mode == 4) {
+        int rc = run_diagfirst(0);
         if (rc) return rc;
     } else {
         for (int k = 0; k < nP; k += 2) {

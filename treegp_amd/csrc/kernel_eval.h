@@ -46,9 +46,12 @@ __device__ __forceinline__ double tgp_exp2_neg(double s) {     // 2^(-s), s >= 0
     // amplitude).  It was tried in the hope that rint / cvt / ldexp were slow instructions; they are not (the fused predict
     // keeps the textbook form, which is one instruction shorter), so the K build's rate did not move with it either.
     // s is clamped at 1021 so that the result stays a normal number: beyond it the true value is below 4.5e-308 and
-    // 2^-1021 p stands in for it (absolute error < 4.5e-308).
+    // 2^-1021 p stands in for it (absolute error < 4.5e-308).  A negative s (an indefinite invLam) is clamped at -1023: the
+    // exponent-field add below must not run into the infinity / NaN encodings; K then holds numbers of order 1e308 and the
+    // factorisation reports it as not positive definite.  A NaN s (NaN coordinate or parameter) stays NaN -- fmin / fmax
+    // would drop it and the point would silently count as uncorrelated; SciPy's cholesky (check_finite) raises there.
     const double magic = 6755399441055744.0;
-    const double t = -fmin(s, 1021.0);
+    const double t = (s != s) ? s : -fmax(fmin(s, 1021.0), -1023.0);
     const double z = t + magic;
     const double k = z - magic;
     const double f = t - k;
@@ -66,7 +69,7 @@ __device__ __forceinline__ double tgp_exp2_neg(double s) {     // 2^(-s), s >= 0
     p = fma(p, f, 2.4022650695910071233e-1);
     p = fma(p, f, 6.9314718055994530942e-1);
     p = fma(p, f, 1.0);
-    const int ki = __double2loint(z);                       // round(t), -1021 .. 0
+    const int ki = __double2loint(z);                       // round(t), -1021 .. 1023 (t = NaN: p is NaN, whatever ki)
     return __hiloint2double(__double2hiint(p) + (ki << 20), __double2loint(p));
 }
 

@@ -27,6 +27,8 @@ struct tgp_ctx {
     hipStream_t stream = nullptr;      // the stream every kernel is launched on
     hipStream_t own_stream = nullptr;  // created by tgp_init
     hipStream_t side_stream = nullptr; // high-priority stream for the Cholesky look-ahead
+    hipStream_t rest_stream = nullptr; // diagonal-first schedule (chol.hip): the rest of a panel and its near strips
+    hipEvent_t ev_df[8] = {nullptr};   // its cross-stream events (no timing), created with the stream
     bool ext_stream = false;           // stream was set by tgp_set_stream
     std::string err;
     double timings[TGP_NTIMINGS] = {0};
@@ -137,6 +139,7 @@ __host__ __device__ inline void tilemap(int64_t b, int64_t T, int &ti, int &tj) 
 
 // implemented across the .hip files
 int tgp_ensure_side_stream(tgp_ctx *ctx);
+int tgp_ensure_rest_stream(tgp_ctx *ctx);
 int tgp_ensure_scratch(tgp_ctx *ctx, size_t bytes);
 int tgp_ensure_scratch2(tgp_ctx *ctx, size_t bytes);
 int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,

@@ -70,7 +70,9 @@ class log_likelihood(object):
             else:
                 _, log_det, chi2, _ = ops.gp_solve(spec, self.X, self.y, self.y_err, want_alpha=False, ctx=ctx)
             ll = -0.5 * chi2 - (0.5 * self.ndata) * np.log(2.0 * np.pi) - 0.5 * log_det
-        except (np.linalg.LinAlgError, FloatingPointError, ValueError, ops._lib.TgpError):
+        except (np.linalg.LinAlgError, FloatingPointError, ValueError):
+            # the mathematical failures the reference turns into -inf (log_likelihood.py:38-39).  A TgpError -- bad argument,
+            # HIP error, out of device memory -- is NOT one of them: it propagates instead of posing as a bad theta
             ll = -np.inf
         if not np.isfinite(ll):
             ll = -np.inf
@@ -93,8 +95,8 @@ class log_likelihood(object):
                 finally:
                     factor.free()
             ll = -0.5 * chi2 - (0.5 * self.ndata) * np.log(2.0 * np.pi) - 0.5 * log_det
-        except (np.linalg.LinAlgError, FloatingPointError, ValueError, ops._lib.TgpError):
-            return -np.inf, np.zeros(ntheta)
+        except (np.linalg.LinAlgError, FloatingPointError, ValueError):
+            return -np.inf, np.zeros(ntheta)              # TgpError (device / argument errors) propagates, see log_likelihood
         if not np.isfinite(ll):
             return -np.inf, np.zeros(ntheta)
         return ll, jac.dot(g4)
@@ -140,16 +142,49 @@ class log_likelihood(object):
                                           "the reference: treegp/kernels.py:128-150)" % (template,))
             return True
         # (on the multi-GPU route K^-1 would be formed by every rank on its replicated factor: not a saving there)
-        return gaussian and self.ndata > _PARALLEL_MAX_N and not self.distributed
+        return gaussian and self.ndata > _PARALLEL_MAX_N and not self.distributed and self._gradient_fits()
+
+    def _gradient_fits(self):
+        """The device gradient forms K^-1: two Np x Np buffers beside the factor, and its launches index row tiles of a
+        matrix of at most 65535 rows (csrc/cov.hip: cov_plan).  Beyond either limit the fit keeps SciPy's finite differences."""
+        lib = _lib.load_library()
+        Np = int(lib.tgp_padded_n(self.ndata))
+        if Np > 65535:
+            return False
+        need = 8.0 * (2.0 * Np * Np + 2.0 * float(lib.tgp_panel_elems(Np)))
+        import ctypes
+        free, total = ctypes.c_int64(), ctypes.c_int64()
+        if lib.tgp_mem_info(_lib.get_ctx(), ctypes.byref(free), ctypes.byref(total)) != 0:
+            return True
+        return need < 0.9 * free.value
 
     def _minimise(self, cost, template, resident=None):
         if self._use_exact_gradient(template):
             work = template.clone_with_theta(template.theta)
 
+            state = {"exact": True}
+
             def cost_and_gradient(theta):
                 work.theta = theta
-                ll, grad = self.log_likelihood_gradient(work, resident=resident)
-                return -ll, -grad
+                if state["exact"]:
+                    try:
+                        ll, grad = self.log_likelihood_gradient(work, resident=resident)
+                        return -ll, -grad
+                    except ops._lib.TgpError as err:
+                        if self.gradient == "analytic":
+                            raise                         # asked for explicitly: fail loudly
+                        import warnings
+                        warnings.warn("exact likelihood gradient unavailable (%s); continuing with finite differences" % err)
+                        state["exact"] = False
+                # SciPy's forward differences (the reference's scheme), one evaluation after the other
+                f0 = -self.log_likelihood(work, resident=resident)
+                grad = np.zeros(len(theta))
+                for i in range(len(theta)):
+                    shifted = np.array(theta, dtype=float)
+                    shifted[i] += _FD_STEP
+                    work.theta = shifted
+                    grad[i] = (-self.log_likelihood(work, resident=resident) - f0) / (shifted[i] - theta[i])
+                return f0, grad
 
             best = optimize.minimize(cost_and_gradient, template.theta, jac=True, method="L-BFGS-B")["x"]
         elif self.parallel_fd:
