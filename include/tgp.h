@@ -65,8 +65,10 @@ int tgp_device_count(void);
  * [0] K build  [1] Cholesky total  [2] triangular solves  [3] predict  [4] pair binning
  * [5] trailing-update (syrk) kernel time summed  [6] number of trailing-update launches
  * [7] trailing-update flops (sum over launches)  [8] K-build bytes written
- * [9] result transfer of tgp_gp_predict_cov ([3] is then its device compute time)       */
-#define TGP_NTIMINGS 10
+ * [9] result transfer of tgp_gp_predict_cov ([3] is then its device compute time)
+ * [10] triangular sweeps over L inside [2]: 2 = forward + backward, 1 = backward only (the forward substitution
+ *      rode along with the factorisation, inside [1]), 0 = none (likelihood only, right-hand side as a matrix row) */
+#define TGP_NTIMINGS 11
 int tgp_last_timings(tgp_ctx *ctx, double *ms, int n);
 /* when on (default off) the Cholesky brackets every trailing-update launch with events */
 int tgp_set_profiling(tgp_ctx *ctx, int on);

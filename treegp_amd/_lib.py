@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TGP_LIB_PATH") or os.path.join(_HERE, "csrc", "libtgp.so")   # override: A/B builds
 
 TGP_RBF, TGP_ARBF, TGP_VK, TGP_AVK = 0, 1, 2, 3
-NTIMINGS = 10
+NTIMINGS = 11
 
 
 class TgpKernel(C.Structure):

@@ -306,25 +306,67 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
     double *d_A = e->A_cache, *d_W = e->W_cache;
     double *d_b = (double *)ctx->scratch;
     int rc = 0;
+    // The right-hand side rides along with the factorisation (PotrfRider): the inverse slabs of the sweeps and the forward
+    // substitution are done, super-block by super-block, on a third stream while the trailing update runs; what is left
+    // afterwards is the backward sweep -- one read of L instead of two plus the slab build.  A kept factor owns the slabs
+    // that were built on the way (nothing is rebuilt at the first covariance / multi-field / gradient call).
+    static const bool both_sweeps = getenv("TGP_CHI2_BOTH_SWEEPS") != nullptr;      // A/B: y . alpha as before
+    const bool forward_only = d_alpha == nullptr && !both_sweeps;                   // only |L^-1 y|^2 is wanted
+    PotrfRider rider;
+    double *own_slabs = nullptr;          // slabs that will belong to the kept factor
+    int own_S = 0, S = 0;
+    if (!augmented && potrs_big_step(Np, &S)) {
+        rc = tgp_ensure_scratch2(ctx, (size_t)Np * sizeof(double));
+        if (rc) return rc;
+        bool build = false;
+        double *slabs = nullptr;
+        rc = acquire_slabs(ctx, Np, S, keep ? &own_slabs : nullptr, keep ? &own_S : nullptr, &slabs, &build);
+        if (rc) return rc;
+        rc = launch_pad_copy(ctx, d_y, n, Np, d_b);
+        if (rc) return rc;
+        rider.d_b = d_b;
+        rider.d_z = (double *)ctx->scratch2;
+        rider.slabs = slabs;
+        rider.S = S;
+    }
+    auto fail = [&](int code) {
+        if (own_slabs) (void)hipFree(own_slabs);
+        return code;
+    };
     // The solves are queued behind the factorisation without waiting for its verdict (one host round trip less per
     // likelihood evaluation); if a pivot failed they run on a meaningless factor and their result is discarded below.
-    int info = launch_potrf(ctx, d_A, Np, d_W, /*defer_info=*/true, /*n_data=*/n);
-    if (info < 0) return info;
+    int info = launch_potrf(ctx, d_A, Np, d_W, /*defer_info=*/true, /*n_data=*/n, rider.slabs ? &rider : nullptr);
+    if (info < 0) return fail(info);
     TGP_HIP(hipEventRecord(ctx->ev[2], st));
+    double sweeps = 0.0;
     if (info == 0 && augmented) {
         rc = launch_logdet_rowsq(ctx, d_A, Np, n, ctx->d_scal);
-        if (rc) return rc;
+        if (rc) return fail(rc);
+        TGP_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    } else if (info == 0 && rider.active) {
+        double *d_z = rider.d_z;
+        if (!forward_only) {
+            rc = launch_potrs_big_bwd(ctx, d_A, Np, S, rider.slabs, d_b, d_z);      // alpha = L^-T z
+            if (rc) return fail(rc);
+            sweeps = 1.0;
+        }
+        rc = launch_logdet_dot(ctx, d_A, Np, n, forward_only ? d_z : d_y, forward_only ? d_z : d_b, ctx->d_scal);
+        if (rc) return fail(rc);
+        if (d_alpha) TGP_HIP(hipMemcpyAsync(d_alpha, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
         TGP_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     } else if (info == 0) {
         rc = launch_pad_copy(ctx, d_y, n, Np, d_b);
-        if (rc) return rc;
+        if (rc) return fail(rc);
+        if (own_slabs) {                  // allocated above for the rider, which this schedule did not carry: build them here
+            rc = launch_vslab_build(ctx, d_A, d_W, Np, own_S, own_slabs);
+            if (rc) return fail(rc);
+        }
         // without alpha only the quadratic form is wanted: y^T K^-1 y = |L^-1 y|^2, the forward sweep alone
-        static const bool both_sweeps = getenv("TGP_CHI2_BOTH_SWEEPS") != nullptr;      // A/B: y . alpha as before
-        const bool forward_only = d_alpha == nullptr && !both_sweeps;
-        rc = launch_potrs(ctx, d_A, d_W, Np, d_b, forward_only);
-        if (rc) return rc;
+        rc = launch_potrs(ctx, d_A, d_W, Np, d_b, forward_only, keep ? &own_slabs : nullptr, keep ? &own_S : nullptr);
+        if (rc) return fail(rc);
+        sweeps = forward_only ? 1.0 : 2.0;
         rc = launch_logdet_dot(ctx, d_A, Np, n, forward_only ? d_b : d_y, d_b, ctx->d_scal);
-        if (rc) return rc;
+        if (rc) return fail(rc);
         if (d_alpha) TGP_HIP(hipMemcpyAsync(d_alpha, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
         TGP_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     }
@@ -339,9 +381,10 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
     TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
     ctx->timings[2] = ms;
     ctx->timings[8] = 8.0 * ((double)Np * (Np + 1) / 2.0) + 16.0 * (double)Np;
+    ctx->timings[10] = sweeps;
     if (info > 0) {
         if (info > n) info = (int)n;     // cannot happen (padding is the identity); defensive
-        return info;
+        return fail(info);
     }
     if (logdet) *logdet = ctx->h_scal[0];
     if (ydota) *ydota = ctx->h_scal[1];
@@ -351,6 +394,8 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
         f->Np = Np;
         f->d_A = d_A;
         f->d_W = d_W;
+        f->d_slabs = own_slabs;
+        f->slab_S = own_S;
         e->A_cache = e->W_cache = nullptr;      // ownership moves to the handle
         e->cache_Np = 0;
         *keep = f;

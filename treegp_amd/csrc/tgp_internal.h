@@ -146,7 +146,24 @@ int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, in
                         const double *d_yerr, double *d_A);
 int launch_kernel_dense(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,
                         const double *d_Y, int64_t m, int self, double *d_out);
-int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_info = false, int64_t n_data = -1);
+// A right-hand side that rides along with the factorisation (chol.hip): as soon as a super-block of S columns of L is final,
+// a third stream builds its inverse slabs and takes the forward-substitution step through it -- both are memory-bound and
+// run beside the MFMA-bound trailing update.  When launch_potrf returns, d_z = L^-1 b is queued and only the backward sweep
+// (launch_potrs_big_bwd) is left.  `active` is cleared when the schedule in use does not carry riders (one-stream modes).
+struct PotrfRider {
+    double *d_b = nullptr;      // in: padded right-hand side (consumed)
+    double *d_z = nullptr;      // out: L^-1 b
+    double *slabs = nullptr;    // [V | Vt | TT] of the sweeps' step S, built on the way
+    int S = 0;
+    bool active = false;
+};
+int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_info = false, int64_t n_data = -1,
+                 PotrfRider *rider = nullptr);
+bool potrs_big_step(int64_t Np, int *S);
+int acquire_slabs(tgp_ctx *ctx, int64_t Np, int S, double **slab_cache, int *slab_S, double **out, bool *need_build);
+int launch_potrs_big_fwd_step(tgp_ctx *ctx, hipStream_t st, const double *d_A, int64_t Np, int S, const double *slabs, int K,
+                              double *d_b, double *d_z);
+int launch_potrs_big_bwd(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z);
 int launch_kbuild_lower_dist(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,
                              const double *d_yerr, double *d_Aloc, const int64_t *d_loff, int G, int g);
 int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base);

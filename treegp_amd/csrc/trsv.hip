@@ -352,6 +352,7 @@ __global__ __launch_bounds__(256) void fwd_update256_kernel(const double *__rest
 // sweep below (10.6 vs 12.2 ms at N=32768); the fused kernels serve the multi-GPU driver, where fewer
 // launches and collectives per block matter more.
 // Big-step sweeps (trsv_big.hip) from TGP_POTRS_BIG_FROM rows on (default 2048; 0 = never); TGP_POTRS_STEP = 512 | 1024.
+bool potrs_big_step(int64_t Np, int *S);
 static bool potrs_big_config(int64_t Np, int *S) {
     const int64_t big_from = getenv("TGP_POTRS_BIG_FROM") ? atoll(getenv("TGP_POTRS_BIG_FROM")) : 2048;
     // step: 512 below Np = 12 288, 1024 from there.  The third doubling level of the slab build (512 -> 1024) is 2 x 2 Np 512^2
@@ -362,9 +363,11 @@ static bool potrs_big_config(int64_t Np, int *S) {
     return big_from > 0 && Np >= big_from;
 }
 
+bool potrs_big_step(int64_t Np, int *S) { return potrs_big_config(Np, S); }
+
 // the inverse slabs of this factor: the caller's cache (built on first use) or the context's buffer (rebuilt every call).
 // *need_build says whether they have to be built now.
-static int acquire_slabs(tgp_ctx *ctx, int64_t Np, int S, double **slab_cache, int *slab_S, double **out, bool *need_build) {
+int acquire_slabs(tgp_ctx *ctx, int64_t Np, int S, double **slab_cache, int *slab_S, double **out, bool *need_build) {
     *need_build = true;
     if (slab_cache) {
         if (*slab_cache && slab_S && *slab_S != S) {             // built for another step (TGP_POTRS_STEP changed): start over

@@ -413,26 +413,34 @@ void launch_bulk_fwd(hipStream_t st, const double *d_A, int64_t Np, int p0, int 
     bulk_fwd_kernel<NP, NR><<<(unsigned)((below + 4 * RPW - 1) / (4 * RPW)), 256, 0, st>>>(d_A, Np, p0, npan, row0, below, z, b, vs);
 }
 
-// NR right-hand sides (vectors at stride vs in d_b and d_z) through both sweeps
+// one step of the forward sweep: z_K = V_K b_K, then b[below] -= L[below, K] z_K
+template <int NR>
+void fwd_step(hipStream_t st, const double *d_A, int64_t Np, int S, const double *V, int K, double *d_b, double *d_z, int64_t vs) {
+    const int NPmax = S / 256;
+    const int64_t r0 = (int64_t)K * S;
+    const int rows = (int)((Np - r0) < S ? (Np - r0) : S);
+    launch_diag_gemv<false, NR>(st, NPmax, V, Np, r0, rows, d_b, d_z, vs);
+    const int64_t below = Np - (r0 + rows);
+    if (below > 0) {
+        const int p0 = (int)(r0 / 256), npan = rows / 256;
+        if (NPmax <= 2) launch_bulk_fwd<2, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs);
+        else launch_bulk_fwd<4, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs);
+    }
+}
+
+// NR right-hand sides (vectors at stride vs in d_b and d_z) through both sweeps.  `backward_only`: d_z already holds L^-1 b
+// (the forward sweep rode along with the factorisation, chol.hip: PotrfRider).
 template <int NR>
 int potrs_big_nr(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z, int64_t vs,
-                 bool forward_only, const SlabPipeline *pipe = nullptr) {
+                 bool forward_only, const SlabPipeline *pipe = nullptr, bool backward_only = false) {
     hipStream_t st = ctx->stream;
     const double *V = slabs, *Vt = slabs + Np * S;
     const int nS = (int)((Np + S - 1) / S);
     const int NPmax = S / 256;
-    for (int K = 0; K < nS; ++K) {
+    for (int K = 0; K < nS && !backward_only; ++K) {
         // slabs built beside this sweep (launch_potrs): super-block K's chunk has to be there
         if (pipe && K > 0 && K % pipe->chunk == 0) TGP_HIP(hipStreamWaitEvent(st, pipe->ready[K / pipe->chunk], 0));
-        const int64_t r0 = (int64_t)K * S;
-        const int rows = (int)((Np - r0) < S ? (Np - r0) : S);
-        launch_diag_gemv<false, NR>(st, NPmax, V, Np, r0, rows, d_b, d_z, vs);
-        const int64_t below = Np - (r0 + rows);
-        if (below > 0) {
-            const int p0 = (int)(r0 / 256), npan = rows / 256;
-            if (NPmax <= 2) launch_bulk_fwd<2, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs);
-            else launch_bulk_fwd<4, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs);
-        }
+        fwd_step<NR>(st, d_A, Np, S, V, K, d_b, d_z, vs);
     }
     if (forward_only) {
         for (int v = 0; v < NR; ++v)
@@ -463,6 +471,18 @@ int potrs_big_nr(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const doubl
 int launch_potrs_big(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z,
                      bool forward_only, const SlabPipeline *pipe) {
     return potrs_big_nr<1>(ctx, d_A, Np, S, slabs, d_b, d_z, Np, forward_only, pipe);
+}
+
+// The forward sweep in pieces, for the rider of the factorisation (chol.hip): step K on stream `st` once super-block K of the
+// factor is final and its slabs are built; afterwards d_z = L^-1 b, and launch_potrs_big_bwd turns it into L^-T L^-1 b in d_b.
+int launch_potrs_big_fwd_step(tgp_ctx *ctx, hipStream_t st, const double *d_A, int64_t Np, int S, const double *slabs, int K,
+                              double *d_b, double *d_z) {
+    fwd_step<1>(st, d_A, Np, S, slabs, K, d_b, d_z, Np);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+int launch_potrs_big_bwd(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z) {
+    return potrs_big_nr<1>(ctx, d_A, Np, S, slabs, d_b, d_z, Np, false, nullptr, true);
 }
 
 // nrhs right-hand sides, rows of d_B (nrhs, Np), in groups of 4, 2, 1; d_Z: scratch of the same shape
