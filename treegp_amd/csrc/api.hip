@@ -306,16 +306,17 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
     double *d_A = e->A_cache, *d_W = e->W_cache;
     double *d_b = (double *)ctx->scratch;
     int rc = 0;
-    // The right-hand side rides along with the factorisation (PotrfRider): the inverse slabs of the sweeps and the forward
-    // substitution are done, super-block by super-block, on a third stream while the trailing update runs; what is left
-    // afterwards is the backward sweep -- one read of L instead of two plus the slab build.  A kept factor owns the slabs
-    // that were built on the way (nothing is rebuilt at the first covariance / multi-field / gradient call).
+    // TGP_RIDER > 0: the right-hand side rides along with the factorisation (PotrfRider): the inverse slabs of the sweeps and
+    // the forward substitution are done, super-block by super-block, on a third stream while the trailing update runs; what is
+    // left afterwards is the backward sweep.  Measured net-neutral to negative (chol.hip), so off by default.  Either way a
+    // kept factor owns the slabs built for its solve (nothing is rebuilt at the first covariance / multi-field / gradient call).
     static const bool both_sweeps = getenv("TGP_CHI2_BOTH_SWEEPS") != nullptr;      // A/B: y . alpha as before
     const bool forward_only = d_alpha == nullptr && !both_sweeps;                   // only |L^-1 y|^2 is wanted
     PotrfRider rider;
     double *own_slabs = nullptr;          // slabs that will belong to the kept factor
     int own_S = 0, S = 0;
-    if (!augmented && potrs_big_step(Np, &S)) {
+    static const bool rider_on = getenv("TGP_RIDER") && atoi(getenv("TGP_RIDER")) > 0;      // off by default: chol.hip
+    if (rider_on && !augmented && potrs_big_step(Np, &S)) {
         rc = tgp_ensure_scratch2(ctx, (size_t)Np * sizeof(double));
         if (rc) return rc;
         bool build = false;
