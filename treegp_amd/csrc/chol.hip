@@ -355,39 +355,52 @@ struct DistSegs {
 // valid tiles are enumerated: `start` holds, per group of 8 local tile rows, the index of its first super-tile.
 struct DistMap {
     int start[258];           // prefix of super-tiles per row group; start[ngroups] = total  (N up to 262144 on one rank)
-    int ngroups;
+    int ngroups;              // 0: dense enumeration (strips: workgroup b = local tile row b / ncol, column b % ncol)
+    int fb;                   // first block >= kpanel + NSEG this rank owns (host: dist_first_ge)
+    unsigned ginv;            // floor(2^32 / G) + 1: x / G == (x * ginv) >> 32 for 0 <= x < 65536 (block indices are < 1024); 0 for G == 1
 };
-// one tile of the rank's share: b is the (virtual) workgroup index of the plain launch
+__device__ __forceinline__ int div_g(int x, unsigned ginv) { return ginv ? (int)__umulhi((unsigned)x, ginv) : x; }     // ginv == 0: G == 1
+// one tile of the rank's share: b is the (virtual) workgroup index of the plain launch.  Index arithmetic in 32 bits with a
+// reciprocal of G from the host -- the run-time-G 64-bit divisions of round 2's version (a dozen per tile, scalar code)
+// were 1.6 % of the kernel at depth 1024 (world of one, A/B against the single-GPU kernel inside this driver).
+// Block b' of rank r sits at index (b' - first) / G among r's blocks >= first (b' owned by r: stepping down by G stays >= first).
 template <int NSEG>
 __device__ __forceinline__ void syrk_distn_tile(int64_t b, double *Aloc, const int64_t *__restrict__ loff, int kpanel, int G, int g,
                                                 const DistSegs<NSEG> &S, int col_lo, int ncol, int nrows, const DistMap &M) {
-    const int64_t st = ((b >> 3) >> 6) * 8 + (b & 7);
-    if (st >= M.start[M.ngroups]) return;
-    int R = 0;
-    for (int step = 128; step > 0; step >>= 1)
-        if (R + step <= M.ngroups && M.start[R + step] <= st) R += step;      // last group with start <= st
-    const int within = (int)((b >> 3) & 63);
-    const int lt = R * 8 + (within >> 3);
-    const int ct = (int)(st - M.start[R]) * 8 + (within & 7);
-    if (lt >= nrows || ct >= ncol) return;
-    const int64_t gtj = (int64_t)ct + col_lo;
-    const int64_t s0 = kpanel + NSEG;
-    const int64_t bi = dist_first_ge(s0, g, G) + (int64_t)(lt >> 1) * G;
-    const int64_t gti = 2 * (bi - s0) + (lt & 1);
+    int lt, ct;
+    if (M.ngroups == 0) {
+        lt = (int)(b / ncol);
+        ct = (int)(b - (int64_t)lt * ncol);
+        if (lt >= nrows) return;
+    } else {
+        const int st = (int)((b >> 3) >> 6) * 8 + (int)(b & 7);
+        if (st >= M.start[M.ngroups]) return;
+        int R = 0;
+        for (int step = 128; step > 0; step >>= 1)
+            if (R + step <= M.ngroups && M.start[R + step] <= st) R += step;      // last group with start <= st
+        const int within = (int)((b >> 3) & 63);
+        lt = R * 8 + (within >> 3);
+        ct = (st - M.start[R]) * 8 + (within & 7);
+        if (lt >= nrows || ct >= ncol) return;
+    }
+    const int gtj = ct + col_lo;
+    const int s0 = kpanel + NSEG;
+    const int bi = M.fb + (lt >> 1) * G;
+    const int gti = 2 * (bi - s0) + (lt & 1);
     if (gtj > gti) return;
     if (ncol <= 8) TGP_CHAIN_PRIO();          // strips of the panel chain (2 or 2 GS tile columns), not the bulk
-    const int64_t bj = s0 + (gtj >> 1);
-    const int rj = (int)(bj % G);
+    const int bj = s0 + (gtj >> 1);
+    const int rj = bj - G * div_g(bj, M.ginv);
     const int64_t hi = (lt & 1) * TGP_TB, hj = (gtj & 1) * TGP_TB;
     SegPtrs<NSEG> sp;
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
-        const int64_t first = kpanel + s + 1;                 // first block held by gathered panel s
-        const int64_t is = (bi - dist_first_ge(first, g, G)) / G, js = (bj - dist_first_ge(first, rj, G)) / G;
+        const int first = kpanel + s + 1;                     // first block held by gathered panel s
+        const int is = div_g(bi - first, M.ginv), js = div_g(bj - first, M.ginv);
         sp.a[s] = S.P[s] + (((int64_t)g * S.cmax[s] + is) * TGP_PW + hi) * TGP_PW;
         sp.b[s] = S.P[s] + (((int64_t)rj * S.cmax[s] + js) * TGP_PW + hj) * TGP_PW;
     }
-    double *c = Aloc + loff[bj] + (((bi - dist_first_ge(bj, g, G)) / G) * TGP_PW + hi) * TGP_PW + hj;
+    double *c = Aloc + loff[bj] + ((int64_t)div_g(bi - bj, M.ginv) * TGP_PW + hi) * TGP_PW + hj;
     gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, c);
 }
 
@@ -1082,10 +1095,49 @@ int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64
     if (col_lo < 0) col_lo = 0;
     const int64_t ncol = (int64_t)col_hi - col_lo;
     if (nloc <= 0 || ncol <= 0) return 0;
+    // experiment (TGP_DIST_W1_SEGS=1, world of one only): the single-GPU kernel on the same work -- is the 5 % between the
+    // two drivers the kernel's or its surroundings'?
+    static const bool w1_segs = getenv("TGP_DIST_W1_SEGS") != nullptr;
+    if (w1_segs && G == 1 && nseg == 4 && queue_nres == 0) {
+        const int ob = kpanel + nseg + col_lo / 2;
+        const int T = (int)(ncol_all - col_lo);
+        const int strip = (col_hi < ncol_all) ? (int)ncol : 0;
+        SegPtrs<4> P;
+        for (int sgi = 0; sgi < 4; ++sgi) {
+            P.a[sgi] = d_P[sgi] + (int64_t)(ob - (kpanel + sgi + 1)) * TGP_PW * TGP_PW;
+            P.b[sgi] = nullptr;
+        }
+        const unsigned gs = strip == 0 ? (unsigned)tilemap_grid(T) : (unsigned)((int64_t)T * strip);
+        syrk_segs_kernel<4><<<gs, 256, 0, ctx->stream>>>(d_Aloc, Np, ob, T, strip, P);
+        TGP_HIP(hipGetLastError());
+        return 0;
+    }
     // staircase of valid tiles: local tile row lt reaches global tile column gti(lt); super-tiles per group of 8 rows
     const int nrows = (int)(2 * nloc);
     const int64_t s0 = kpanel + nseg, fb = dist_first_ge(s0, g, G);
     DistMap M;
+    M.fb = (int)fb;
+    M.ginv = G == 1 ? 0u : (unsigned)((((uint64_t)1) << 32) / (uint64_t)G) + 1u;
+    TGP_ARG(nB < 65536 && G >= 1);
+    // Strips (the panel chain's updates of a few tile columns): a dense grid, one workgroup per (tile row, tile column).  The
+    // super-tile map would start three empty workgroups for every useful one of a two-column strip, and beside a bulk
+    // update that fills every slot it is slot grants, not arithmetic, that a strip waits for (rocprofv3, world of one at
+    // N = 65 536: 748 / 561 / 375 us per strip of depth 768 / 512 / 256 against 468 / 345 / 239 us on the single-GPU path).
+    static const bool dense_strips = getenv("TGP_DIST_SPARSE_STRIPS") == nullptr;
+    if (dense_strips && ncol <= 8 && queue_nres == 0) {
+        M.ngroups = 0;
+        M.start[0] = 0;
+        const unsigned grid = (unsigned)((int64_t)nrows * ncol);
+        hipStream_t st0 = ctx->stream;
+        switch (nseg) {
+            case 1: launch_distn<1>(st0, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, 0, nullptr); break;
+            case 2: launch_distn<2>(st0, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, 0, nullptr); break;
+            case 3: launch_distn<3>(st0, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, 0, nullptr); break;
+            default: launch_distn<4>(st0, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, 0, nullptr); break;
+        }
+        TGP_HIP(hipGetLastError());
+        return 0;
+    }
     M.ngroups = (nrows + 7) / 8;
     TGP_ARG(M.ngroups <= 257);
     int total = 0;
