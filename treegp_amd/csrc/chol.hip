@@ -1153,12 +1153,16 @@ int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64
     if (total == 0) return 0;
     const unsigned grid = (unsigned)(((total + 7) / 8) * 8 * 64);
     hipStream_t st = ctx->stream;
-    // queued form: one set of counters per launch, zeroed by tgp_dd_queue_reset at the start of a factorisation; when the
-    // sets run out the launch is a plain one
+    // queued form: one set of counters per launch, zeroed by tgp_dd_queue_reset at the start of a factorisation; beyond
+    // TGP_NQUEUE launches (N > 131 072 in groups of four) the sets are reused in turn, each zeroed on this stream in front of
+    // its launch -- the launch that used it TGP_NQUEUE launches ago is long finished (same stream)
     int nres = queue_nres > 3 ? 3 : queue_nres;
     unsigned *queue = nullptr;
-    if (nres > 0 && ctx->dist_nqueue < TGP_NQUEUE) queue = ctx->d_queue + TGP_QUEUE_WORDS * (ctx->dist_nqueue++);
-    else nres = 0;
+    if (nres > 0) {
+        queue = ctx->d_queue + TGP_QUEUE_WORDS * (ctx->dist_nqueue % TGP_NQUEUE);
+        if (ctx->dist_nqueue >= TGP_NQUEUE) TGP_HIP(hipMemsetAsync(queue, 0, TGP_QUEUE_WORDS * sizeof(unsigned), st));
+        ++ctx->dist_nqueue;
+    }
     switch (nseg) {
         case 1: launch_distn<1>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue); break;
         case 2: launch_distn<2>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue); break;

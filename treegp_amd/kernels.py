@@ -142,6 +142,8 @@ class AnisotropicRBF(_CholeskyParametrised):
         """dK/dtheta_k = -1/2 K dX^T (d invLam/d theta_k) dX (kernels.py:128-150), from the device's K; host arithmetic on
         (n, n) arrays, one per theta -- nothing on the fit's path asks for it (log_likelihood.py:57 passes no jac; the
         likelihood gradient has its own device entry point, ops.gp_loglik_grad)."""
+        if self.hyperparameter_cholesky_factor.fixed:            # kernels.py:128-130: no free parameter, an (n, n, 0) gradient
+            return np.empty((X.shape[0], X.shape[0], 0))
         d = [X[:, None, a] - X[None, :, a] for a in range(self.ndim)]
         out = np.empty(K.shape + (self.ntheta,))
         for k, g in enumerate(self.invLam_gradient()):
@@ -263,6 +265,8 @@ def spec_jacobian(kernel):
             return np.zeros((0, 4))
         return np.array([[1.0, 0.0, 0.0, 0.0]])
     if isinstance(kernel, AnisotropicRBF):
+        if kernel.hyperparameter_cholesky_factor.fixed:         # theta is empty then (kernels.py:128-130)
+            return np.zeros((0, 4))
         nd = kernel.ndim
         rows = []
         for g in kernel.invLam_gradient():
