@@ -173,7 +173,7 @@ def configs_measured(lib, ctx, ops, _lib):
                 "gp_solves_per_sec": 1e3 / (acc["kbuild_ms"] + acc["chol_ms"] + acc["trsv_ms"]),
                 "likelihood_evaluations_per_sec": 1e3 / lik_ms,
                 "cholesky_tflops_fp64": chol_tf, "cholesky_frac_mfma_peak": chol_tf / FP64_MFMA_PEAK_TFLOPS,
-                "trsv_frac_hbm": (4.0 * npad * (npad + 1)) / (acc["trsv_ms"] * 1e-3) / 8e12,
+                "trsv_frac_hbm": (8.0 * npad * (npad + 1)) / (acc["trsv_ms"] * 1e-3) / 8e12,      # both sweeps: L read twice
                 "predict_pairs_per_sec": float(m) * n / (acc["predict_ms"] * 1e-3),
                 "predict_points_per_sec": m / (acc["predict_ms"] * 1e-3)})
     for b in bufs + [da, dys]:
@@ -219,7 +219,8 @@ def configs_measured(lib, ctx, ops, _lib):
                 "kbuild_frac_of_vk_ceiling": elems / (best * 1e-3) / VK_CEILING,
                 "two_pcf_fit_ms": fit_ms, "solve_plus_predict_32768_ms": solve_predict_ms,
                 "kk_log_ms_incl_copies": kk_ms, "kk_log_pairs_per_sec": n * (n - 1) / 2.0 / (kk_ms * 1e-3),
-                "kk_log_frac_of_lds_atomic_ceiling": n * (n - 1) / 2.0 / (kk_ms * 1e-3) / LDS_ATOMIC_CEILING,
+                # > 1 by design: the crowded bins accumulate in registers, so fewer atomics than the ceiling's one-per-sum are issued
+                "kk_log_over_lds_atomic_ceiling": n * (n - 1) / 2.0 / (kk_ms * 1e-3) / LDS_ATOMIC_CEILING,
                 "bootstrap_444_resamples_21x21_ms": {"device_incl_copies": boot_dev, "wall": boot_wall}})
     return out
 
@@ -254,7 +255,11 @@ def main():
 
     lib = _lib.load_library()
     ctx = _lib.get_ctx(device=local_rank)
-    api = world > 1 or args.api or args.meanify
+    # TGP_BENCH_FORCE_DIST=1: the N > 1 code path (process group, engine, API route, per-rank diagnostics) with whatever
+    # world size the launcher gave, including one rank -- a rehearsal of the driver's multi-GPU run on the real backend
+    force_dist = os.environ.get("TGP_BENCH_FORCE_DIST") == "1" and "WORLD_SIZE" in os.environ
+    use_dist = world > 1 or force_dist
+    api = use_dist or args.api or args.meanify
     fits = None
     if args.meanify:
         import tempfile
@@ -269,7 +274,7 @@ def main():
     ymean = y.mean()
 
     engine = None
-    if world > 1:
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -326,7 +331,7 @@ def main():
         # multi-GPU route (treegp_amd.dist: row-block-cyclic Cholesky, query points sharded), every rank the same calls
         import treegp_amd
         gp = treegp_amd.GPInterpolation(kernel=headline_kernel_string(), optimizer="none", normalize=True, white_noise=0.0,
-                                        average_fits=fits, backend="dist" if world > 1 else "single")
+                                        average_fits=fits, backend="dist" if use_dist else "single")
 
         def step(acc):
             t0 = time.perf_counter()
@@ -354,7 +359,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     per_rank = None
-    if world > 1:
+    if use_dist:
         import torch
         import torch.distributed as dist
         acc.update(engine.acc)
@@ -388,17 +393,18 @@ def main():
             "dtype": "f64", "data": "synthetic", "ranks_seen": ranks_seen,
             "config": {"workload": "%s: 2-D AnisotropicRBF star field, N=%d training points, solved end to end + fused "
                                    "predict of M=%d points; %s; %s"
-                                   % (recipe, n, m, "one GPU" if world == 1 else "row-block-cyclic over %d GPUs" % world,
+                                   % (recipe, n, m, "one GPU" if not use_dist else ("row-block-cyclic over %d GPUs" % world if world > 1 else
+                                                                                        "multi-GPU route rehearsed with one rank"),
                                       "through treegp_amd.GPInterpolation (initialize + predict)" if api else
                                       "device-resident C-ABI calls (tgp_d_gp_solve + tgp_d_gp_predict)"),
                        "n_train": n, "m_predict": m, "kernel": "1.0**2 * AnisotropicRBF(invLam=inv(L(0.05,0.2,0.1)))",
-                       "parallelism": "single" if world == 1 else "rowcyclic%d" % world, "through_api": bool(api),
+                       "parallelism": "single" if not use_dist else "rowcyclic%d" % world, "through_api": bool(api),
                        "meanify": bool(args.meanify)},
         }
         if per_rank is not None:
             np_ = (n + 255) // 256 * 256
             out["per_rank_ms_per_step"] = per_rank
-            out["bytes_received_expected"] = 4.0 * np_ * np_ * (world - 1) / world
+            out["bytes_received_expected"] = 4.0 * np_ * np_ * (world - 1) / world if world > 1 else 0.0
             out["per_rank_note"] = ("chol_ms = factorisation wall on the rank's main stream; bulk_ms = its trailing-update kernels; "
                                     "chain_ms = its look-ahead stream (diagonal blocks, broadcasts, local solves, all-gathers, strips); "
                                     "gather_wait_ms = main stream stalled behind the chain between two bulk updates")
@@ -409,7 +415,7 @@ def main():
             launches = max(acc["syrk_launches"], 1)
             traffic, src = (None, "not collected for this configuration")
             alg_bytes = None
-            if world == 1:
+            if not use_dist:
                 # HBM-side bytes per launch of this kernel for this exact workload, from separate rocprofv3 --pmc
                 # passes on the shipped sources (FETCH_SIZE x2 for the 16-B/lane operand loads, WRITE_SIZE exact;
                 # tools/pmc_bench.sh); algorithmic bytes per launch = C read + written once (16 B per updated element)
@@ -419,7 +425,7 @@ def main():
                                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": src,
                                "algorithmic_bytes": alg_bytes,
                                "traffic_over_algorithmic": (traffic / alg_bytes) if (traffic and alg_bytes) else None,
-                               "kernel": ("syrk_segs_kernel<4>" if n >= 22528 else "syrk_dtv_kernel<4, 2>") if world == 1 else "syrk_distn_kernel (rank 0)",
+                               "kernel": ("syrk_segs_kernel<4>" if n >= 22528 else "syrk_dtv_kernel<4, 2>") if not use_dist else "syrk_distn_kernel (rank 0)",
                                "launches": int(acc["syrk_launches"]),
                                "avg_launch_ms": acc["syrk_ms"] / launches}
         if "chol_ms" in acc:
@@ -427,7 +433,7 @@ def main():
             out["gp_solves_per_sec"] = K / ((acc["kbuild_ms"] + acc["chol_ms"] + acc["trsv_ms"]) * 1e-3)
             out["predict_points_per_sec"] = m * K / (acc["predict_ms"] * 1e-3)
             npad = (n + 255) // 256 * 256
-            if world == 1:
+            if not use_dist:
                 kb_bytes = K * (8.0 * (npad * (npad + 1) / 2.0) + 16.0 * npad)
                 out["kbuild_GBps"] = kb_bytes / (acc["kbuild_ms"] * 1e-3) / 1e9
                 # K build is HBM-write bound, 8 Np(Np+1)/2 + 16 Np algorithmic bytes per launch
@@ -449,14 +455,17 @@ def main():
             pr_tf = 30.0 * m_rank * n * K / (acc["predict_ms"] * 1e-3) / 1e12
             out["roofline_predict"] = {"bound": "valu", "achieved": pr_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": pr_tf / 78.6,
                                        "pairs_per_sec": m_rank * n * K / (acc["predict_ms"] * 1e-3),
-                                       "kernel": "predict_gauss_fast_kernel", "avg_ms": acc["predict_ms"] / K}
+                                       "kernel": "predict_gauss_tab_kernel<256>", "avg_ms": acc["predict_ms"] / K,
+                                       # 16.4 VALU instructions per pair in the loop (csrc/predict.hip): share of the issue slots
+                                       # of 256 CUs x 4 SIMDs x 16 lanes at 2.4 GHz
+                                       "valu_issue_frac_at_2p4ghz": m_rank * n * K / (acc["predict_ms"] * 1e-3) * 16.4 / (256 * 4 * 16 * 2.4e9)}
             out["phases_ms_per_step"] = {k: acc[k] / K for k in ("kbuild_ms", "chol_ms", "trsv_ms", "predict_ms", "syrk_ms")}
-        if world == 1 and not args.no_configs:
+        if not use_dist and not args.no_configs:
             out["configs_measured"] = configs_measured(lib, ctx, ops, _lib)
-        if world == 1 and args.cpu_sample > 0:
+        if not use_dist and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 4 * args.cpu_sample, n)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

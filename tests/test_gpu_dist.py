@@ -289,8 +289,31 @@ def test_bench_line_schema_single_gpu():
         assert key in c1, key
     assert "N=8192" in c1["config"] and 0 < c1["cholesky_frac_mfma_peak"] < 1 and 0 < c1["trsv_frac_hbm"] < 1
     for key in ("kbuild_elements_per_sec", "kbuild_frac_of_vk_ceiling", "two_pcf_fit_ms", "kk_log_pairs_per_sec",
-                "kk_log_frac_of_lds_atomic_ceiling", "bootstrap_444_resamples_21x21_ms", "solve_plus_predict_32768_ms"):
+                "kk_log_over_lds_atomic_ceiling", "bootstrap_444_resamples_21x21_ms", "solve_plus_predict_32768_ms"):
         assert key in c2, key
     assert "N=32768" in c2["config"] and c2["two_pcf_fit_ms"] > 0
     assert any(k.startswith("extrapolated_n") for k in cb)
     np.testing.assert_allclose(out["value"], (24576 + 4 * 24576) / (out["ms_per_step"] * 1e-3), rtol=1e-9)
+
+
+def test_bench_multi_gpu_path_on_rccl_world_of_one():
+    """The N > 1 leg of bench.py -- process group with the high-priority option, engine, GPInterpolation(backend="dist"),
+    per-rank diagnostics -- on the REAL backend (nccl = RCCL) with one rank (TGP_BENCH_FORCE_DIST=1): everything the driver's
+    multi-GPU run executes except the payload of the collectives."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               TGP_BENCH_FORCE_DIST="1")
+    env.pop("TGP_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--ntrain",
+                        "30000", "--meanify"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["config"]["through_api"] and out["config"]["meanify"] and out["config"]["parallelism"] == "rowcyclic1"
+    assert out["roofline"]["kernel"].startswith("syrk_distn") and 0.3 < out["roofline"]["frac"] < 1.0
+    assert len(out["per_rank_ms_per_step"]["chain_ms"]) == 1 and out["per_rank_ms_per_step"]["bytes_received"] == [0.0]

@@ -131,8 +131,13 @@ __host__ __device__ inline void tilemap(int64_t b, int64_t T, int &ti, int &tj) 
     while (Si * (Si + 1) / 2 > st) --Si;
     while ((Si + 1) * (Si + 2) / 2 <= st) ++Si;
     int64_t Sj = st - Si * (Si + 1) / 2;
+#ifdef TGP_SUP_COLMAJOR          // A/B build (round 3): walk a super-tile column by column instead of row by row
+    int i = (int)((Si << sh) + (within & ((1 << sh) - 1)));
+    int j = (int)((Sj << sh) + (within >> sh));
+#else
     int i = (int)((Si << sh) + (within >> sh));
     int j = (int)((Sj << sh) + (within & ((1 << sh) - 1)));
+#endif
     if (j > i || i >= T) { ti = -1; tj = -1; return; }
     ti = i; tj = j;
 }
