@@ -106,6 +106,32 @@ def test_config5_recipe_through_the_api_virtual_ranks(G, n, group, tmp_path, mon
             np.testing.assert_allclose(yp, ora, rtol=0, atol=1e-10 * np.abs(ora).max())
 
 
+def test_default_schedule_at_a_size_that_takes_groups_of_four(tmp_path):
+    """Nothing forced: at N = 30 000 the driver picks groups of four panels by itself (Np >= 28 672), the schedule the
+    BASELINE sizes run; four virtual ranks through the API against the single-GPU API and the device residual."""
+    import treegp_amd
+    from treegp_amd import ops
+    from treegp_amd.kernels import kernel_to_spec
+    n, m, G = 30000, 4000, 4
+    X, y, y_err, Xs, X0, y0, kw = _recipe(n, m, tmp_path, seed=13)
+    one = treegp_amd.GPInterpolation(**kw)
+    one.initialize(X, y, y_err)
+    ref = one.predict(Xs)
+
+    def rank_fn(rank):
+        gp = treegp_amd.GPInterpolation(backend="dist", **kw)
+        gp.initialize(X, y, y_err)
+        return gp.predict(Xs), gp._alpha.copy()
+
+    spec = kernel_to_spec(one.kernel)
+    resid_y = one._y - one._mean - one._spatial_average
+    for yp, alpha in _virtual_ranks(G, rank_fn):
+        np.testing.assert_allclose(yp, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+        Ka = ops.gp_predict(spec, X, alpha, X)                 # K alpha without K
+        rel = np.linalg.norm(Ka + one._y_err ** 2 * alpha - resid_y) / np.linalg.norm(resid_y)
+        assert rel < 1e-10, rel
+
+
 def test_threshold_route_fields_and_errors_virtual_ranks(tmp_path):
     """An enabled engine takes objects that name no backend once they reach its size threshold and leaves smaller ones
     alone; ``predict_fields`` solves every field against the replicated factor; a matrix that is not positive definite

@@ -17,6 +17,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   T=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmcb_$T -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $R/gpurun_out/pmcb_$T.json 2> $R/gpurun_out/pmcb_$T.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmcb_$T -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-configs > $R/gpurun_out/pmcb_$T.json 2> $R/gpurun_out/pmcb_$T.err
 done
 python3 $R/tools/pmc_derive.py

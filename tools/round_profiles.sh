@@ -17,7 +17,7 @@ python3 tools/world_of_one.py 65536 2 2> /dev/null | grep -v amdgpu > $O/${TAG}_
 echo "tools done"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/${TAG}_prof_bench $O/${TAG}_prof_trsv
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_bench -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $O/${TAG}_bench_n65536_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_bench -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-configs > $O/${TAG}_bench_n65536_under_rocprof.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_trsv -- python3 $R/tools/trsv_bench.py 8192 65536 > /dev/null 2>&1
 find $O/${TAG}_prof_bench -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_bench_n65536_kernel_stats.csv \;
 find $O/${TAG}_prof_trsv -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_trsv_kernel_stats.csv \;
