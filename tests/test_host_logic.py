@@ -348,6 +348,11 @@ def test_ml_gradient_mode_selection(monkeypatch):
     assert not mod.log_likelihood(small, None, None)._use_exact_gradient(gauss)
     assert mod.log_likelihood(big, None, None)._use_exact_gradient(gauss)
     assert not mod.log_likelihood(big, None, None)._use_exact_gradient(vk)
+    # beyond the device gradient's own limit (row tiles of a matrix of at most 65 535 rows, csrc/cov.hip) the fit keeps
+    # finite differences instead of failing into -inf at the start point: n = 65 281 pads to 65 536
+    assert mod.log_likelihood(np.zeros((65280, 2)), None, None)._use_exact_gradient(gauss)
+    assert not mod.log_likelihood(np.zeros((65281, 2)), None, None)._use_exact_gradient(gauss)
+    assert not mod.log_likelihood(np.zeros((65536, 2)), None, None)._use_exact_gradient(gauss)
     monkeypatch.setenv("TGP_ML_GRADIENT", "analytic")
     assert mod.log_likelihood(small, None, None)._use_exact_gradient(gauss)
     with pytest.raises(NotImplementedError, match="no analytic derivative"):

@@ -154,7 +154,11 @@ class log_likelihood(object):
         need = 8.0 * (2.0 * Np * Np + 2.0 * float(lib.tgp_panel_elems(Np)))
         import ctypes
         free, total = ctypes.c_int64(), ctypes.c_int64()
-        if lib.tgp_mem_info(_lib.get_ctx(), ctypes.byref(free), ctypes.byref(total)) != 0:
+        try:
+            ctx = _lib.get_ctx()
+        except RuntimeError:              # no device: nothing will run anyway, the choice is made on the size alone
+            return True
+        if lib.tgp_mem_info(ctx, ctypes.byref(free), ctypes.byref(total)) != 0:
             return True
         return need < 0.9 * free.value
 
