@@ -148,6 +148,7 @@ def test_golden_config1_and_aniso2d(tg, golden):
                                  {"TGP_QUEUE_T": "0"}, {"TGP_STRIP64_T": "0"}, {"TGP_NO_AUGMENT": "1"}, {"TGP_QUEUE_T": "200", "TGP_HEAD_START": "1"},
                                  {"TGP_CHOL_MODE": "4"}, {"TGP_CHOL_MODE": "2", "TGP_DF_T": "12"}, {"TGP_CHOL_MODE": "4", "TGP_DF_SMALL_TALL": "0"},
                                  {"TGP_PREDICT_EXP": "0"}, {"TGP_PREDICT_EXP": "32"}, {"TGP_PREDICT_EXP": "64"},
+                                 {"TGP_NO_AUGMENT_ALPHA": "1"},
                                  {"TGP_RIDER": "2"}, {"TGP_RIDER": "1", "TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "8"}])
 def test_alternative_kernel_paths_agree(env):
     """The A/B switches kept in the library (older tiles, schedules and diagonal-block kernels) must stay correct:
@@ -217,3 +218,26 @@ def test_likelihood_only_solve_matches_full_solve(tg, n):
     a_ref, ld_ref = O.gp_solve(O.kernel_matrix("gauss", X, amp=1.7, a=80.0, b=10.0, c=60.0), y, e)
     np.testing.assert_allclose(chi2, float(y @ a_ref), rtol=1e-10)
     np.testing.assert_allclose(logdet2, ld_ref, rtol=1e-11)
+
+
+@pytest.mark.parametrize("n", [2049, 2303, 3000, 5000, 8000, 12289])
+def test_alpha_from_the_augmented_row_matches_both_sweeps(tg, n):
+    """n not a multiple of 256, alpha wanted, factor not kept: y rides through the factorisation as matrix row Np-1 and
+    only the backward sweep runs (treegp/gp_interp.py:181-182 is cholesky + cho_solve = both sweeps).  Same alpha as the
+    kept-factor path, which keeps a clean factor and does both sweeps, and as the oracle."""
+    from treegp_amd import _lib, ops
+    rng = np.random.default_rng(n)
+    X = rng.uniform(0, 1, (n, 2)); y = rng.standard_normal(n) * 2.0 - 0.3; e = rng.uniform(0.05, 0.15, n)
+    spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.4, a=90.0, b=12.0, c=70.0)
+    alpha, logdet, ydota, _ = ops.gp_solve(spec, X, y, e)
+    assert _lib.timings(_lib.get_ctx())[10] == 1.0                 # one sweep over L in the solve phase
+    alpha2, logdet2, ydota2, fac = ops.gp_solve(spec, X, y, e, keep=True)
+    assert _lib.timings(_lib.get_ctx())[10] == 2.0
+    fac.free()
+    np.testing.assert_allclose(alpha, alpha2, rtol=0, atol=1e-12 * np.abs(alpha2).max())
+    np.testing.assert_allclose(logdet, logdet2, rtol=1e-13)
+    np.testing.assert_allclose(ydota, ydota2, rtol=1e-11)
+    if n <= 5000:
+        a_ref, ld_ref = O.gp_solve(O.kernel_matrix("gauss", X, amp=1.4, a=90.0, b=12.0, c=70.0), y, e)
+        np.testing.assert_allclose(alpha, a_ref, rtol=0, atol=1e-10 * np.abs(a_ref).max())
+        np.testing.assert_allclose(logdet, ld_ref, rtol=1e-11)

@@ -343,6 +343,26 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
     if (info == 0 && augmented) {
         rc = launch_logdet_rowsq(ctx, d_A, Np, n, ctx->d_scal);
         if (rc) return fail(rc);
+        if (d_alpha) {
+            // alpha wanted too: the augmented row IS L^-1 y, so only the backward sweep is left (slabs built here, in one go).
+            // The row's own huge pivot does not enter: its component of the right-hand side is zero.
+            int Sa = 0;
+            (void)potrs_big_step(Np, &Sa);
+            rc = tgp_ensure_scratch2(ctx, (size_t)Np * sizeof(double));
+            if (rc) return fail(rc);
+            double *d_z = (double *)ctx->scratch2, *slabs = nullptr;
+            bool build = false;
+            rc = acquire_slabs(ctx, Np, Sa, nullptr, nullptr, &slabs, &build);
+            if (rc) return fail(rc);
+            rc = launch_vslab_build(ctx, d_A, d_W, Np, Sa, slabs);
+            if (rc) return fail(rc);
+            rc = launch_extract_row(ctx, d_A, Np, n, d_z);
+            if (rc) return fail(rc);
+            rc = launch_potrs_big_bwd(ctx, d_A, Np, Sa, slabs, d_b, d_z);
+            if (rc) return fail(rc);
+            sweeps = 1.0;
+            TGP_HIP(hipMemcpyAsync(d_alpha, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
         TGP_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     } else if (info == 0 && rider.active) {
         double *d_z = rider.d_z;
@@ -420,8 +440,13 @@ int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t
     if (rc) return rc;
     // Likelihood only (no alpha, factor not kept) and a padding row to spare: y rides along as row Np-1 of the matrix and
     // comes out of the factorisation as L^-1 y -- no triangular sweep (trsv.hip: augment_rhs_kernel)
+    // With alpha wanted as well (round 3; not for kept factors, which must stay clean), the row's content is the right-hand
+    // side of the backward sweep: the forward sweep disappears for every n that is not a multiple of 256 (big-step sweeps only).
     static const bool no_augment = getenv("TGP_NO_AUGMENT") != nullptr || getenv("TGP_CHI2_BOTH_SWEEPS") != nullptr;
-    const bool augmented = !no_augment && d_alpha == nullptr && keep == nullptr && n < Np;
+    static const bool no_augment_alpha = getenv("TGP_NO_AUGMENT_ALPHA") != nullptr;
+    int S_unused = 0;
+    const bool augmented = !no_augment && keep == nullptr && n < Np &&
+                           (d_alpha == nullptr || (!no_augment_alpha && potrs_big_step(Np, &S_unused)));
     if (augmented) {
         rc = launch_augment_rhs(ctx, d_A, Np, n, d_y);
         if (rc) return rc;

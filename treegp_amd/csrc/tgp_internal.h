@@ -209,6 +209,7 @@ int launch_dot(tgp_ctx *ctx, const double *d_a, const double *d_b, int64_t n, do
 int launch_logdet_dot(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, const double *d_a, const double *d_b, double *d_out);
 int launch_pad_copy(tgp_ctx *ctx, const double *d_y, int64_t n, int64_t Np, double *d_b);
 int launch_augment_rhs(tgp_ctx *ctx, double *d_A, int64_t Np, int64_t n, const double *d_y);
+int launch_extract_row(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_z);
 int launch_logdet_rowsq(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out);
 int launch_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_alpha,
                    const double *d_Xs, int64_t m, double *d_ys);

@@ -179,6 +179,14 @@ __global__ __launch_bounds__(1024) void logdet_rowsq_kernel(const double *__rest
     }
 }
 
+// z (Np) <- [L[Np-1, 0:n], 0 ...]: what the factorisation left in the augmented row, as the right-hand side of the backward sweep
+__global__ void extract_row_kernel(const double *__restrict__ A, int64_t Np, int64_t n, double *__restrict__ z) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= Np) return;
+    const int64_t p = c >> 8, r = Np - 1;
+    z[c] = c < n ? A[panel_off(p, Np) + (r - p * TGP_PW) * TGP_PW + (c & 255)] : 0.0;
+}
+
 // b (Np) <- [y (n), 0 ...]: the padded right-hand side in one launch
 __global__ void pad_copy_kernel(const double *__restrict__ y, int64_t n, int64_t Np, double *__restrict__ b) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -567,6 +575,12 @@ int launch_augment_rhs(tgp_ctx *ctx, double *d_A, int64_t Np, int64_t n, const d
 }
 int launch_logdet_rowsq(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_out) {
     logdet_rowsq_kernel<<<1, 1024, 0, ctx->stream>>>(d_A, Np, n, d_out);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_extract_row(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *d_z) {
+    extract_row_kernel<<<(unsigned)((Np + 255) / 256), 256, 0, ctx->stream>>>(d_A, Np, n, d_z);
     TGP_HIP(hipGetLastError());
     return 0;
 }
