@@ -24,6 +24,7 @@ exercise the communication logic under ``gloo`` on CPUs.
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -699,9 +700,7 @@ class DistributedGP(object):
 # ``predict_fields`` and the kept-factor calls (posterior covariance, gp_interp.py:184-192) -- factorise with
 # ``DistributedCholesky`` and shard the query points; everything around them (normalize, white noise, mean function,
 # ``_alpha`` cache, LinAlgError on every rank) is the single-GPU host code, untouched.
-import threading as _threading
-
-_tls = _threading.local()
+_tls = threading.local()
 _process_engine = None
 DEFAULT_MIN_N = 32768            # below this one GPU finishes a solve before eight have exchanged their panels
 
