@@ -194,6 +194,22 @@ def new_ctx(device=0):
     return h
 
 
+class OwnedCtx(object):
+    """An additional context that is destroyed (tgp_destroy) with the last reference to this object -- for the multi-GPU
+    engine, whose contexts must outlive any factor handle created on them."""
+
+    def __init__(self, device=0):
+        self.handle = new_ctx(device)
+
+    def __del__(self):
+        try:
+            if self.handle is not None and _lib is not None:
+                _lib.tgp_destroy(self.handle)
+        except Exception:                 # interpreter shutdown
+            pass
+        self.handle = None
+
+
 def check(ctx, rc, what):
     """rc < 0 -> TgpError with the library's message; rc > 0 is returned to the caller."""
     if rc < 0:

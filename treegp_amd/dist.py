@@ -175,11 +175,12 @@ class RankStreams(object):
         from . import _lib
         lib = _lib.load_library()
         idx = device.index if device.index is not None else 0
+        self._owned = (_lib.OwnedCtx(idx), _lib.OwnedCtx(idx))          # destroyed with this object
         self.side_stream = torch.cuda.Stream(device=device, priority=-1)
-        self.ctx_side = _lib.new_ctx(idx)
+        self.ctx_side = self._owned[0].handle
         lib.tgp_set_stream(self.ctx_side, C.c_void_p(self.side_stream.cuda_stream))
         self.keep_stream = torch.cuda.Stream(device=device)
-        self.ctx_keep = _lib.new_ctx(idx)
+        self.ctx_keep = self._owned[1].handle
         lib.tgp_set_stream(self.ctx_keep, C.c_void_p(self.keep_stream.cuda_stream))
 
 
@@ -722,8 +723,11 @@ class DistEngine(object):
         self.device = device
         self.min_n = int(os.environ.get("TGP_DIST_MIN_N", DEFAULT_MIN_N)) if min_n is None else int(min_n)
         self.profile = bool(profile)
-        self.ctx = _lib.new_ctx(device.index if device.index is not None else 0)     # never the process-wide context:
-        self.streams = RankStreams(device)                                           # its stream follows torch's
+        # never the process-wide context: its stream follows torch's.  Owned: destroyed with the engine and the last factor
+        # handle that was created on it
+        self._owned_ctx = _lib.OwnedCtx(device.index if device.index is not None else 0)
+        self.ctx = self._owned_ctx.handle
+        self.streams = RankStreams(device)
         self._solver = None                   # (n, HipLocalOps, DistributedCholesky) of the last problem size
         self.acc = {}                         # profile=True: phase times (ms, this rank) summed over calls; reset by the caller
 
@@ -795,7 +799,7 @@ class DistEngine(object):
             h = C.c_void_p()
             self._lib.check(self.ctx, self.lib.tgp_factor_borrow(self.ctx, o._p(o.Afull), o._p(o.W), n, C.byref(h)),
                             "tgp_factor_borrow")
-            factor = _ops.Factor(self.ctx, h, n, keepalive=(o.A, o.Afull, o.W))
+            factor = _ops.Factor(self.ctx, h, n, keepalive=(o.A, o.Afull, o.W, self._owned_ctx))
             self._solver = None                              # the buffers now belong to the handle
         return (a if want_alpha else None), logdet, float(np.dot(y, a)), factor
 

@@ -36,7 +36,7 @@ class Factor(object):
 
     def free(self):
         if self._h:
-            _lib.load_library().tgp_factor_free(self._ctx, self._h)
+            _lib.load_library().tgp_factor_free(self._ctx, self._h)     # (synchronises the context's stream first)
             self._h = None
         self._keepalive = None
 
