@@ -215,6 +215,7 @@ class HipLocalOps(object):
         # context) carries the copies that build the replicated factor: they only need a gather to have
         # landed and its buffer not to be reused yet -- off the panel chain, where they cost up to 0.3 ms per panel
         st = streams or RankStreams(device)
+        self._streams = st                    # (owns the two contexts)
         self.side_stream, self.ctx_side, self.keep_stream, self.ctx_keep = st.side_stream, st.ctx_side, st.keep_stream, st.ctx_keep
         # replicated factor for the solves: every panel is seen by every rank anyway (broadcast + all-gather); kept
         # in the single-GPU packed layout it lets the triangular sweeps run locally, without their 2 N/256 collectives
