@@ -221,7 +221,7 @@ def test_ml_fit_and_two_pcf_through_the_api_virtual_ranks():
         # same maximum -- same likelihood there, theta within the reference's own tolerance of the truth (:141)
         np.testing.assert_allclose(out["log-likelihood"][1], single["log-likelihood"][1], rtol=1e-6)
         np.testing.assert_allclose(out["log-likelihood"][0], truth.theta, atol=5e-1)
-        np.testing.assert_allclose(out["log-likelihood"][0], single["log-likelihood"][0], atol=5e-2)
+        np.testing.assert_allclose(out["log-likelihood"][0], single["log-likelihood"][0], atol=1e-1)
 
 
 @pytest.mark.parametrize("G", [2, 4])
