@@ -110,7 +110,14 @@ void tgp_factor_release_to_cache(tgp_ctx *ctx, tgp_factor *f) {
     e->A_cache = f->d_A;
     e->W_cache = f->d_W;
     e->cache_Np = f->Np;
-    if (f->d_slabs) (void)hipFree(f->d_slabs);
+    // its slabs become the context's (the next solve that keeps a factor of this size takes them back, factor_and_solve):
+    // no hipMalloc / hipFree -- a device-wide synchronisation each -- per likelihood evaluation of a gradient-driven fit
+    if (f->d_slabs && !ctx->vslab) {
+        ctx->vslab = f->d_slabs;
+        ctx->vslab_bytes = vslab_bytes(f->Np, f->slab_S);
+    } else if (f->d_slabs) {
+        (void)hipFree(f->d_slabs);
+    }
     if (f->d_slabs2) (void)hipFree(f->d_slabs2);
     delete f;
 }
@@ -158,6 +165,7 @@ void tgp_destroy(tgp_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     if (ctx->vslab) (void)hipFree(ctx->vslab);
+    if (ctx->vslab_tt) (void)hipFree(ctx->vslab_tt);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->h_info) (void)hipHostFree(ctx->h_info);
@@ -378,7 +386,14 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
     } else if (info == 0) {
         rc = launch_pad_copy(ctx, d_y, n, Np, d_b);
         if (rc) return fail(rc);
-        if (own_slabs) {                  // allocated above for the rider, which this schedule did not carry: build them here
+        int S2 = 0;
+        if (keep && !own_slabs && potrs_big_step(Np, &S2) && ctx->vslab && ctx->vslab_bytes == vslab_bytes(Np, S2)) {
+            own_slabs = (double *)ctx->vslab;      // the context's buffer (e.g. handed back by the previous kept factor of this
+            own_S = S2;                            // size, tgp_factor_release_to_cache) moves to the new handle: no hipMalloc
+            ctx->vslab = nullptr;
+            ctx->vslab_bytes = 0;
+        }
+        if (own_slabs) {                  // memory in hand (from the context, or allocated above for a rider that did not run): build here
             rc = launch_vslab_build(ctx, d_A, d_W, Np, own_S, own_slabs);
             if (rc) return fail(rc);
         }

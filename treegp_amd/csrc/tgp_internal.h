@@ -43,6 +43,8 @@ struct tgp_ctx {
     hipEvent_t ev_slab[17] = {nullptr};   // slab-build pipeline (trsv.hip), created on first use
     void *vslab = nullptr;        // inverse slabs of the 1024-row triangular sweeps (trsv_big.hip) when the caller keeps none
     size_t vslab_bytes = 0;
+    void *vslab_tt = nullptr;     // build-time scratch of the slab build (Np x S doubles): one per context, not one per factor
+    size_t vslab_tt_bytes = 0;
     int dist_nqueue = 0;          // queue sets handed out since tgp_dd_queue_reset (multi-GPU driver)
     int chain_exclusive = 0;      // tgp_dd_set_exclusive: diagonal blocks of this context ask for a compute unit of their own
     unsigned *d_queue = nullptr;  // tile-queue counters of the persistent bulk update (TGP_NQUEUE launches x TGP_QUEUE_WORDS)

@@ -352,14 +352,24 @@ __global__ __launch_bounds__(512) void bulk_bwd_kernel(const double *__restrict_
 }
 }  // namespace
 
-size_t vslab_bytes(int64_t Np, int S) { return (size_t)3 * Np * S * sizeof(double); }
+size_t vslab_bytes(int64_t Np, int S) { return (size_t)2 * Np * S * sizeof(double); }
 
-// slabs: [V | Vt | TT], each Np x S.  Nothing is cleared: every part a later kernel reads is written first (vinit_kernel's
+// slabs: [V | Vt], each Np x S; the build's scratch TT (Np x S) belongs to the context, not to the slabs (round 3: a kept factor
+// used to carry a third of dead weight, 0.5 GB at N = 65 536).  Nothing is cleared: every part a later kernel reads is written first (vinit_kernel's
 // corner blocks, the level products, the transposing copies).  Builds the slabs of rows [row_lo, row_hi) (multiples of S, or
 // Np) on stream `st`: super-blocks are independent of each other.
 int launch_vslab_build_range(tgp_ctx *ctx, hipStream_t st, const double *d_A, const double *d_W, int64_t Np, int S, double *slabs,
                              int64_t row_lo, int64_t row_hi) {
-    double *V = slabs, *Vt = slabs + Np * S, *TT = slabs + 2 * Np * S;
+    const size_t tt_need = (size_t)Np * S * sizeof(double);
+    if (tt_need > ctx->vslab_tt_bytes) {          // grow-only; a build in flight on another stream of this context uses the old one
+        TGP_HIP(hipDeviceSynchronize());
+        if (ctx->vslab_tt) TGP_HIP(hipFree(ctx->vslab_tt));
+        ctx->vslab_tt = nullptr;
+        ctx->vslab_tt_bytes = 0;
+        TGP_HIP(hipMalloc(&ctx->vslab_tt, tt_need));
+        ctx->vslab_tt_bytes = tt_need;
+    }
+    double *V = slabs, *Vt = slabs + Np * S, *TT = (double *)ctx->vslab_tt;
     if (row_hi > Np) row_hi = Np;
     if (row_hi <= row_lo) return 0;
     const int64_t span = row_hi - row_lo;

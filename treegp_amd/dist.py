@@ -145,7 +145,8 @@ def local_replicate_vote(lib, Np, G, device, env=None):
     env = os.environ.get("TGP_DIST_REPLICATE") if env is None else env
     if not (G > 1 or env == "1") or env == "0":
         return False
-    full_bytes = int(lib.tgp_panel_elems(Np)) * 8
+    # the copy itself plus what its solves allocate beside it: inverse slabs (2 Np S doubles) and their build scratch (Np S)
+    full_bytes = int(lib.tgp_panel_elems(Np)) * 8 + 3 * Np * 1024 * 8
     return full_bytes < 0.5 * torch.cuda.mem_get_info(device)[0]
 
 
