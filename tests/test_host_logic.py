@@ -359,3 +359,48 @@ def test_ml_gradient_mode_selection(monkeypatch):
         mod.log_likelihood(small, None, None)._use_exact_gradient(vk)
     monkeypatch.setenv("TGP_ML_GRADIENT", "fd")
     assert not mod.log_likelihood(big, None, None)._use_exact_gradient(gauss)
+
+
+def test_multi_gpu_route_selection(monkeypatch):
+    """Which solves take the multi-GPU route (treegp_amd.dist.enable / scope / TGP_DIST, GPInterpolation(backend=...)): host
+    logic only, with a stand-in for the engine (the real one needs a GPU)."""
+    from treegp_amd import dist, ops
+
+    class FakeEngine(object):
+        def __init__(self, comm=None, device=None, min_n=None, profile=False):
+            self.min_n = dist.DEFAULT_MIN_N if min_n is None else int(min_n)
+            self.comm = type("Comm", (), {"size": 2, "rank": 0})()
+
+    monkeypatch.setattr(dist, "DistEngine", FakeEngine)
+    monkeypatch.setattr(ops, "set_pair_comm", lambda comm: None)
+    monkeypatch.delenv("TGP_DIST", raising=False)
+    assert dist.engine_for(10 ** 6) is None                              # nothing enabled: one GPU
+    eng = dist.enable(min_n=1000)
+    try:
+        assert dist.engine_for(999) is None and dist.engine_for(1000) is eng      # never implicit below the threshold
+        assert ops._dist_engine(5000, None) is eng
+        assert ops._dist_engine(5000, object()) is None                  # a caller that names its context stays on its GPU
+        with dist.scope("single"):
+            assert dist.engine_for(10 ** 6) is None
+        with dist.scope("dist"):
+            assert dist.engine_for(5) is eng                             # the explicit kwarg: any size
+            with dist.scope(None):                                       # a nested scope that says nothing changes nothing
+                assert dist.engine_for(5) is eng
+        assert dist.engine_for(5) is None
+    finally:
+        dist.disable()
+    assert dist.engine_for(10 ** 6) is None
+    with pytest.raises(RuntimeError, match="backend"):
+        with dist.scope("dist"):
+            dist.engine_for(5)                                           # no engine, no process group: loud
+    assert dist.engine_for(5) is None                                    # (the scope was left properly)
+    monkeypatch.setenv("TGP_DIST", "1")
+    with pytest.raises(RuntimeError, match="TGP_DIST=1"):
+        dist.engine_for(10 ** 6)                                         # asked for by environment, torch.distributed not up
+    monkeypatch.delenv("TGP_DIST")
+    with pytest.raises(ValueError):
+        dist.scope("gpu")
+    with pytest.raises(ValueError, match="backend"):
+        tg.GPInterpolation(kernel="RBF(1)", optimizer="none", backend="cluster")
+    gp = tg.GPInterpolation(kernel="RBF(1)", optimizer="none", backend="single")
+    assert gp.backend == "single" and tg.GPInterpolation(kernel="RBF(1)", optimizer="none").backend is None
