@@ -198,8 +198,14 @@ def test_ml_fit_and_two_pcf_through_the_api_virtual_ranks():
     X1 = rng.uniform(-10, 10, (n1, 1))
     y1 = rng.multivariate_normal(np.zeros(n1), treegp_amd.eval_kernel(iso)(X1)) + 0.01 * rng.standard_normal(n1)
     e1 = np.full(n1, 0.01)
+    n2 = 2000
+    X2 = rng.uniform(-10, 10, (n2, 2))
+    y2 = rng.multivariate_normal(np.zeros(n2), truth(X2)) + 0.01 * rng.standard_normal(n2)
+    e2 = np.full(n2, 0.01)
     cases = {"log-likelihood": (kern, X, y, y_err, dict()),
-             "two-pcf": (iso, X1, y1, e1, dict(nbins=15, min_sep=0.1, max_sep=1.75))}
+             "two-pcf": (iso, X1, y1, e1, dict(nbins=15, min_sep=0.1, max_sep=1.75)),
+             # the TwoD correlation function with its bootstrap covariance (resamples dealt to the ranks) and the robust 2-D fit
+             "anisotropic": (kern, X2, y2, e2, dict(nbins=21, min_sep=0.0, max_sep=1.0, p0=[0.3, 0.0, 0.0]))}
 
     def fit(opt, backend):
         k, Xc, yc, ec, extra = cases[opt]
@@ -222,6 +228,9 @@ def test_ml_fit_and_two_pcf_through_the_api_virtual_ranks():
         np.testing.assert_allclose(out["log-likelihood"][1], single["log-likelihood"][1], rtol=1e-6)
         np.testing.assert_allclose(out["log-likelihood"][0], truth.theta, atol=5e-1)
         np.testing.assert_allclose(out["log-likelihood"][0], single["log-likelihood"][0], atol=1e-1)
+        # the anisotropic fit: same pixel sums and bootstrap rows to 1e-12, same chi2 minimiser: the same kernel
+        np.testing.assert_allclose(out["anisotropic"][0], single["anisotropic"][0], rtol=1e-5, atol=1e-6)
+        # (against the truth this draw is a 0.76 fluctuation in one component; tests/test_gpu_api.py holds the reference's own draw)
 
 
 @pytest.mark.parametrize("G", [2, 4])
