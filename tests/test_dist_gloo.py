@@ -18,11 +18,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, out_dir, group=None):
+def _worker(rank, world, port, n, out_dir, group=None, gather=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if group is not None:
         os.environ["TGP_DIST_GROUP"] = str(group)
+    if gather is not None:
+        os.environ["TGP_DIST_GATHER"] = gather
     torch.set_num_threads(1)
     lean = group is not None                 # the many-rank cases: one pass with the replicated factor, no side checks
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -37,6 +39,7 @@ def _worker(rank, world, port, n, out_dir, group=None):
         K = np.exp(-0.5 * d2 / 0.1 ** 2) + np.diag(0.05 + 0.01 * rng.uniform(size=n))
         y = rng.standard_normal(n)
         comm = TorchComm()
+        assert gather is None or comm.gather_mode == gather
         ref = np.linalg.solve(K, y)
         for replicated in ((True,) if lean else (False, True)):          # distributed sweeps / sweeps on the replicated factor
             ops = NumpyLocalOps(K, n, world, rank, replicated=replicated)
@@ -90,6 +93,14 @@ def test_distributed_cholesky_gloo_groups_of_four(tmp_path, world, n, group):
     """the schedule the headline size runs (groups of four panels, look-ahead, replicated factor) with 4 and 8 REAL
     processes: more ranks than panels per group, ranks that own no block of a group, a short last group"""
     mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path), group), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
+
+
+def test_distributed_cholesky_gloo_point_to_point_panel_exchange(tmp_path):
+    """TGP_DIST_GATHER=p2p: every panel exchanged by one send + one receive per peer (all xGMI links in parallel on a real
+    node) instead of all_gather_into_tensor; same factor, same solution -- four processes, groups of four panels"""
+    world, n = 4, 1900
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path), 4, "p2p"), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
 
 

@@ -52,6 +52,11 @@ class TorchComm(object):
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self.native_gather = dist.get_backend(group) == "nccl"
+        # TGP_DIST_GATHER=p2p: the panel exchange as one send + one receive per peer instead of all_gather_into_tensor.  xGMI is
+        # point-to-point: a ring all-gather moves (G-1)/G of every panel through ONE link per rank, direct sends use all G-1
+        # links at once.  Off by default until an 8-GPU run says which of the two RCCL's all-gather is on this topology
+        # (DESIGN 7); exercised under gloo on CPUs (tests/test_dist_gloo.py) and, degenerate, with one rank on RCCL.
+        self.gather_mode = os.environ.get("TGP_DIST_GATHER", "allgather")
         self.device = None                   # where host-side reductions have to be staged (RCCL: on the GPU)
         if self.native_gather:
             import torch
@@ -69,10 +74,23 @@ class TorchComm(object):
     def all_gather_start(self, out, inp):
         """Non-blocking all-gather where the backend has one (RCCL runs it on its own stream, so it
         overlaps the kernels queued behind it); returns an object with .wait()."""
+        if self.gather_mode == "p2p" and self.size > 1 and (self.native_gather or not inp.is_cuda):
+            return self._p2p_gather(out, inp)
         if self.native_gather:
             return _Work(self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True), out)
         self.all_gather(out, inp)
         return _Done(out)
+
+    def _p2p_gather(self, out, inp):
+        """every rank's `inp` to every other rank, directly: out[r n : (r+1) n] <- rank r's inp"""
+        dist, n = self.dist, inp.numel()
+        ops = []
+        for step in range(1, self.size):
+            dst, src = (self.rank + step) % self.size, (self.rank - step) % self.size
+            ops.append(dist.P2POp(dist.isend, inp, dst, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, out[src * n:(src + 1) * n], src, group=self.group))
+        out[self.rank * n:(self.rank + 1) * n].copy_(inp)
+        return _Works(dist.batch_isend_irecv(ops), out, stream_ordered=self.native_gather)
 
     def all_gather(self, out, inp):
         """out (size * len(inp)) <- concatenation of every rank's inp"""
@@ -95,6 +113,22 @@ class _Work(object):
 
     def wait(self):
         self.work.wait()
+
+
+class _Works(object):
+    """Several point-to-point transfers in flight (TGP_DIST_GATHER=p2p) and the tensor they fill."""
+
+    def __init__(self, works, tensor, stream_ordered):
+        self.works, self.tensor, self.stream_ordered = works, tensor, stream_ordered
+
+    def wait(self):
+        # RCCL: wait() orders the CURRENT stream behind the transfers, so every stream that reads the panel calls it (side,
+        # keep and main stream do).  gloo: wait() blocks the host until completion and must not be repeated on a finished
+        # request (a second wait on a gloo send / receive never returns).
+        for w in self.works:
+            w.wait()
+        if not self.stream_ordered:
+            self.works = ()
 
 
 class _Done(object):
