@@ -480,6 +480,22 @@ def main():
                                        # of 256 CUs x 4 SIMDs x 16 lanes at 2.4 GHz
                                        "valu_issue_frac_at_2p4ghz": m_rank * n * K / (acc["predict_ms"] * 1e-3) * 16.4 / (256 * 4 * 16 * 2.4e9)}
             out["phases_ms_per_step"] = {k: acc[k] / K for k in ("kbuild_ms", "chol_ms", "trsv_ms", "predict_ms", "syrk_ms")}
+        if not use_dist and not api and not args.no_configs:
+            # the same workload once more through the drop-in API on this one GPU (host buffers in, NumPy out): what the
+            # N > 1 lines, which always step through GPInterpolation, are to be compared with
+            import treegp_amd
+            gp1 = treegp_amd.GPInterpolation(kernel=headline_kernel_string(), optimizer="none", normalize=True, white_noise=0.0,
+                                             backend="single")
+            api_ms = {}
+            for it in range(2):                               # the first pass warms the host-boundary buffers
+                t0 = time.perf_counter()
+                gp1.initialize(X, y, y_err)
+                t1 = time.perf_counter()
+                gp1.predict(Xs)
+                t2 = time.perf_counter()
+                api_ms = {"initialize": (t1 - t0) * 1e3, "predict": (t2 - t1) * 1e3, "total": (t2 - t0) * 1e3}
+            out["api_route_ms_per_step_one_gpu"] = api_ms
+            del gp1
         if not use_dist and not args.no_configs:
             out["configs_measured"] = configs_measured(lib, ctx, ops, _lib)
         if not use_dist and args.cpu_sample > 0:

@@ -282,6 +282,7 @@ def test_bench_line_schema_single_gpu():
     for key in ("value", "unit", "cores", "blas_threads", "kind", "sample", "passes", "phases_s"):
         assert key in cb, key
     assert cb["kind"] == "port" and 1 <= cb["cores"] <= cb["blas_threads"] and cb["passes"] >= 3
+    assert out["api_route_ms_per_step_one_gpu"]["total"] > 0.9 * out["ms_per_step"]       # the same work through GPInterpolation
     # configs[1] and configs[2] ride on the same line
     c1, c2 = out["configs_measured"]
     for key in ("ms", "gp_solves_per_sec", "likelihood_evaluations_per_sec", "cholesky_tflops_fp64", "cholesky_frac_mfma_peak",
