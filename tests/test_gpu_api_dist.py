@@ -132,6 +132,38 @@ def test_default_schedule_at_a_size_that_takes_groups_of_four(tmp_path):
         assert rel < 1e-10, rel
 
 
+def test_config4_problem_with_eight_virtual_ranks_through_the_api(tmp_path):
+    """configs[3] of BASELINE.json in its eight-rank form, through the drop-in API: N = 65 536, groups of four panels, replicated
+    factor, 8 virtual ranks sharing this one GPU (the collectives' payload goes through an in-process communicator, not xGMI).
+    Predictions equal the single-GPU API's at 1e-10 of the field's scale; the solve's residual is at rounding level."""
+    import treegp_amd
+    from treegp_amd import ops
+    from treegp_amd.kernels import kernel_to_spec
+    from treegp_amd.synthetic import star_field, headline_kernel_string
+    n, m, G = 65536, 4096, 8
+    X, y, y_err, Xs = star_field(n, m)
+    kw = dict(kernel=headline_kernel_string(), optimizer="none", normalize=True)
+    one = treegp_amd.GPInterpolation(**kw)
+    one.initialize(X, y, y_err)
+    ref = one.predict(Xs)
+
+    def rank_fn(rank):
+        gp = treegp_amd.GPInterpolation(backend="dist", **kw)
+        gp.initialize(X, y, y_err)
+        yp = gp.predict(Xs)
+        return (yp, gp._alpha.copy()) if rank == 0 else (yp, None)
+
+    res = _virtual_ranks(G, rank_fn)
+    for yp, _ in res:
+        np.testing.assert_allclose(yp, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+    alpha = res[0][1]
+    spec = kernel_to_spec(one.kernel)
+    r = one._y - one._mean
+    Ka = ops.gp_predict(spec, X, alpha, X)
+    rel = np.linalg.norm(Ka + y_err ** 2 * alpha - r) / np.linalg.norm(r)
+    assert rel < 1e-10, rel
+
+
 def test_threshold_route_fields_and_errors_virtual_ranks(tmp_path):
     """An enabled engine takes objects that name no backend once they reach its size threshold and leaves smaller ones
     alone; ``predict_fields`` solves every field against the replicated factor; a matrix that is not positive definite
