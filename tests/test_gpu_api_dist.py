@@ -164,6 +164,64 @@ def test_config4_problem_with_eight_virtual_ranks_through_the_api(tmp_path):
     assert rel < 1e-10, rel
 
 
+def test_config5_full_size_with_eight_virtual_ranks_through_the_api(tmp_path, monkeypatch):
+    """configs[4] of BASELINE.json at full size in its eight-rank form, through the drop-in API: N = 131 072 with the mean-function
+    table (KNN-4) and non-uniform y_err; 8 virtual ranks on this one GPU, so the factor cannot be replicated eight times and the
+    sweeps are the distributed ones (TGP_DIST_REPLICATE=0 -- on a real node every rank has room for its copy).  Against the
+    single-GPU API on the same data: predictions at 1e-10 of the field's scale, and the device residual of the solve."""
+    import treegp_amd
+    from treegp_amd import ops
+    from treegp_amd.kernels import kernel_to_spec
+    monkeypatch.setenv("TGP_DIST_REPLICATE", "0")
+    n, m, G = 131072, 2048, 8
+    X, y, y_err, Xs, X0, y0, kw = _recipe(n, m, tmp_path, seed=20240613)
+    one = treegp_amd.GPInterpolation(**kw)
+    one.initialize(X, y, y_err)
+    ref = one.predict(Xs)
+    assert np.abs(one._spatial_average).max() > 0.02            # the mean function is really there
+
+    def rank_fn(rank):
+        gp = treegp_amd.GPInterpolation(backend="dist", **kw)
+        gp.initialize(X, y, y_err)
+        yp = gp.predict(Xs)
+        return (yp, gp._alpha.copy()) if rank == 0 else (yp, None)
+
+    res = _virtual_ranks(G, rank_fn)
+    for yp, _ in res:
+        np.testing.assert_allclose(yp, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+    alpha = res[0][1]
+    r = one._y - one._mean - one._spatial_average
+    Ka = ops.gp_predict(kernel_to_spec(one.kernel), X, alpha, X)
+    rel = np.linalg.norm(Ka + one._y_err ** 2 * alpha - r) / np.linalg.norm(r)
+    assert rel < 1e-10, rel
+
+
+def test_without_the_replicated_factor(tmp_path, monkeypatch):
+    """TGP_DIST_REPLICATE=0 (or a factor that does not fit beside a rank's share): the solves run as distributed sweeps and
+    give the same predictions; calls that need a kept factor say so on every rank instead of computing something else."""
+    import treegp_amd
+    monkeypatch.setenv("TGP_DIST_REPLICATE", "0")
+    n, m = 2600, 500
+    X, y, y_err, Xs, X0, y0, kw = _recipe(n, m, tmp_path, seed=21)
+    one = treegp_amd.GPInterpolation(**kw)
+    one.initialize(X, y, y_err)
+    ref, ll_ref = one.predict(Xs), one.return_log_likelihood()
+
+    def rank_fn(rank):
+        gp = treegp_amd.GPInterpolation(backend="dist", **kw)
+        gp.initialize(X, y, y_err)
+        yp = gp.predict(Xs)
+        with pytest.raises(NotImplementedError, match="replicated factor"):
+            gp.predict(Xs[:20], return_cov=True)
+        with pytest.raises(NotImplementedError, match="replicated factor"):
+            gp.predict_fields(np.stack([y, y]), Xs)
+        return yp, gp.return_log_likelihood()
+
+    for yp, ll in _virtual_ranks(3, rank_fn):
+        np.testing.assert_allclose(yp, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-11)
+
+
 def test_threshold_route_fields_and_errors_virtual_ranks(tmp_path):
     """An enabled engine takes objects that name no backend once they reach its size threshold and leaves smaller ones
     alone; ``predict_fields`` solves every field against the replicated factor; a matrix that is not positive definite
