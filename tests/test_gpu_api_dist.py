@@ -70,6 +70,7 @@ def _virtual_ranks(G, fn):
         t.start()
     for t in threads:
         t.join(timeout=600)
+    torch.cuda.empty_cache()                  # the ranks' shares (tens of GB at the BASELINE sizes) go back to the device
     assert not errors, errors
     return results
 
