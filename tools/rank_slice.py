@@ -64,3 +64,38 @@ wall, bulk, chain, wait, fl = min(res[1:])
 print("N=%d, rank %d of %d alone on one MI355X (no communication): factorisation %.1f ms wall; bulk update %.1f ms (%.1f TF on "
       "the rank's share); panel chain %.1f ms on the side stream; main stream stalled behind the chain %.1f ms; group size %d"
       % (n, g, G, wall, bulk, fl / bulk / 1e9, chain, wait, chol.group), flush=True)
+
+if len(sys.argv) > 4 and sys.argv[4] == "launches":
+    # per-launch view of the bulk updates (main stream): tiles, time, rate
+    rec = []
+    orig = o.update_group
+
+    def wrapped(k, bufs, cmaxs, col_lo=0, col_hi=-1, side=False, queue_nres=0):
+        if side:
+            return orig(k, bufs, cmaxs, col_lo, col_hi, side=side, queue_nres=queue_nres)
+        e0, e1 = timer(), timer()
+        e0.record()
+        orig(k, bufs, cmaxs, col_lo, col_hi, side=side, queue_nres=queue_nres)
+        e1.record()
+        rec.append((k, col_lo, col_hi, e0, e1))
+
+    o.update_group = wrapped
+    o.kbuild(dX, de)
+    chol.factorize()
+    torch.cuda.synchronize()
+    GS, nB = chol.group, o.nB
+    from treegp_amd.dist import first_ge
+    print("   k  cols        tiles   ms      TF    rounds(512 slots)")
+    for k, lo, hi, e0, e1 in rec:
+        s0 = k + GS
+        tiles = 0
+        b = first_ge(s0, g, G)
+        while b < nB:
+            for half in (0, 1):
+                gti = 2 * (b - s0) + half                       # last valid global tile column of this local tile row
+                top = gti if hi < 0 else min(gti, hi - 1)
+                tiles += max(0, top - lo + 1)
+            b += G
+        ms = e0.elapsed_time(e1)
+        if tiles:
+            print("%4d  %3d..%-4s %7d  %7.3f  %5.1f  %6.1f" % (k, lo, "end" if hi < 0 else hi, tiles, ms, tiles * 2.0 * 128 * 128 * 256 * GS / ms / 1e9, tiles / 512.0))
