@@ -147,6 +147,7 @@ int tgp_init(const int *devices, int ndev, tgp_ctx **out) {
     if (hipMalloc((void **)&ctx->d_info, 256) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_queue, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned)) != hipSuccess) { delete ctx; return -2; }
     if (hipMemset(ctx->d_info, 0, 256) != hipSuccess) { delete ctx; return -2; }
+    if (hipMalloc((void **)&ctx->d_flags, 16 * 64) != hipSuccess || hipMemset(ctx->d_flags, 0, 16 * 64) != hipSuccess) { delete ctx; return -2; }
     if (hipHostMalloc((void **)&ctx->h_info, 256, hipHostMallocDefault) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_scal, 16 * sizeof(double)) != hipSuccess) { delete ctx; return -2; }
     if (hipHostMalloc((void **)&ctx->h_scal, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess) { delete ctx; return -2; }
@@ -168,6 +169,7 @@ void tgp_destroy(tgp_ctx *ctx) {
     if (ctx->vslab_tt) (void)hipFree(ctx->vslab_tt);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->h_info) (void)hipHostFree(ctx->h_info);
     if (ctx->d_scal) (void)hipFree(ctx->d_scal);
     if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);

@@ -26,6 +26,15 @@ __device__ int tgp_queue_stamp_T = 40;
 #endif
 
 namespace {
+// Cross-stream hand-off without an event: this one-thread kernel, queued behind the producer on its stream, publishes a
+// sequence number; the consumer stream waits for it with hipStreamWaitValue32.  From the producer's last kernel ending to the
+// consumer's first kernel starting: 2.7 us, against 10 us for hipEventRecord + hipStreamWaitEvent (and 4.4 us for
+// hipStreamWriteValue32; tools/probes/waitvalue_probe.hip, profiles/r03_waitvalue_probe.txt).  The panel chain of the
+// chain-bound sizes crosses streams twice per pair of panels.
+__global__ void signal_kernel(unsigned *flag, unsigned v) {
+    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // a column of 128-row tiles: tile t uses A rows [128 t, +128), the fixed B block, C rows [128 t, +128)
 template <int MODE, int LDB>
 __global__ __launch_bounds__(256, 2) void gemm_col_kernel(const double *A, const double *B, double *C) {
@@ -639,6 +648,18 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     };
     auto Wk = [&](int k) { return d_W + (int64_t)(2 * k) * TGP_TB * TGP_TB; };
     auto panel = [&](int k) { return d_A + panel_off(k, Np); };
+    // hand-offs between the streams: flags + stream wait-value (signal_kernel above); TGP_SYNC_EVENTS=1: events, as before round 3
+    static const bool sync_events = getenv("TGP_SYNC_EVENTS") != nullptr;
+    auto signal = [&](hipStream_t from, int id, hipEvent_t ev) -> hipError_t {      // after everything queued on `from` so far
+        if (sync_events) return hipEventRecord(ev, from);
+        const unsigned v = ++ctx->flag_seq[id];
+        signal_kernel<<<1, 1, 0, from>>>(ctx->d_flags + 16 * id, v);
+        return hipGetLastError();
+    };
+    auto await = [&](hipStream_t to, int id, hipEvent_t ev) -> hipError_t {          // the last signal() on this id
+        if (sync_events) return hipStreamWaitEvent(to, ev, 0);
+        return hipStreamWaitValue32(to, ctx->d_flags + 16 * id, ctx->flag_seq[id], hipStreamWaitValueGte, 0xffffffffu);
+    };
     // TGP_HEAD_START=1 (A/B): the bulk waits for an event the side stream records once IT has seen the strip update
     // finish, one hop more than the chain's first kernel.  It was the first remedy for the chain waiting behind the bulk's
     // first round of workgroups (measured at N = 8192: 240 us of a 660 us cycle); with the clear compute units of the
@@ -677,9 +698,9 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
         hipStream_t sc = ctx->side_stream, sr = ctx->rest_stream;
         hipEvent_t evP2 = ctx->ev_df[0], evTn = ctx->ev_df[1], evTr = ctx->ev_df[2], evUa1 = ctx->ev_df[3], evFar = ctx->ev_df[4],
                    evJoin = ctx->ev_df[5];
-        TGP_HIP(hipEventRecord(evJoin, st));
-        TGP_HIP(hipStreamWaitEvent(sc, evJoin, 0));
-        TGP_HIP(hipStreamWaitEvent(sr, evJoin, 0));
+        TGP_HIP(signal(st, 2, evJoin));
+        TGP_HIP(await(sc, 2, evJoin));
+        TGP_HIP(await(sr, 2, evJoin));
         bool have_prev = false;
         for (int k = kstart; k < nP; ++k) {
             const int64_t mk = Np - (int64_t)TGP_PW * k;
@@ -689,7 +710,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             const bool queued = Tb <= queue_t && Tb > small_t_pairs && nqueue < TGP_NQUEUE;
             const bool excl = queued || T <= 4;                        // free compute units are guaranteed
             if (mk == TGP_PW) {                                        // last panel: nothing below, nothing to the right
-                if (have_prev) TGP_HIP(hipStreamWaitEvent(sc, evUa1, 0));
+                if (have_prev) TGP_HIP(await(sc, 6, evUa1));
                 factor_panel(sc, Pk, mk, W0, ctx->d_info, k * TGP_PW, excl, n_data);
                 break;
             }
@@ -697,16 +718,16 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             double *Rn = Pk + (int64_t)TGP_PW * TGP_PW;                // row 256: the next diagonal block's rows
             // ---- C: the critical chain
             run_potrf128(sc, Pk, TGP_PW, W0, ctx->d_info, k * TGP_PW, excl);
-            if (have_prev) TGP_HIP(hipStreamWaitEvent(sc, evUa1, 0));   // panel k-1 applied to the rows below this diagonal block
+            if (have_prev) TGP_HIP(await(sc, 6, evUa1));   // panel k-1 applied to the rows below this diagonal block
             gemm_col_small_kernel<0, TGP_TB><<<24, 256, 0, sc>>>(R1, W0, R1);              // rows 128..511: X0 = R0 W0^T
-            TGP_HIP(hipEventRecord(evP2, sc));                          // ("evM0": W0 and L10 are final)
+            TGP_HIP(signal(sc, 3, evP2));                          // ("evM0": W0 and L10 are final)
             gemm_col_small_kernel<1, TGP_PW><<<24, 256, 0, sc>>>(R1, R1, R1 + TGP_TB);     //                R1 -= X0 X0d^T
             run_potrf128(sc, R1 + TGP_TB, TGP_PW, W1, ctx->d_info, k * TGP_PW + TGP_TB, excl);
             gemm_col_small_kernel<0, TGP_TB><<<16, 256, 0, sc>>>(Rn + TGP_TB, W1, Rn + TGP_TB);   // next block's rows: X1 = R1 W1^T
-            TGP_HIP(hipEventRecord(evTn, sc));
+            TGP_HIP(signal(sc, 4, evTn));
             // ---- R1: the rows below the next diagonal block: the two products that need only W0 and L10 start under the
             // chain's second diagonal tile, the third (W1) follows it
-            TGP_HIP(hipStreamWaitEvent(sr, evP2, 0));
+            TGP_HIP(await(sr, 3, evP2));
             const int ntail = T - 2;                                   // 128-row tiles from block k+2 on
             double *Rt = Pk + (int64_t)2 * TGP_PW * TGP_PW;
             if (ntail > 0) {
@@ -718,15 +739,15 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
                     gemm_col_kernel<1, TGP_PW><<<ntail, 256, 0, sr>>>(Rt, R1, Rt + TGP_TB);
                 }
             }
-            TGP_HIP(hipStreamWaitEvent(sr, evTn, 0));
+            TGP_HIP(await(sr, 4, evTn));
             if (ntail > 0) {
                 if (ntail <= df_small_tall) gemm_col_small_kernel<0, TGP_TB><<<ntail * 8, 256, 0, sr>>>(Rt + TGP_TB, W1, Rt + TGP_TB);
                 else gemm_col_kernel<0, TGP_TB><<<ntail, 256, 0, sr>>>(Rt + TGP_TB, W1, Rt + TGP_TB);
             }
-            TGP_HIP(hipEventRecord(evTr, sr));
+            TGP_HIP(signal(sr, 5, evTr));
             // ---- B: block column k+2 first (the chain needs it one cycle from now), then the bulk
             const double *P0 = Rn;                                     // panel k's row of the first trailing row
-            TGP_HIP(hipStreamWaitEvent(st, evTr, 0));
+            TGP_HIP(await(st, 5, evTr));
             if (T > 2) {
                 const int Tf = T - 2;
                 const double *Pf = P0 + (int64_t)2 * TGP_TB * TGP_PW;
@@ -734,13 +755,13 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
                 syrk_strip64_kernel<1><<<(unsigned)((int64_t)2 * Tf * strip), 256, 0, st>>>(d_A, Np, k + 2, Tf, strip, Pf, nullptr);
             }
             // ---- R1: panel k+1's columns below its diagonal block (the previous panel's far strip touched them last)
-            if (have_prev) TGP_HIP(hipStreamWaitEvent(sr, evFar, 0));
+            if (have_prev) TGP_HIP(await(sr, 7, evFar));
             if (T > 2) syrk_strip64_kernel<1><<<(unsigned)((int64_t)2 * (T - 2) * 2), 256, 0, sr>>>(d_A, Np, k + 1, T, 2, P0, nullptr, 2);
             // ---- C: the next diagonal block (panel k-1's far strip touched it last)
-            if (have_prev) TGP_HIP(hipStreamWaitEvent(sc, evFar, 0));
+            if (have_prev) TGP_HIP(await(sc, 7, evFar));
             syrk_small_kernel<1><<<dim3(16u, 2u), 256, 0, sc>>>(d_A, Np, k + 1, 2, P0, nullptr);
-            TGP_HIP(hipEventRecord(evUa1, sr));
-            TGP_HIP(hipEventRecord(evFar, st));
+            TGP_HIP(signal(sr, 6, evUa1));
+            TGP_HIP(signal(st, 7, evFar));
             if (Tb > 0) {
                 const double m = (double)Tb * TGP_TB;
                 const double *Pb = P0 + (int64_t)4 * TGP_TB * TGP_PW;
@@ -767,10 +788,10 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             }
             have_prev = true;
         }
-        TGP_HIP(hipEventRecord(evP2, sc));
-        TGP_HIP(hipEventRecord(evTr, sr));
-        TGP_HIP(hipStreamWaitEvent(st, evP2, 0));
-        TGP_HIP(hipStreamWaitEvent(st, evTr, 0));
+        TGP_HIP(signal(sc, 3, evP2));
+        TGP_HIP(signal(sr, 5, evTr));
+        TGP_HIP(await(st, 3, evP2));
+        TGP_HIP(await(st, 5, evTr));
         return 0;
     };
     static const int df_t = [] { const char *e = getenv("TGP_DF_T"); return e ? atoi(e) : 0; }();      // hand-over of the pairs (tile rows)
@@ -798,22 +819,23 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
                 launch_syrk<2>(st, d_A, Np, k + 2, T2, 0, P0, P1);
                 return run_diagfirst(k + 2);
             }
+            const int T3 = T2 - 4;
+            // chain-bound steps: the bulk runs as a persistent grid that keeps one compute unit per shader engine clear
+            // for the side stream, and the diagonal blocks insist on a compute unit of their own
+            const bool queued = T3 <= queue_t && T3 > small_t_pairs && nqueue < TGP_NQUEUE;
             {   // U2a: tile columns 0..3 (panels k+2, k+3)
                 const double rows = (double)T2 * TGP_TB, w = (T2 < 4 ? T2 : 4) * (double)TGP_TB;
                 const double elems = w * (rows - w) + w * (w + 1.0) / 2.0;
                 int rc = timed([&] { launch_syrk<2>(st, d_A, Np, k + 2, T2, 4, P0, P1); }, 2.0 * 2.0 * TGP_PW * elems);
                 if (rc) return rc;
             }
-            TGP_HIP(hipEventRecord(ctx->ev[4], st));
-            TGP_HIP(hipStreamWaitEvent(sd, ctx->ev[4], 0));
-            const int T3 = T2 - 4;
-            // chain-bound steps: the bulk runs as a persistent grid that keeps one compute unit per shader engine clear
-            // for the side stream, and the diagonal blocks insist on a compute unit of their own
-            const bool queued = T3 <= queue_t && T3 > small_t_pairs && nqueue < TGP_NQUEUE;
+            TGP_HIP(signal(st, 0, ctx->ev[4]));
+            TGP_HIP(await(sd, 0, ctx->ev[4]));
             if (queued) TGP_HIP(head_start(sd));      // off by default, see above
             factor_pair(sd, k + 2, queued);
-            TGP_HIP(hipEventRecord(ctx->ev[5], sd));
-            {
+            TGP_HIP(signal(sd, 1, ctx->ev[5]));
+            if (riding && !rider_paused) {
+                if (!sync_events) TGP_HIP(hipEventRecord(ctx->ev[5], sd));      // the rider follows an event
                 int rc = rider_follow(ctx->ev[5], k + 4 < nP ? k + 4 : nP);
                 if (rc) return rc;
             }
@@ -845,7 +867,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
                 }, 2.0 * TGP_PW * m * (m + 1.0));
                 if (rc) return rc;
             }
-            TGP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));
+            TGP_HIP(await(st, 1, ctx->ev[5]));
         }
         return 0;
     };
@@ -942,11 +964,12 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
                 int rc = timed([&] { bulk(k, k + 4, T4, 8); }, 2.0 * 4.0 * TGP_PW * elems);
                 if (rc) return rc;
             }
-            TGP_HIP(hipEventRecord(ctx->ev[4], st));
-            TGP_HIP(hipStreamWaitEvent(sd, ctx->ev[4], 0));
+            TGP_HIP(signal(st, 0, ctx->ev[4]));
+            TGP_HIP(await(sd, 0, ctx->ev[4]));
             factor_group(sd, k + 4);
-            TGP_HIP(hipEventRecord(ctx->ev[5], sd));
-            {
+            TGP_HIP(signal(sd, 1, ctx->ev[5]));
+            if (riding && !rider_paused) {
+                if (!sync_events) TGP_HIP(hipEventRecord(ctx->ev[5], sd));      // the rider follows an event
                 int rc = rider_follow(ctx->ev[5], k + 8 < nP ? k + 8 : nP);
                 if (rc) return rc;
             }
@@ -956,7 +979,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
                 int rc = timed([&] { bulk(k, k + 8, T5, 0); }, 4.0 * TGP_PW * m * (m + 1.0));
                 if (rc) return rc;
             }
-            TGP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));
+            TGP_HIP(await(st, 1, ctx->ev[5]));
         }
     } else if (mode == 2) {
         int rc = run_pairs(0, true);

@@ -29,6 +29,8 @@ struct tgp_ctx {
     hipStream_t side_stream = nullptr; // high-priority stream for the Cholesky look-ahead
     hipStream_t rest_stream = nullptr; // diagonal-first schedule (chol.hip): the rest of a panel and its near strips
     hipEvent_t ev_df[8] = {nullptr};   // its cross-stream events (no timing), created with the stream
+    unsigned *d_flags = nullptr;       // cross-stream hand-off flags (chol.hip: hand-offs by stream wait-value), 16 x 64 B
+    unsigned flag_seq[16] = {0};       // last value signalled on each (monotonic over the context's life)
     bool ext_stream = false;           // stream was set by tgp_set_stream
     std::string err;
     double timings[TGP_NTIMINGS] = {0};
