@@ -653,6 +653,14 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     static const bool sync_events = getenv("TGP_SYNC_EVENTS") != nullptr;
     auto signal = [&](hipStream_t from, int id, hipEvent_t ev) -> hipError_t {      // after everything queued on `from` so far
         if (sync_events) return hipEventRecord(ev, from);
+        if (ctx->flag_seq[id] >= 0xfffffff0u) {
+            // the sequence numbers are about to wrap (days of continuous use): let everything queued finish -- every wait that
+            // was issued is then satisfied -- and start all flags of this context again from zero
+            hipError_t e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemset(ctx->d_flags, 0, 16 * 64);
+            if (e != hipSuccess) return e;
+            for (unsigned &q : ctx->flag_seq) q = 0;
+        }
         const unsigned v = ++ctx->flag_seq[id];
         signal_kernel<<<1, 1, 0, from>>>(ctx->d_flags + 16 * id, v);
         return hipGetLastError();
