@@ -149,6 +149,7 @@ def test_golden_config1_and_aniso2d(tg, golden):
                                  {"TGP_CHOL_MODE": "4"}, {"TGP_CHOL_MODE": "2", "TGP_DF_T": "12"}, {"TGP_CHOL_MODE": "4", "TGP_DF_SMALL_TALL": "0"},
                                  {"TGP_PREDICT_EXP": "0"}, {"TGP_PREDICT_EXP": "32"}, {"TGP_PREDICT_EXP": "64"},
                                  {"TGP_NO_AUGMENT_ALPHA": "1"}, {"TGP_SYNC_EVENTS": "1"}, {"TGP_SYNC_EVENTS": "1", "TGP_CHOL_MODE": "4"},
+                                 {"TGP_FLAG_SEQ_START": "4294967274"},       # the hand-off sequence numbers wrap during this solve
                                  {"TGP_RIDER": "2"}, {"TGP_RIDER": "1", "TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "8"}])
 def test_alternative_kernel_paths_agree(env):
     """The A/B switches kept in the library (older tiles, schedules and diagonal-block kernels) must stay correct:

@@ -148,6 +148,13 @@ int tgp_init(const int *devices, int ndev, tgp_ctx **out) {
     if (hipMalloc((void **)&ctx->d_queue, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned)) != hipSuccess) { delete ctx; return -2; }
     if (hipMemset(ctx->d_info, 0, 256) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_flags, 16 * 64) != hipSuccess || hipMemset(ctx->d_flags, 0, 16 * 64) != hipSuccess) { delete ctx; return -2; }
+    if (const char *e = getenv("TGP_FLAG_SEQ_START")) {      // test hook: start the hand-off sequence numbers near their wrap-around
+        const unsigned v0 = (unsigned)strtoul(e, nullptr, 10);
+        unsigned h[16 * 16];
+        for (unsigned &x : h) x = v0;
+        if (hipMemcpy(ctx->d_flags, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return -2; }
+        for (unsigned &q : ctx->flag_seq) q = v0;
+    }
     if (hipHostMalloc((void **)&ctx->h_info, 256, hipHostMallocDefault) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_scal, 16 * sizeof(double)) != hipSuccess) { delete ctx; return -2; }
     if (hipHostMalloc((void **)&ctx->h_scal, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess) { delete ctx; return -2; }
