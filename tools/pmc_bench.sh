@@ -13,8 +13,9 @@ mkdir -p $R/gpurun_out
 hipcc --offload-arch=gfx950 -O2 -w -o /tmp/fetch_calib $R/tools/probes/fetch_calib.hip
 cd /tmp && export TMPDIR=/tmp
 # Under counter collection rocprofv3 serialises the dispatches of the intercepted queues, and a stream blocked in
-# hipStreamWaitValue32 (the factorisation's cross-stream hand-offs since round 3) then never gets going: the passes below hung
-# for 7 minutes until the box's watchdog ended them.  The kernels and their traffic are the same with event hand-offs:
+# hipStreamWaitValue32 (the factorisation's cross-stream hand-offs since round 3) then never gets going: these passes once hung
+# for 7 minutes until the box's watchdog ended them.  The library now falls back to event hand-offs by itself when it sees
+# ROCPROF_COUNTER_COLLECTION (set by rocprofv3 --pmc); the kernels and their traffic are the same.  Belt and braces:
 export TGP_SYNC_EVENTS=1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmccal_$C -- /tmp/fetch_calib > $R/gpurun_out/pmccal_$C.log 2>&1

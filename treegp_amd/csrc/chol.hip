@@ -650,7 +650,9 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     auto Wk = [&](int k) { return d_W + (int64_t)(2 * k) * TGP_TB * TGP_TB; };
     auto panel = [&](int k) { return d_A + panel_off(k, Np); };
     // hand-offs between the streams: flags + stream wait-value (signal_kernel above); TGP_SYNC_EVENTS=1: events, as before round 3
-    static const bool sync_events = getenv("TGP_SYNC_EVENTS") != nullptr;
+    // Under rocprofv3 counter collection (--pmc sets ROCPROF_COUNTER_COLLECTION) the profiler serialises the dispatches of the
+    // queues it intercepts and a stream parked in hipStreamWaitValue32 never gets going (observed: a 7-minute hang): events there.
+    static const bool sync_events = getenv("TGP_SYNC_EVENTS") != nullptr || getenv("ROCPROF_COUNTER_COLLECTION") != nullptr;
     auto signal = [&](hipStream_t from, int id, hipEvent_t ev) -> hipError_t {      // after everything queued on `from` so far
         if (sync_events) return hipEventRecord(ev, from);
         if (ctx->flag_seq[id] >= 0xfffffff0u) {
