@@ -251,8 +251,12 @@ int launch_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t
     TGP_ARG(n > 0 && m > 0);
     const KParams p = make_kparams(k);
     const int64_t qblocks = (m + 255) / 256;
-    // enough workgroups for ~8 per CU, but never split finer than one LDS tile
-    int64_t nsplit = (2048 + qblocks - 1) / qblocks;
+    // Many more workgroups than slots (256 CUs x 7 resident at 70 VGPRs = 1792), but never split finer than one LDS tile: with
+    // 2048 equal workgroups the last 256 ran one per CU after the other 1792 had finished (9.06 ms at N = 65 536 / M = 262 144);
+    // 3584 / 7168 / 14 336 / 28 672 workgroups: 8.54 / 8.39 / 8.28 / 8.27 ms = 2.07e12 pairs/s (profiles/r03_predict_exp.txt).
+    // Forcing 8 waves per SIMD instead (41 VGPRs, everything resident at once) is slower: 9.9 ms.
+    static const int64_t wg_target = [] { const char *e = getenv("TGP_PREDICT_WGS"); return e ? (int64_t)atoll(e) : (int64_t)14336; }();
+    int64_t nsplit = (wg_target + qblocks - 1) / qblocks;
     const int64_t maxsplit = (n + PT - 1) / PT;
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
