@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fused predict alone (random alpha, no solve) at the three BASELINE shapes, best of 6: pairs/s.  A/B two builds with TGP_LIB_PATH=..."""
+"""Fused predict alone (random alpha, no solve) at the three BASELINE shapes, best of 6: pairs/s.  A/B two builds with TGP_LIB_PATH=...; --vk: von Karman (generic kernel)."""
 import ctypes as C
 import sys
 
@@ -13,6 +13,10 @@ lib, ctx = _lib.load_library(), _lib.get_ctx()
 lib.tgp_set_profiling(ctx, 1)
 iL = headline_invlam()
 spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=iL[0, 0], b=iL[0, 1], c=iL[1, 1])
+vk = "--vk" in sys.argv
+if vk:
+    sys.argv.remove("--vk")
+    spec = ops.KernelSpec(_lib.TGP_VK, amp=1.0, ell=0.1)
 for n in [int(v) for v in sys.argv[1:]] or (8192, 32768, 65536):
     X, y, ye, Xs = star_field(n, 4 * n)
     alpha = np.random.default_rng(1).standard_normal(n)
