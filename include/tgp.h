@@ -233,8 +233,11 @@ int tgp_d_potrs_multi(tgp_ctx *ctx, const double *d_A, const double *d_W, int64_
 /* unpack the lower triangle into a dense (n, n) row-major host matrix (upper part zero) */
 int tgp_d_unpack_lower(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, double *out);
 /* ---- multi-GPU tier (one process per GPU; driver: treegp_amd/dist.py) ------------------------
- * Row-block-cyclic over 256-row blocks: rank g of G owns blocks b = g, g+G, ...  Its share of
- * panel p (blocks b >= p) is stored like a single-GPU panel at element offset
+ * Row-block-cyclic over 256-row blocks with the deal reflected every G blocks: round q = b / G gives
+ * rank g block q G + g when q is even and q G + (G-1-g) when q is odd, so that the lower triangle's
+ * work (block row b carries b + 1 block columns) is even over the ranks.  A rank's local index of block
+ * b is b / G; an all-gathered panel is [rank][cmax][256][256] with cmax = the most blocks any rank holds.
+ * A rank's share of panel p (blocks b >= p) is stored like a single-GPU panel at element offset
  * tgp_dist_panel_off(p).  h_loff / d_loff are host / device copies of those offsets (Np/256+1
  * entries).  These calls only enqueue work on the context stream (tgp_set_stream points it at the
  * caller's stream so that RCCL collectives order with it); they replace, per panel, the same
@@ -277,6 +280,15 @@ int tgp_dd_queue_reset(tgp_ctx *ctx);
 int tgp_dd_set_exclusive(tgp_ctx *ctx, int on);
 int tgp_dd_update_group_queued(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
                                int nseg, const double *const *d_gathered, const int *cmax, int col_lo, int col_hi, int nres);
+/* the whole update after a group in ONE launch, the tile columns [0, head_cols) first; the launch publishes a flag when
+ * they are done and tgp_dd_wait_head parks the stream of `waiter` (the panel chain's context) on it.  Only where
+ * tgp_handoff_mode(ctx) == 1 (hand-offs by stream wait-value; 2 = events: split the update in two calls instead).   */
+int tgp_dd_update_group_fused(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
+                              const double *const *d_gathered, const int *cmax, int head_cols, int nres);
+int tgp_dd_wait_head(tgp_ctx *ctx, tgp_ctx *waiter);
+/* how this context's streams hand over to each other: 1 = flags + hipStreamWaitValue32, 2 = events (chosen by a first-use
+ * trial per device, or TGP_SYNC_EVENTS=1 / 0) */
+int tgp_handoff_mode(tgp_ctx *ctx);
 /* Replicated factor for the solves: store panel kpanel into d_Afull, a full single-GPU packed matrix
  * (tgp_panel_elems(Np) doubles) kept on every rank -- its 256x256 diagonal block from the broadcast buffer
  * (d_bcast, may be NULL) and/or the rows below it from the all-gathered panel (d_gathered, may be NULL).

@@ -5,7 +5,7 @@ import threading
 import numpy as np
 import torch
 
-from treegp_amd.dist import BLK, BCAST_ELEMS, first_ge, panel_blocks
+from treegp_amd.dist import BLK, BCAST_ELEMS, block_of, gathered_index, panel_blocks, panel_cmax
 
 
 class ThreadComm(object):
@@ -78,10 +78,10 @@ class NumpyLocalOps(object):
         self.Np = (n + BLK - 1) // BLK * BLK
         self.nB = self.Np // BLK
         self.nloc = panel_blocks(0, self.nB, g, G)
-        self.cmax0 = -(-max(self.nB - 1, 0) // G)
+        self.cmax0 = panel_cmax(1, self.nB, G)
         Kp = np.eye(self.Np)
         Kp[:n, :n] = Kfull
-        self.blocks = [g + lb * G for lb in range(self.nloc)]
+        self.blocks = [block_of(lb, g, G) for lb in range(self.nloc)]
         self.rows = {b: Kp[b * BLK:(b + 1) * BLK, :].copy() for b in self.blocks}     # full-width rows
         self.bcast = torch.zeros(BCAST_ELEMS, dtype=torch.float64)
         self._info = 0
@@ -103,8 +103,7 @@ class NumpyLocalOps(object):
         handle.wait()
         P = gathered.numpy()
         for b in range(k + 1, self.nB):
-            r = b % self.G
-            idx = (b - first_ge(k + 1, r, self.G)) // self.G
+            r, idx = gathered_index(b, k + 1, self.G)
             o = (r * cmax + idx) * BLK * BLK
             self.Lfull[b * BLK:(b + 1) * BLK, k * BLK:(k + 1) * BLK] = P[o:o + BLK * BLK].reshape(BLK, BLK)
 
@@ -166,8 +165,7 @@ class NumpyLocalOps(object):
             col_hi = ncol
 
         def blk(s, b):
-            r = b % G
-            idx = (b - first_ge(k + s + 1, r, G)) // G
+            r, idx = gathered_index(b, k + s + 1, G)
             o = (r * cmaxs[s] + idx) * BLK * BLK
             return Ps[s][o:o + BLK * BLK].reshape(BLK, BLK)
         for bi in self.blocks:
@@ -190,8 +188,7 @@ class NumpyLocalOps(object):
             col_hi = ncol
 
         def blk(P, cmax, first, b):
-            r = b % G
-            idx = (b - first_ge(first, r, G)) // G
+            r, idx = gathered_index(b, first, G)
             o = (r * cmax + idx) * BLK * BLK
             return P[o:o + BLK * BLK].reshape(BLK, BLK)
         for bi in self.blocks:
@@ -215,8 +212,7 @@ class NumpyLocalOps(object):
             col_hi = ncol
 
         def blk(b):
-            r = b % G
-            idx = (b - first_ge(k + 1, r, G)) // G
+            r, idx = gathered_index(b, k + 1, G)
             o = (r * cmax + idx) * BLK * BLK
             return P[o:o + BLK * BLK].reshape(BLK, BLK)
         for bi in self.blocks:

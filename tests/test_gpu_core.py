@@ -140,19 +140,17 @@ def test_golden_config1_and_aniso2d(tg, golden):
     np.testing.assert_allclose(yp, g["y_pred"], rtol=0, atol=1e-10 * np.abs(g["y_pred"]).max())
 
 
-@pytest.mark.parametrize("env", [{"TGP_SYRK_TILE": "0"}, {"TGP_SYRK_TILE": "8"}, {"TGP_POTRF_VARIANT": "1"},
-                                 {"TGP_POTRF_VARIANT": "0"}, {"TGP_SMALL_T": "0", "TGP_SMALL_ROWS": "0"},
+@pytest.mark.parametrize("env", [{"TGP_SMALL_T": "0", "TGP_SMALL_ROWS": "0"},
                                  {"TGP_CHOL_MODE": "0"}, {"TGP_CHOL_MODE": "1"}, {"TGP_CHOL_MODE": "2"},
                                  {"TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "0"}, {"TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "8"},
                                  {"TGP_CHOL_MODE": "3", "TGP_SMALL_T": "0", "TGP_SMALL_ROWS": "0"}, {"TGP_PREDICT_GENERIC": "1"},
-                                 {"TGP_QUEUE_T": "0"}, {"TGP_STRIP64_T": "0"}, {"TGP_NO_AUGMENT": "1"}, {"TGP_QUEUE_T": "200", "TGP_HEAD_START": "1"},
-                                 {"TGP_CHOL_MODE": "4"}, {"TGP_CHOL_MODE": "2", "TGP_DF_T": "12"}, {"TGP_CHOL_MODE": "4", "TGP_DF_SMALL_TALL": "0"},
+                                 {"TGP_QUEUE_T": "0"}, {"TGP_QUEUE_T": "200"}, {"TGP_STRIP64_T": "0"}, {"TGP_NO_AUGMENT": "1"},
                                  {"TGP_PREDICT_EXP": "0"}, {"TGP_PREDICT_EXP": "32"}, {"TGP_PREDICT_EXP": "64"},
-                                 {"TGP_NO_AUGMENT_ALPHA": "1"}, {"TGP_SYNC_EVENTS": "1"}, {"TGP_SYNC_EVENTS": "1", "TGP_CHOL_MODE": "4"},
-                                 {"TGP_FLAG_SEQ_START": "4294967274"},       # the hand-off sequence numbers wrap during this solve
-                                 {"TGP_RIDER": "2"}, {"TGP_RIDER": "1", "TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "8"}])
+                                 {"TGP_NO_AUGMENT_ALPHA": "1"}, {"TGP_SYNC_EVENTS": "1"}, {"TGP_SYNC_EVENTS": "0"},
+                                 {"TGP_SYNC_EVENTS": "1", "TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "8"},
+                                 {"TGP_FLAG_SEQ_START": "4294967274"}])      # the hand-off sequence numbers wrap during this solve
 def test_alternative_kernel_paths_agree(env):
-    """The A/B switches kept in the library (older tiles, schedules and diagonal-block kernels) must stay correct:
+    """The A/B switches kept in the library (schedules, tile thresholds, hand-off mechanism) must stay correct:
     each one solves and predicts the same problem in a fresh process (the switches are read once per process)."""
     import os
     import subprocess

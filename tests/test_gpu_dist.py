@@ -57,6 +57,31 @@ def test_virtual_ranks_queued_bulk(G, n, group, units, monkeypatch):
     _run_virtual_ranks(G, n)
 
 
+@pytest.mark.parametrize("G,n,group,units", [(2, 5000, 4, "0"), (8, 6000, 4, "0"), (3, 4000, 2, "2")])
+def test_virtual_ranks_split_update_with_events(G, n, group, units, monkeypatch):
+    """The two-launch form of a group's update (head columns, event, rest) that the driver falls back to where stream
+    wait-value hand-offs are not available (csrc/handoff.hip's trial, TGP_SYNC_EVENTS=1); the default everywhere else in this
+    file is the fused launch that releases the panel chain from inside the kernel."""
+    monkeypatch.setenv("TGP_DIST_GROUP", str(group))
+    monkeypatch.setenv("TGP_DIST_QUEUE", units)
+    monkeypatch.setenv("TGP_DIST_FUSED", "0")
+    _run_virtual_ranks(G, n)
+
+
+def test_hand_offs_by_stream_wait_value_pass_their_trial_here():
+    """On a plain GPU box the first-use trial of csrc/handoff.hip (consumer parked first, producer second, host timeout)
+    must choose flags + hipStreamWaitValue32 -- a silent fall-back to events would cost 5 - 9 % at N <= 8192 and the fused
+    multi-GPU launch -- and TGP_SYNC_EVENTS=1 (the profiler setting) must choose events."""
+    import subprocess
+    from treegp_amd import _lib
+    lib = _lib.load_library()
+    assert lib.tgp_handoff_mode(_lib.new_ctx(0)) == 1
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); from treegp_amd import _lib; print('mode', _lib.load_library().tgp_handoff_mode(_lib.new_ctx(0)))" % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TGP_SYNC_EVENTS="1"), capture_output=True, text=True, timeout=300)
+    assert "mode 2" in r.stdout, r.stdout + r.stderr
+
+
 def _run_virtual_ranks(G, n):
     import torch
     from treegp_amd import _lib, ops
@@ -188,6 +213,49 @@ def test_update_entry_points_agree():
     assert torch.equal(outs[0], outs[1])
     assert not torch.equal(outs[0], base)
     _lib.load_library().tgp_reset_stream(ops_.ctx)
+
+
+@pytest.mark.parametrize("G,g,n,ns", [(1, 0, 2300, 2), (3, 1, 5200, 4), (8, 7, 9000, 4), (8, 0, 9000, 3), (4, 2, 3000, 1)])
+def test_fused_update_equals_the_two_launches(G, g, n, ns):
+    """tgp_dd_update_group_fused (head columns first, the rest behind them in the same launch, XCD-balanced tail, flag
+    published from inside) writes the same bytes as the head launch + the rest launch, plain and as the persistent grid,
+    on one rank's share of a G-rank layout; and it releases a stream parked on tgp_dd_wait_head."""
+    import torch
+    from treegp_amd import _lib
+    from treegp_amd.dist import HipLocalOps, BLK, panel_cmax
+    from treegp_amd._lib import as_xy
+    spec, X, y, y_err, Xs = _problem(n, 10)
+    dev = torch.device("cuda", 0)
+    o = HipLocalOps(_lib.new_ctx(0), spec, len(y), G, g, dev, replicate=False)
+    if not o.fused_ok():
+        pytest.skip("hand-offs by events on this box")
+    dX, de = o.to_device(as_xy(X)), o.to_device(y_err)
+    o.kbuild(dX, de)
+    torch.cuda.synchronize()
+    base = o.A.clone()
+    rng = np.random.default_rng(G * 10 + g)
+    cm = [panel_cmax(s + 1, o.nB, G) for s in range(ns)]
+    bufs = [o.to_device(1e-3 * rng.standard_normal(max(G * c, 1) * BLK * BLK)) for c in cm]
+    outs = []
+    for variant in range(4):
+        o.A.copy_(base)
+        if variant == 0:
+            o.update_group(0, bufs, cm, 0, 2 * ns)
+            o.update_group(0, bufs, cm, 2 * ns, -1)
+        elif variant == 1:
+            o.update_group(0, bufs, cm, 0, -1)
+        else:
+            o.queue_reset()
+            o.update_group_fused(0, bufs, cm, 2 * ns, queue_nres=0 if variant == 2 else 2)
+            o.side_wait_head()
+            with o.on_side():
+                marker = torch.ones(1, device=dev)          # runs only once the head is done
+        torch.cuda.synchronize()
+        outs.append(o.A.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
+    assert not torch.equal(outs[0], base) or o.nloc == 0
+    assert float(marker[0]) == 1.0
+    _lib.load_library().tgp_reset_stream(o.ctx)
 
 
 def test_driver_on_rccl_backend_world_of_one():

@@ -9,8 +9,8 @@ S=$(mktemp /tmp/chol_XXXX.s)
 get() { awk -v pat="$1" '$0 ~ "^"pat {f=1} f && /amdhsa_next_free_vgpr/ {print $2; exit}' $S; }
 P=$(get "_ZN8potrf_v215potrf128_kernelILb1")
 B4=$(get "_ZN12_GLOBAL__N_116syrk_segs_kernelILi4")
-B2=$(get "_ZN12_GLOBAL__N_115syrk_dtv_kernelILi4ELi2")
+B2=$(get "_ZN12_GLOBAL__N_115syrk_dtv_kernelILi2")
 D4=$(get "_ZN12_GLOBAL__N_117syrk_distn_kernelILi4")
 rm -f $S
-echo "next_free_vgpr: potrf128_kernel<true> = $P (budget 264); syrk_segs_kernel<4> = $B4, syrk_dtv_kernel<4,2> = $B2, syrk_distn_kernel<4> = $D4 (budget 248)"
+echo "next_free_vgpr: potrf128_kernel<true> = $P (budget 264); syrk_segs_kernel<4> = $B4, syrk_dtv_kernel<2> = $B2, syrk_distn_kernel<4> = $D4 (budget 248)"
 [ "$P" -le 264 ] && [ "$B4" -le 248 ] && [ "$B2" -le 248 ] && [ "$D4" -le 248 ]

@@ -80,22 +80,33 @@ if len(sys.argv) > 4 and sys.argv[4] == "launches":
         rec.append((k, col_lo, col_hi, e0, e1))
 
     o.update_group = wrapped
+    orig_fused = o.update_group_fused
+
+    def wrapped_fused(k, bufs, cmaxs, head_cols, queue_nres=0):
+        e0, e1 = timer(), timer()
+        e0.record()
+        orig_fused(k, bufs, cmaxs, head_cols, queue_nres=queue_nres)
+        e1.record()
+        rec.append((k, 0, -1, e0, e1))
+
+    o.update_group_fused = wrapped_fused
     o.kbuild(dX, de)
     chol.factorize()
     torch.cuda.synchronize()
     GS, nB = chol.group, o.nB
-    from treegp_amd.dist import first_ge
+    from treegp_amd.dist import block_of, first_round
     print("   k  cols        tiles   ms      TF    rounds(512 slots)")
     for k, lo, hi, e0, e1 in rec:
         s0 = k + GS
         tiles = 0
-        b = first_ge(s0, g, G)
-        while b < nB:
+        q = first_round(s0, g, G)
+        while block_of(q, g, G) < nB:
+            b = block_of(q, g, G)
             for half in (0, 1):
                 gti = 2 * (b - s0) + half                       # last valid global tile column of this local tile row
                 top = gti if hi < 0 else min(gti, hi - 1)
                 tiles += max(0, top - lo + 1)
-            b += G
+            q += 1
         ms = e0.elapsed_time(e1)
         if tiles:
             print("%4d  %3d..%-4s %7d  %7.3f  %5.1f  %6.1f" % (k, lo, "end" if hi < 0 else hi, tiles, ms, tiles * 2.0 * 128 * 128 * 256 * GS / ms / 1e9, tiles / 512.0))

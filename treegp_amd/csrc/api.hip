@@ -55,15 +55,6 @@ int tgp_ensure_side_stream(tgp_ctx *ctx) {
     return 0;
 }
 
-int tgp_ensure_rest_stream(tgp_ctx *ctx) {
-    if (ctx->rest_stream) return 0;
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    TGP_HIP(hipStreamCreateWithPriority(&ctx->rest_stream, hipStreamNonBlocking, hi));
-    for (auto &e : ctx->ev_df) TGP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    return 0;
-}
-
 int tgp_ensure_scratch2(tgp_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->scratch2_bytes) return 0;
     if (ctx->scratch2) TGP_HIP(hipFree(ctx->scratch2));
@@ -154,6 +145,7 @@ int tgp_init(const int *devices, int ndev, tgp_ctx **out) {
         for (unsigned &x : h) x = v0;
         if (hipMemcpy(ctx->d_flags, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return -2; }
         for (unsigned &q : ctx->flag_seq) q = v0;
+        ctx->head_count = v0;
     }
     if (hipHostMalloc((void **)&ctx->h_info, 256, hipHostMallocDefault) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_scal, 16 * sizeof(double)) != hipSuccess) { delete ctx; return -2; }
@@ -187,9 +179,6 @@ void tgp_destroy(tgp_ctx *ctx) {
     for (auto &ev : ctx->prof_events) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
-    if (ctx->rest_stream) (void)hipStreamDestroy(ctx->rest_stream);
-    for (auto &ev : ctx->ev_df)
-        if (ev) (void)hipEventDestroy(ev);
     delete static_cast<tgp_ctx_full *>(ctx);
 }
 
@@ -323,37 +312,18 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
     double *d_A = e->A_cache, *d_W = e->W_cache;
     double *d_b = (double *)ctx->scratch;
     int rc = 0;
-    // TGP_RIDER > 0: the right-hand side rides along with the factorisation (PotrfRider): the inverse slabs of the sweeps and
-    // the forward substitution are done, super-block by super-block, on a third stream while the trailing update runs; what is
-    // left afterwards is the backward sweep.  Measured net-neutral to negative (chol.hip), so off by default.  Either way a
-    // kept factor owns the slabs built for its solve (nothing is rebuilt at the first covariance / multi-field / gradient call).
+    // A kept factor owns the slabs built for its solve (nothing is rebuilt at the first covariance / multi-field / gradient call).
     static const bool both_sweeps = getenv("TGP_CHI2_BOTH_SWEEPS") != nullptr;      // A/B: y . alpha as before
     const bool forward_only = d_alpha == nullptr && !both_sweeps;                   // only |L^-1 y|^2 is wanted
-    PotrfRider rider;
     double *own_slabs = nullptr;          // slabs that will belong to the kept factor
-    int own_S = 0, S = 0;
-    static const bool rider_on = getenv("TGP_RIDER") && atoi(getenv("TGP_RIDER")) > 0;      // off by default: chol.hip
-    if (rider_on && !augmented && potrs_big_step(Np, &S)) {
-        rc = tgp_ensure_scratch2(ctx, (size_t)Np * sizeof(double));
-        if (rc) return rc;
-        bool build = false;
-        double *slabs = nullptr;
-        rc = acquire_slabs(ctx, Np, S, keep ? &own_slabs : nullptr, keep ? &own_S : nullptr, &slabs, &build);
-        if (rc) return rc;
-        rc = launch_pad_copy(ctx, d_y, n, Np, d_b);
-        if (rc) return rc;
-        rider.d_b = d_b;
-        rider.d_z = (double *)ctx->scratch2;
-        rider.slabs = slabs;
-        rider.S = S;
-    }
+    int own_S = 0;
     auto fail = [&](int code) {
         if (own_slabs) (void)hipFree(own_slabs);
         return code;
     };
     // The solves are queued behind the factorisation without waiting for its verdict (one host round trip less per
     // likelihood evaluation); if a pivot failed they run on a meaningless factor and their result is discarded below.
-    int info = launch_potrf(ctx, d_A, Np, d_W, /*defer_info=*/true, /*n_data=*/n, rider.slabs ? &rider : nullptr);
+    int info = launch_potrf(ctx, d_A, Np, d_W, /*defer_info=*/true, /*n_data=*/n);
     if (info < 0) return fail(info);
     TGP_HIP(hipEventRecord(ctx->ev[2], st));
     double sweeps = 0.0;
@@ -381,17 +351,6 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
             TGP_HIP(hipMemcpyAsync(d_alpha, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
         }
         TGP_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-    } else if (info == 0 && rider.active) {
-        double *d_z = rider.d_z;
-        if (!forward_only) {
-            rc = launch_potrs_big_bwd(ctx, d_A, Np, S, rider.slabs, d_b, d_z);      // alpha = L^-T z
-            if (rc) return fail(rc);
-            sweeps = 1.0;
-        }
-        rc = launch_logdet_dot(ctx, d_A, Np, n, forward_only ? d_z : d_y, forward_only ? d_z : d_b, ctx->d_scal);
-        if (rc) return fail(rc);
-        if (d_alpha) TGP_HIP(hipMemcpyAsync(d_alpha, d_b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        TGP_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     } else if (info == 0) {
         rc = launch_pad_copy(ctx, d_y, n, Np, d_b);
         if (rc) return fail(rc);
@@ -402,7 +361,7 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
             ctx->vslab = nullptr;
             ctx->vslab_bytes = 0;
         }
-        if (own_slabs) {                  // memory in hand (from the context, or allocated above for a rider that did not run): build here
+        if (own_slabs) {                  // memory in hand (from the context): build here
             rc = launch_vslab_build(ctx, d_A, d_W, Np, own_S, own_slabs);
             if (rc) return fail(rc);
         }

@@ -26,15 +26,6 @@ __device__ int tgp_queue_stamp_T = 40;
 #endif
 
 namespace {
-// Cross-stream hand-off without an event: this one-thread kernel, queued behind the producer on its stream, publishes a
-// sequence number; the consumer stream waits for it with hipStreamWaitValue32.  From the producer's last kernel ending to the
-// consumer's first kernel starting: 2.7 us, against 10 us for hipEventRecord + hipStreamWaitEvent (and 4.4 us for
-// hipStreamWriteValue32; tools/probes/waitvalue_probe.hip, profiles/r03_waitvalue_probe.txt).  The panel chain of the
-// chain-bound sizes crosses streams twice per pair of panels.
-__global__ void signal_kernel(unsigned *flag, unsigned v) {
-    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // a column of 128-row tiles: tile t uses A rows [128 t, +128), the fixed B block, C rows [128 t, +128)
 template <int MODE, int LDB>
 __global__ __launch_bounds__(256, 2) void gemm_col_kernel(const double *A, const double *B, double *C) {
@@ -75,18 +66,6 @@ __global__ __launch_bounds__(256, 2) void panel_tall_kernel(double *rows0, const
     gemm_tile_128<0, TGP_TB, TGP_TB>(rows + TGP_TB, W1, rows + TGP_TB);
 }
 
-// The same on the latency tile: 16-row slices, eight workgroups per 128 rows (the diagonal-first schedule's rows below the
-// next diagonal block, when a panel has only a few dozen tiles and the chip is otherwise idle).
-__global__ __launch_bounds__(256) void panel_tall_small_kernel(double *rows0, const double *W0, const double *L10, const double *W1) {
-    double *rows = rows0 + (int64_t)blockIdx.x * 16 * TGP_PW;
-    TGP_CHAIN_PRIO();
-    nt_small_tile<0, TGP_TB, 1>(rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
-    __syncthreads();
-    nt_small_tile<1, TGP_TB, 1>(rows, TGP_PW, L10, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
-    __syncthreads();
-    nt_small_tile<0, TGP_TB, 1>(rows + TGP_TB, TGP_PW, W1, TGP_TB, rows + TGP_TB, TGP_PW, nullptr, nullptr);
-}
-
 // rows 128..255 of a 256 x 256 diagonal block between its two potrf128 calls, one workgroup, one launch:
 // L10 = A10 W0^T, then A11 -= L10 L10^T
 __global__ __launch_bounds__(256, 2) void diag_mid_kernel(double *R1, const double *W0) {
@@ -111,16 +90,15 @@ __global__ __launch_bounds__(256) void syrk_small_kernel(double *Abase, int64_t 
                                    NSEG > 1 ? P1 + obb : nullptr);
 }
 
-// Trailing update C(ti, tj) -= sum over NSEG panels of P[ti] P[tj]^T on the lower-triangular tile set
-// of the trailing matrix that starts at block `ob` (256-row blocks).  P0 / P1 point at the row of
-// the factored panel(s) that corresponds to the first trailing row.
+// Trailing update C(ti, tj) -= sum over NSEG panels of P[ti] P[tj]^T on the lower-triangular tile set of the trailing
+// matrix that starts at block `ob` (256-row blocks), on the DTV tile (gemm_tile.h), 128 x 128 per workgroup, 2 per CU.
+// P0 / P1 point at the row of the factored panel(s) that corresponds to the first trailing row.
 //   strip == 0 : all tiles tj <= ti < T, XCD-aware super-tile enumeration (tilemap)
 //   strip  > 0 : only the first `strip` tile columns (the columns the next panels live in), so
 //                that their factorisation can start before the rest of the update has finished
-template <typename CFG, int NSEG>
-__global__ __launch_bounds__(256, 2) void syrk_trailing_kernel(double *Abase, int64_t Np, int ob, int T, int strip,
-                                                               const double *P0, const double *P1,
-                                                               unsigned long long *stamps = nullptr) {
+template <int NSEG>
+__global__ __launch_bounds__(256, 2) void syrk_dtv_kernel(double *Abase, int64_t Np, int ob, int T, int strip, const double *P0,
+                                                          const double *P1) {
     int ti, tj;
     if (strip == 0) {
         tilemap(blockIdx.x, T, ti, tj);
@@ -130,52 +108,12 @@ __global__ __launch_bounds__(256, 2) void syrk_trailing_kernel(double *Abase, in
         ti = (int)(blockIdx.x / strip);
         if (ti < tj || ti >= T) return;
     }
+    if (strip) TGP_CHAIN_PRIO();
     const int64_t pj = ob + (tj >> 1);
     const int64_t I = (int64_t)TGP_PW * ob + (int64_t)TGP_TB * ti;
     double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
     const int64_t oa = (int64_t)ti * TGP_TB * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
-    gemm_tile_128<1, TGP_PW, TGP_PW, CFG, NSEG>(P0 + oa, P0 + obb, C, stamps ? stamps + 4 * blockIdx.x : nullptr,
-                                                NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
-}
-
-// Same update on the DTV tile (gemm_tile.h): NW = 4 -> 128 x 128 per workgroup (2 per CU), NW = 8 -> 256 x 128
-// (1 per CU, rows in 256-blocks: (bi, tj) with tj <= 2 bi + 1; the upper 128 x 128 block of a diagonal
-// 256-block is updated too -- storage nobody reads -- which wastes 1/T of the flops).
-template <int NW, int NSEG>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void syrk_dtv_kernel(double *Abase, int64_t Np, int ob, int T, int strip,
-                                                                           const double *P0, const double *P1) {
-    int ti, tj;          // ti in units of 32 NW rows
-    if constexpr (NW == 4) {
-        if (strip == 0) {
-            tilemap(blockIdx.x, T, ti, tj);
-            if (ti < 0) return;
-        } else {
-            tj = (int)(blockIdx.x % strip);
-            ti = (int)(blockIdx.x / strip);
-            if (ti < tj || ti >= T) return;
-        }
-    } else {
-        const int T2 = T >> 1;
-        if (strip == 0) {
-            const int64_t b = blockIdx.x;
-            const int half = (int)((b >> 3) & 1);
-            int J;
-            tilemap(((b >> 4) << 3) | (b & 7), T2, ti, J);       // low 3 bits (XCD) stay in place
-            if (ti < 0) return;
-            tj = 2 * J + half;
-        } else {
-            tj = (int)(blockIdx.x % strip);
-            ti = (int)(blockIdx.x / strip);
-            if (ti >= T2 || tj > 2 * ti + 1) return;
-        }
-    }
-    if (strip) TGP_CHAIN_PRIO();
-    constexpr int RM = 32 * NW;
-    const int64_t pj = ob + (tj >> 1);
-    const int64_t I = (int64_t)TGP_PW * ob + (int64_t)RM * ti;
-    double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
-    const int64_t oa = (int64_t)ti * RM * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
-    gemm_tile_dtv<NW, TGP_PW, NSEG>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
+    gemm_tile_dtv<4, TGP_PW, NSEG>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
 }
 
 // Strip updates on the chain's critical path (the tile columns of the next panels) with 64-row tiles: each wave owns
@@ -297,59 +235,6 @@ __global__ __launch_bounds__(256, 2) void syrk_segs_kernel(double *Abase, int64_
     gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, C);
 }
 
-// First-generation 128x128 diagonal-block kernel (kept for A/B runs, TGP_POTRF_VARIANT=0; the
-// default is potrf_v2::potrf128_kernel in potrf128.h).  In-LDS Gauss-Jordan: after step j, columns <= j of T hold L^-1 rows, columns > j the Schur
-// complement; column j of L goes to global memory as soon as it is final.
-__global__ __launch_bounds__(256) void potrf128_lds_kernel(double *A, int lda, double *W, int *info, int base) {
-    constexpr int TS = 129;
-    __shared__ double T[128 * TS];
-    __shared__ double lcol[128], vrow[128];
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < 128 * 128; idx += 256) {
-        const int i = idx >> 7, c = idx & 127;
-        T[i * TS + c] = (c <= i) ? A[(int64_t)i * lda + c] : 0.0;
-    }
-    __syncthreads();
-    const int tr = tid >> 4, tc = tid & 15;
-    for (int j = 0; j < 128; ++j) {
-        const double djj = T[j * TS + j];
-        const double d = sqrt(djj);
-        const double inv = 1.0 / d;
-        if (tid == 0 && !(djj > 0.0)) atomicCAS(info, 0, base + j + 1);
-        __syncthreads();                       // everyone has read T[j][j]
-        if (tid < 128) {
-            const int t = tid;
-            if (t > j) {
-                const double v = T[t * TS + j] * inv;
-                lcol[t] = v;
-                vrow[t] = v;
-                A[(int64_t)t * lda + j] = v;
-            } else if (t == j) {
-                vrow[j] = inv;
-                T[j * TS + j] = inv;
-                A[(int64_t)j * lda + j] = d;
-            } else {
-                const double v = T[j * TS + t] * inv;
-                vrow[t] = v;
-                T[j * TS + t] = v;
-            }
-        }
-        __syncthreads();
-        for (int i = j + 1 + tr; i < 128; i += 16) {
-            const double li = lcol[i];
-            for (int c = tc; c <= i; c += 16) {
-                const double old = (c == j) ? 0.0 : T[i * TS + c];
-                T[i * TS + c] = old - li * vrow[c];
-            }
-        }
-        __syncthreads();
-    }
-    for (int idx = tid; idx < 128 * 128; idx += 256) {
-        const int i = idx >> 7, c = idx & 127;
-        W[idx] = (c <= i) ? T[i * TS + c] : 0.0;
-    }
-}
-
 // multi-GPU trailing update: rank g updates its own block rows, after a GROUP of NSEG consecutive panels
 // kpanel .. kpanel+NSEG-1, in one pass of depth 256 NSEG.
 // Gathered panel s holds the blocks > kpanel+s ([rank][cmax[s]][256][256]); tiles are counted from block kpanel+NSEG.
@@ -357,60 +242,110 @@ template <int NSEG>
 struct DistSegs {
     const double *P[NSEG];
     int cmax[NSEG];
+    int frg[NSEG];            // dist_first_round(kpanel + s + 1, g, G): this rank's first local index inside gathered panel s
 };
 // Tile enumeration of a rank's share, XCD-aware like the single-GPU tilemap: blocks b, b+8, ... share an XCD (and its
 // L2); each XCD works through 8 x 8 super-tiles (8 local tile rows against 8 tile columns) dealt round-robin.  The
 // share is a staircase (local tile row lt reaches up to its own global column), so only super-tiles that contain
 // valid tiles are enumerated: `start` holds, per group of 8 local tile rows, the index of its first super-tile.
+// A rank's launches are short (2 .. 30 rounds of 512 tiles at 8 ranks and N = 65 536), so two things that do not matter
+// on one GPU do here:
+//  * whole super-tiles dealt in turn leave the XCDs up to one super-tile = one full round of an XCD's 64 slots apart:
+//    only the first 8 floor(total / 8) super-tiles are dealt whole, every one of the remaining (< 8) is cut into its 8
+//    tile rows, one per XCD (`whole`);
+//  * the tile columns of the NEXT group of panels (`head_cols`, which the panel chain waits for) and the rest used to
+//    be two launches, each with its own ramp and tail: in the fused form the first `nhead` workgroup indices are the
+//    dense grid of the head columns, the super-tile map of the rest follows, and the workgroup that completes the
+//    last head tile publishes `seq` to `flag`, on which the chain's stream is parked (hipStreamWaitValue32).
 struct DistMap {
     int start[258];           // prefix of super-tiles per row group; start[ngroups] = total  (N up to 262144 on one rank)
-    int ngroups;              // 0: dense enumeration (strips: workgroup b = local tile row b / ncol, column b % ncol)
-    int fb;                   // first block >= kpanel + NSEG this rank owns (host: dist_first_ge)
+    int ngroups;              // 0: dense enumeration only (strips: workgroup b = local tile row b / ncol, column b % ncol)
+    int qfb;                  // local index (= round) of the first block >= kpanel + NSEG this rank owns (host: dist_first_round)
     unsigned ginv;            // floor(2^32 / G) + 1: x / G == (x * ginv) >> 32 for 0 <= x < 65536 (block indices are < 1024); 0 for G == 1
+    int whole;                // 64 floor(total / 8): slots per XCD class that belong to whole super-tiles
+    int nhead, head_cols;     // fused form: workgroup indices below nhead (a multiple of 8) are the dense grid of the head columns
+    unsigned *done, *flag;    // head tiles finished so far (monotonic over launches) / where to publish
+    unsigned target, seq;     // value of *done that completes this launch's head / what to publish then
 };
 __device__ __forceinline__ int div_g(int x, unsigned ginv) { return ginv ? (int)__umulhi((unsigned)x, ginv) : x; }     // ginv == 0: G == 1
+// the reflected owner map of tgp_internal.h (dist_owner / dist_block_of / dist_first_round) in 32 bits: position of rank r in
+// round q and, the same involution, rank at position r of round q
+__device__ __forceinline__ int snake_pos(int q, int r, int G) { return (q & 1) ? G - 1 - r : r; }
+__device__ __forceinline__ int first_round32(int s, int r, int G, unsigned ginv) {
+    const int q = div_g(s, ginv);
+    return q + (snake_pos(q, r, G) < s - G * q ? 1 : 0);
+}
 // one tile of the rank's share: b is the (virtual) workgroup index of the plain launch.  Index arithmetic in 32 bits with a
 // reciprocal of G from the host -- the run-time-G 64-bit divisions of round 2's version (a dozen per tile, scalar code)
 // were 1.6 % of the kernel at depth 1024 (world of one, A/B against the single-GPU kernel inside this driver).
-// Block b' of rank r sits at index (b' - first) / G among r's blocks >= first (b' owned by r: stepping down by G stays >= first).
+// Block b' of rank r sits at index b' / G - dist_first_round(first, r, G) among r's blocks >= first.
+// Every thread of the workgroup takes the same path (b is uniform).
 template <int NSEG>
 __device__ __forceinline__ void syrk_distn_tile(int64_t b, double *Aloc, const int64_t *__restrict__ loff, int kpanel, int G, int g,
                                                 const DistSegs<NSEG> &S, int col_lo, int ncol, int nrows, const DistMap &M) {
     int lt, ct;
-    if (M.ngroups == 0) {
-        lt = (int)(b / ncol);
-        ct = (int)(b - (int64_t)lt * ncol);
-        if (lt >= nrows) return;
+    bool valid = true;
+    const bool head = M.ngroups == 0 || b < M.nhead;
+    if (head) {
+        const int hc = M.ngroups == 0 ? ncol : M.head_cols;
+        lt = (int)(b / hc);
+        ct = (int)(b - (int64_t)lt * hc);
+        valid = lt < nrows;
     } else {
-        const int st = (int)((b >> 3) >> 6) * 8 + (int)(b & 7);
-        if (st >= M.start[M.ngroups]) return;
+        const int bb = (int)(b - M.nhead);
+        const int x = bb & 7, n = bb >> 3;
+        int st, within;
+        if (n < M.whole) {
+            st = (n >> 6) * 8 + x;
+            within = n & 63;
+        } else {                              // the last (< 8) super-tiles: tile row x of each goes to XCD class x
+            const int nn = n - M.whole;
+            st = (M.whole >> 3) + (nn >> 3);
+            within = x * 8 + (nn & 7);
+        }
+        valid = st < M.start[M.ngroups];
         int R = 0;
         for (int step = 128; step > 0; step >>= 1)
             if (R + step <= M.ngroups && M.start[R + step] <= st) R += step;      // last group with start <= st
-        const int within = (int)((b >> 3) & 63);
         lt = R * 8 + (within >> 3);
-        ct = (st - M.start[R]) * 8 + (within & 7);
-        if (lt >= nrows || ct >= ncol) return;
+        ct = M.head_cols + (st - M.start[R]) * 8 + (within & 7);
+        valid = valid && lt < nrows && ct < ncol;
     }
     const int gtj = ct + col_lo;
     const int s0 = kpanel + NSEG;
-    const int bi = M.fb + (lt >> 1) * G;
+    const int qi = M.qfb + (lt >> 1);
+    const int bi = qi * G + snake_pos(qi, g, G);
     const int gti = 2 * (bi - s0) + (lt & 1);
-    if (gtj > gti) return;
-    if (ncol <= 8) TGP_CHAIN_PRIO();          // strips of the panel chain (2 or 2 GS tile columns), not the bulk
-    const int bj = s0 + (gtj >> 1);
-    const int rj = bj - G * div_g(bj, M.ginv);
-    const int64_t hi = (lt & 1) * TGP_TB, hj = (gtj & 1) * TGP_TB;
-    SegPtrs<NSEG> sp;
+    valid = valid && gtj <= gti;
+    if (valid) {
+        if (head) TGP_CHAIN_PRIO();           // the columns the panel chain waits for (strips, or the head of a fused launch)
+        const int bj = s0 + (gtj >> 1);
+        const int qj = div_g(bj, M.ginv);
+        const int rj = snake_pos(qj, bj - G * qj, G);
+        const int64_t hi = (lt & 1) * TGP_TB, hj = (gtj & 1) * TGP_TB;
+        SegPtrs<NSEG> sp;
 #pragma unroll
-    for (int s = 0; s < NSEG; ++s) {
-        const int first = kpanel + s + 1;                     // first block held by gathered panel s
-        const int is = div_g(bi - first, M.ginv), js = div_g(bj - first, M.ginv);
-        sp.a[s] = S.P[s] + (((int64_t)g * S.cmax[s] + is) * TGP_PW + hi) * TGP_PW;
-        sp.b[s] = S.P[s] + (((int64_t)rj * S.cmax[s] + js) * TGP_PW + hj) * TGP_PW;
+        for (int s = 0; s < NSEG; ++s) {
+            const int first = kpanel + s + 1;                     // first block held by gathered panel s
+            const int is = qi - S.frg[s], js = qj - first_round32(first, rj, G, M.ginv);
+            sp.a[s] = S.P[s] + (((int64_t)g * S.cmax[s] + is) * TGP_PW + hi) * TGP_PW;
+            sp.b[s] = S.P[s] + (((int64_t)rj * S.cmax[s] + js) * TGP_PW + hj) * TGP_PW;
+        }
+        double *c = Aloc + loff[bj] + ((int64_t)(qi - first_round32(bj, g, G, M.ginv)) * TGP_PW + hi) * TGP_PW + hj;
+        gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, c);
+        if (head && M.ngroups != 0) __builtin_amdgcn_s_setprio(0);
     }
-    double *c = Aloc + loff[bj] + ((int64_t)div_g(bi - bj, M.ginv) * TGP_PW + hi) * TGP_PW + hj;
-    gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, c);
+    if (M.ngroups != 0 && b < M.nhead) {
+        // Head tile of a fused launch (valid or not: the count is the grid's).  Every wave makes its stores visible device-wide
+        // (release fence at agent scope: vmcnt(0) + write-back of the XCD's L2) before the barrier; the last workgroup to
+        // count itself in publishes the sequence number the chain's stream waits for.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(M.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1u == M.target) __hip_atomic_store(M.flag, M.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 template <int NSEG>
@@ -466,15 +401,12 @@ __global__ __launch_bounds__(256, 2) void syrk_distn_queue_kernel(double *Aloc, 
 // 32x32 diagonal steps 14k -> 72-88k cycles, the whole block 44 -> 156 us).  Only used where free compute units are
 // guaranteed (the queued bulk update below keeps one per XCD clear); elsewhere the kernel would wait for a CU to drain.
 inline void run_potrf128(hipStream_t st, double *A, int lda, double *W, int *info, int base, bool exclusive = false) {
-    static const int variant = [] { const char *e = getenv("TGP_POTRF_VARIANT"); return e ? atoi(e) : 2; }();
     constexpr unsigned pad = 128 * 1024 - 95744;
     static const bool pad_ok = [] {
         return hipFuncSetAttribute((const void *)potrf_v2::potrf128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)pad) == hipSuccess;
     }();
-    if (variant == 0) potrf128_lds_kernel<<<1, 256, 0, st>>>(A, lda, W, info, base);
-    else if (variant == 1) potrf_v2::potrf128_kernel<false><<<1, 256, 0, st>>>(A, lda, W, info, base);
-    else potrf_v2::potrf128_kernel<true><<<1, 256, (exclusive && pad_ok) ? pad : 0u, st>>>(A, lda, W, info, base);
+    potrf_v2::potrf128_kernel<true><<<1, 256, (exclusive && pad_ok) ? pad : 0u, st>>>(A, lda, W, info, base);
 }
 }  // namespace
 
@@ -516,34 +448,47 @@ void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_inf
     }
 }
 
+inline int small_t() {          // steps with at most this many tile rows run on the latency tile (16-row slices)
+    static const int v = [] { const char *e = getenv("TGP_SMALL_T"); return e ? atoi(e) : 8; }();
+    return v;
+}
+
 template <int NSEG>
-void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int strip, const double *P0, const double *P1,
-                 unsigned long long *stamps = nullptr) {
+void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int strip, const double *P0, const double *P1) {
     if (T <= 0) return;
-    static const int small_t = [] { const char *e = getenv("TGP_SMALL_T"); return e ? atoi(e) : 8; }();
-    if (T <= small_t && !stamps) {
+    if (T <= small_t()) {
         const int cols = strip == 0 ? T : (strip < T ? strip : T);
         syrk_small_kernel<NSEG><<<dim3((unsigned)(T * 8), (unsigned)cols), 256, 0, st>>>(d_A, Np, ob, T, P0, P1);
         return;
     }
-    // TGP_SYRK_TILE: 0 = 2x2-wave tile, operands through LDS | 4 / 8 = DTV tile with 4 / 8 waves (default 4: 69.3 TF on the bare depth-512 update, against 63.0 for tile 0 and 62.7 for tile 8)
-    static const int tile = [] { const char *e = getenv("TGP_SYRK_TILE"); return e ? atoi(e) : 4; }();
-    if (tile == 8 && (T & 1) == 0 && !stamps) {
-        const unsigned gs = strip == 0 ? (unsigned)(2 * tilemap_grid(T / 2)) : (unsigned)((int64_t)(T / 2) * strip);
-        syrk_dtv_kernel<8, NSEG><<<gs, 512, 0, st>>>(d_A, Np, ob, T, strip, P0, P1);
-        return;
-    }
     static const int strip64_t = [] { const char *e = getenv("TGP_STRIP64_T"); return e ? atoi(e) : 128; }();
-    if (strip > 0 && T <= strip64_t && tile == 4 && !stamps) {
+    if (strip > 0 && T <= strip64_t) {
         syrk_strip64_kernel<NSEG><<<(unsigned)((int64_t)2 * T * strip), 256, 0, st>>>(d_A, Np, ob, T, strip, P0, P1);
         return;
     }
     const unsigned gs = strip == 0 ? (unsigned)tilemap_grid(T) : (unsigned)((int64_t)T * strip);
-    if (tile == 4 && !stamps) {
-        syrk_dtv_kernel<4, NSEG><<<gs, 256, 0, st>>>(d_A, Np, ob, T, strip, P0, P1);
-        return;
+    syrk_dtv_kernel<NSEG><<<gs, 256, 0, st>>>(d_A, Np, ob, T, strip, P0, P1);
+}
+
+// The depth-512 bulk update after the pair (k, k+1) as the persistent grid that keeps compute units clear for the chain.
+// How many of them (1 .. 3 per shader engine = 32 .. 96 CUs): as many as leave the bulk -- tiles x ~130 us over the
+// remaining slots -- shorter than the chain (~400 us per pair of panels): with 64 CUs the panel GEMMs run one workgroup
+// per CU (22 instead of 40 us) and the strips in one round.
+void launch_syrk2_queued(tgp_ctx *ctx, hipStream_t st, double *d_A, int64_t Np, int ob, int T, const double *P0, const double *P1,
+                         int nqueue) {
+    static const int queue_res = [] { const char *e = getenv("TGP_QUEUE_RES"); return e ? atoi(e) : 0; }();
+    int nres = 1;
+    if (queue_res > 0) {
+        nres = queue_res > 3 ? 3 : queue_res;
+    } else {
+        const int64_t tiles = (int64_t)T * (T + 1) / 2;
+        for (int r = 3; r > 1; --r) {
+            const int64_t slots = 512 - 64 * r;
+            if ((tiles + slots - 1) / slots * 130 <= 400) { nres = r; break; }
+        }
     }
-    syrk_trailing_kernel<TileDefault, NSEG><<<gs, 256, 0, st>>>(d_A, Np, ob, T, strip, P0, P1, stamps);
+    syrk_dtv_queue_kernel<2><<<512 + 8, 256, 0, st>>>(d_A, Np, ob, T, (unsigned)(tilemap_grid(T) / 8), nres,
+                                                     ctx->d_queue + TGP_QUEUE_WORDS * nqueue, P0, P1);
 }
 }  // namespace
 
@@ -554,10 +499,13 @@ void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int str
 //   fours:  F(k) -> S1 -> F(k+1) -> S2 -> F(k+2) -> S3 -> F(k+3) -> U4: everything right of it, depth 1024
 //           (Sj: the two tile columns of panel k+j against the j panels before it, one launch of depth 256 j)
 // Both with look-ahead: the update is split into the tile columns of the next group (U2a / U4a) and the rest (U2b / U4b),
-// and the next group is factored on a high-priority side stream under the rest.
+// and the next group is factored on a high-priority side stream under the rest.  The streams hand over to each other by
+// tgp_signal / tgp_await (handoff.hip: flags + stream wait-value, or events).
 // History at N=65536 (same tile): 1694 ms one panel at a time, 1571 pairs, 1551 pairs + look-ahead; with the DTV tile
 // 1423 ms pairs + look-ahead, 1362 ms fours + look-ahead (68.9 TF, 87.6 % of the fp64 MFMA peak).
-int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_info, int64_t n_data, PotrfRider *rider) {
+// Schedules that were measured and dropped (diagonal-first, a right-hand side riding along, head start for the chain) are
+// in DESIGN.md Appendix A and the git history.
+int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_info, int64_t n_data) {
     TGP_ARG(Np > 0 && Np % TGP_PW == 0);
     hipStream_t st = ctx->stream;
     TGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), st));
@@ -573,9 +521,9 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     // TGP_CHOL_MODE: 3 = groups of four panels (depth-1024 bulk update) with a pair-wise tail, 2 = pairs with look-ahead,
     // 1 = pairs without look-ahead, 0 = one panel at a time.  Default: 3 from N = 22528 on (measured crossover: equal at 20480, 83.3 vs 84.2 ms at 24576), else 2.
     static const int mode_env = [] { const char *e = getenv("TGP_CHOL_MODE"); return e ? atoi(e) : -1; }();
-    // Up to N = 1280 there is no bulk update worth a second stream (round 3: the hand-offs became flags + stream wait-value and
-    // the look-ahead pays from Np = 1536 on -- 0.650 vs 0.657 ms there, 0.906 vs 0.935 ms at 2048; with events it lost up to 2048:
-    // 0.51 vs 0.56 ms at N = 1024).  Contexts that run side by side (the concurrent likelihood evaluations of the ML fit) ask for
+    // Up to N = 1280 there is no bulk update worth a second stream (with flag hand-offs the look-ahead pays from Np = 1536 on
+    // -- 0.650 vs 0.657 ms there, 0.906 vs 0.935 ms at 2048; with events it lost up to 2048: 0.51 vs 0.56 ms at N = 1024).
+    // Contexts that run side by side (the concurrent likelihood evaluations of the ML fit) ask for
     // one stream each: the runtime has 4 hardware queues, and with two streams per context three contexts already share
     // queues and serialise (6 contexts at N = 1024: 0.60 ms per evaluation with look-ahead, 0.22 ms without).
     const int mode = mode_env >= 0 ? mode_env : (!ctx->lookahead ? 1 : (Np >= 22528 ? 3 : (Np <= 1280 ? 1 : 2)));
@@ -583,53 +531,6 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
         int rc = tgp_ensure_side_stream(ctx);
         if (rc) return rc;
     }
-    // The right-hand side rides along (PotrfRider, tgp_internal.h): a third stream follows the factorisation super-block by
-    // super-block of S columns -- inverse slabs, then the forward-substitution step through them -- beside the trailing
-    // update, which leaves the memory system mostly idle.  Only in the schedules with a side stream (modes 2 and 3).
-    // Built for the round-2 verdict's "drop the forward sweep", measured (same box, A/B by TGP_RIDER, df_check.py), and NOT
-    // on by default: the sweep's phase shrinks as asked -- N = 65 536: 7.69 -> 3.60 ms, N = 8192: 0.42 -> 0.17 ms -- but the
-    // factorisation it rides on grows by as much or more: 1318.5 -> 1324.4 ms at N = 65 536 (net +1.8 ms), 175.2 -> 177.2 ms at
-    // 32 768 (net +0.5), 78.9 -> 79.7 at 24 576 (net -0.25), and in chain-bound steps (all of N <= 16 384) the rider's short
-    // kernels land on the compute units kept clear for the panel chain and hold up its diagonal blocks, which ask for an
-    // empty unit: 6.19 -> 6.57 ms at N = 8192 (net +0.12).  The memory-bound work is not free beside the trailing update: its
-    // workgroups take slots the update's tiles would have had, and its streams through L2 evict operand panels.
-    // TGP_RIDER=1: ride through the groups-of-four schedule (the chain-bound tail is taken after the last panel), 2: everywhere.
-    static const int rider_env = [] { const char *e = getenv("TGP_RIDER"); return e ? atoi(e) : 0; }();
-    bool riding = rider && rider->d_b && rider->d_z && rider->slabs && rider->S > 0 && rider_env > 0 &&
-                  (mode == 3 || (mode == 2 && rider_env == 2));
-    bool rider_paused = false;
-    if (rider) rider->active = riding;
-    int rider_K = 0;                                        // next super-block the rider has to take
-    if (riding) {
-        int rc = tgp_ensure_rest_stream(ctx);
-        if (rc) return rc;
-    }
-    // `ev` was recorded on the stream that factored panel `panels_done - 1`, right after it
-    auto rider_follow = [&](hipEvent_t ev, int panels_done) -> int {
-        if (!riding || rider_paused) return 0;
-        const int S = rider->S, nS = (int)((Np + S - 1) / S);
-        bool waited = false;
-        while (rider_K < nS) {
-            const int64_t hi = (int64_t)(rider_K + 1) * S < Np ? (int64_t)(rider_K + 1) * S : Np;
-            if (hi / TGP_PW > panels_done) break;
-            if (!waited) {
-                TGP_HIP(hipStreamWaitEvent(ctx->rest_stream, ev, 0));
-                waited = true;
-            }
-            int rc = launch_vslab_build_range(ctx, ctx->rest_stream, d_A, d_W, Np, S, rider->slabs, (int64_t)rider_K * S, hi);
-            if (rc) return rc;
-            rc = launch_potrs_big_fwd_step(ctx, ctx->rest_stream, d_A, Np, S, rider->slabs, rider_K, rider->d_b, rider->d_z);
-            if (rc) return rc;
-            ++rider_K;
-        }
-        return 0;
-    };
-    auto rider_follow_main = [&](int panels_done) -> int {    // the same for panels factored on the main stream
-        if (!riding || rider_paused) return 0;
-        TGP_HIP(hipEventRecord(ctx->ev_df[6], st));
-        return rider_follow(ctx->ev_df[6], panels_done);
-    };
-    static const bool want_stamps = getenv("TGP_SYRK_STAMPS") != nullptr;      // development diagnostics
     double flops = 0.0;
     int nlaunch = 0;
     // the roofline accounting (timings 5..7) covers ONE kernel: the bulk update of the schedule in use; in mode 3 the
@@ -649,164 +550,14 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     };
     auto Wk = [&](int k) { return d_W + (int64_t)(2 * k) * TGP_TB * TGP_TB; };
     auto panel = [&](int k) { return d_A + panel_off(k, Np); };
-    // hand-offs between the streams: flags + stream wait-value (signal_kernel above); TGP_SYNC_EVENTS=1: events, as before round 3
-    // Under rocprofv3 counter collection (--pmc sets ROCPROF_COUNTER_COLLECTION) the profiler serialises the dispatches of the
-    // queues it intercepts and a stream parked in hipStreamWaitValue32 never gets going (observed: a 7-minute hang): events there.
-    static const bool sync_events = getenv("TGP_SYNC_EVENTS") != nullptr || getenv("ROCPROF_COUNTER_COLLECTION") != nullptr;
-    auto signal = [&](hipStream_t from, int id, hipEvent_t ev) -> hipError_t {      // after everything queued on `from` so far
-        if (sync_events) return hipEventRecord(ev, from);
-        if (ctx->flag_seq[id] >= 0xfffffff0u) {
-            // the sequence numbers are about to wrap (days of continuous use): let everything queued finish -- every wait that
-            // was issued is then satisfied -- and start all flags of this context again from zero
-            hipError_t e = hipDeviceSynchronize();
-            if (e == hipSuccess) e = hipMemset(ctx->d_flags, 0, 16 * 64);
-            if (e != hipSuccess) return e;
-            for (unsigned &q : ctx->flag_seq) q = 0;
-        }
-        const unsigned v = ++ctx->flag_seq[id];
-        signal_kernel<<<1, 1, 0, from>>>(ctx->d_flags + 16 * id, v);
-        return hipGetLastError();
-    };
-    auto await = [&](hipStream_t to, int id, hipEvent_t ev) -> hipError_t {          // the last signal() on this id
-        if (sync_events) return hipStreamWaitEvent(to, ev, 0);
-        return hipStreamWaitValue32(to, ctx->d_flags + 16 * id, ctx->flag_seq[id], hipStreamWaitValueGte, 0xffffffffu);
-    };
-    // TGP_HEAD_START=1 (A/B): the bulk waits for an event the side stream records once IT has seen the strip update
-    // finish, one hop more than the chain's first kernel.  It was the first remedy for the chain waiting behind the bulk's
-    // first round of workgroups (measured at N = 8192: 240 us of a 660 us cycle); with the clear compute units of the
-    // queued bulk update it no longer pays (7.65 vs 7.79 ms at N = 8192) and it costs the bulk ~22 us per step.
-    static const bool no_head_start = getenv("TGP_HEAD_START") == nullptr;
-    auto head_start = [&](hipStream_t sd) -> hipError_t {
-        if (no_head_start) return hipSuccess;
-        hipError_t e = hipEventRecord(ctx->ev[6], sd);
-        return e != hipSuccess ? e : hipStreamWaitEvent(st, ctx->ev[6], 0);
-    };
     // ---- pairs with look-ahead (the schedule of TGP_CHOL_MODE=2, also the tail of mode 3) --------------------------
     // The update after pair (k, k+1) is split into the 4 tile columns the NEXT pair lives in (U2a) and the rest
     // (U2b); the next pair is factored on a high-priority side stream while U2b keeps the chip busy.
     static const int queue_t = [] { const char *e = getenv("TGP_QUEUE_T"); return e ? atoi(e) : 64; }();
-    static const int queue_res = [] { const char *e = getenv("TGP_QUEUE_RES"); return e ? atoi(e) : 0; }();
-    static const int small_t_pairs = [] { const char *e = getenv("TGP_SMALL_T"); return e ? atoi(e) : 8; }();
     int nqueue = 0;
-    if (Np / TGP_TB - 8 > small_t_pairs)      // some step can take the queued form (T3 = Np/128 - 8 at the first pair)
+    if (Np / TGP_TB - 8 > small_t())          // some step can take the queued form (T3 = Np/128 - 8 at the first pair)
         TGP_HIP(hipMemsetAsync(ctx->d_queue, 0, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned), st));
-    // ---- diagonal-first schedule (chain-bound steps: TGP_CHOL_MODE=4, and the tail of the pair-wise schedule) ----------
-    // What the next diagonal block needs is taken out of everything else.  Three streams:
-    //   C  (side stream, high priority): the critical chain of panel k -- potrf128 of tile (0,0); the two products of its
-    //      column-half update on rows 128..511 only (the second diagonal tile and the rows of the NEXT diagonal block);
-    //      potrf128 of tile (1,1); X = R W1^T on the next block's 256 rows; the depth-256 update of the next diagonal block
-    //      with those rows.  Sixteen-row slices throughout (8 - 32 workgroups per launch).
-    //   R1 (rest stream): the other rows of panel k (one fused launch) and the update of panel k+1's columns below its
-    //      diagonal block (needed by the chain one cycle later).
-    //   B  (main stream): panel k's update of block column k+2, then of everything right of it.
-    // Per 256 columns the chain is ~125 us instead of ~230 us in the pair-wise schedule, where every panel GEMM runs over
-    // all rows and both strip updates sit on the chain (rocprofv3 trace at N = 8192, profiles/r03_trace_n8192_*).
-    // Entry state: every panel < kstart applied to everything, all work joined into the main stream.
-    static const int df_small_tall = [] { const char *e = getenv("TGP_DF_SMALL_TALL"); return e ? atoi(e) : 48; }();
-    auto run_diagfirst = [&](int kstart) -> int {
-        int rc = tgp_ensure_rest_stream(ctx);
-        if (rc) return rc;
-        hipStream_t sc = ctx->side_stream, sr = ctx->rest_stream;
-        hipEvent_t evP2 = ctx->ev_df[0], evTn = ctx->ev_df[1], evTr = ctx->ev_df[2], evUa1 = ctx->ev_df[3], evFar = ctx->ev_df[4],
-                   evJoin = ctx->ev_df[5];
-        TGP_HIP(signal(st, 2, evJoin));
-        TGP_HIP(await(sc, 2, evJoin));
-        TGP_HIP(await(sr, 2, evJoin));
-        bool have_prev = false;
-        for (int k = kstart; k < nP; ++k) {
-            const int64_t mk = Np - (int64_t)TGP_PW * k;
-            double *Pk = panel(k), *W0 = Wk(k), *W1 = W0 + TGP_TB * TGP_TB;
-            const int T = (int)((mk - TGP_PW) / TGP_TB);             // tile rows from block k+1 on
-            const int Tb = T - 4;                                      // tile rows of the bulk update (from block k+3)
-            const bool queued = Tb <= queue_t && Tb > small_t_pairs && nqueue < TGP_NQUEUE;
-            const bool excl = queued || T <= 4;                        // free compute units are guaranteed
-            if (mk == TGP_PW) {                                        // last panel: nothing below, nothing to the right
-                if (have_prev) TGP_HIP(await(sc, 6, evUa1));
-                factor_panel(sc, Pk, mk, W0, ctx->d_info, k * TGP_PW, excl, n_data);
-                break;
-            }
-            double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                // row 128 of the panel
-            double *Rn = Pk + (int64_t)TGP_PW * TGP_PW;                // row 256: the next diagonal block's rows
-            // ---- C: the critical chain
-            run_potrf128(sc, Pk, TGP_PW, W0, ctx->d_info, k * TGP_PW, excl);
-            if (have_prev) TGP_HIP(await(sc, 6, evUa1));   // panel k-1 applied to the rows below this diagonal block
-            gemm_col_small_kernel<0, TGP_TB><<<24, 256, 0, sc>>>(R1, W0, R1);              // rows 128..511: X0 = R0 W0^T
-            TGP_HIP(signal(sc, 3, evP2));                          // ("evM0": W0 and L10 are final)
-            gemm_col_small_kernel<1, TGP_PW><<<24, 256, 0, sc>>>(R1, R1, R1 + TGP_TB);     //                R1 -= X0 X0d^T
-            run_potrf128(sc, R1 + TGP_TB, TGP_PW, W1, ctx->d_info, k * TGP_PW + TGP_TB, excl);
-            gemm_col_small_kernel<0, TGP_TB><<<16, 256, 0, sc>>>(Rn + TGP_TB, W1, Rn + TGP_TB);   // next block's rows: X1 = R1 W1^T
-            TGP_HIP(signal(sc, 4, evTn));
-            // ---- R1: the rows below the next diagonal block: the two products that need only W0 and L10 start under the
-            // chain's second diagonal tile, the third (W1) follows it
-            TGP_HIP(await(sr, 3, evP2));
-            const int ntail = T - 2;                                   // 128-row tiles from block k+2 on
-            double *Rt = Pk + (int64_t)2 * TGP_PW * TGP_PW;
-            if (ntail > 0) {
-                if (ntail <= df_small_tall) {
-                    gemm_col_small_kernel<0, TGP_TB><<<ntail * 8, 256, 0, sr>>>(Rt, W0, Rt);
-                    gemm_col_small_kernel<1, TGP_PW><<<ntail * 8, 256, 0, sr>>>(Rt, R1, Rt + TGP_TB);
-                } else {
-                    gemm_col_kernel<0, TGP_TB><<<ntail, 256, 0, sr>>>(Rt, W0, Rt);
-                    gemm_col_kernel<1, TGP_PW><<<ntail, 256, 0, sr>>>(Rt, R1, Rt + TGP_TB);
-                }
-            }
-            TGP_HIP(await(sr, 4, evTn));
-            if (ntail > 0) {
-                if (ntail <= df_small_tall) gemm_col_small_kernel<0, TGP_TB><<<ntail * 8, 256, 0, sr>>>(Rt + TGP_TB, W1, Rt + TGP_TB);
-                else gemm_col_kernel<0, TGP_TB><<<ntail, 256, 0, sr>>>(Rt + TGP_TB, W1, Rt + TGP_TB);
-            }
-            TGP_HIP(signal(sr, 5, evTr));
-            // ---- B: block column k+2 first (the chain needs it one cycle from now), then the bulk
-            const double *P0 = Rn;                                     // panel k's row of the first trailing row
-            TGP_HIP(await(st, 5, evTr));
-            if (T > 2) {
-                const int Tf = T - 2;
-                const double *Pf = P0 + (int64_t)2 * TGP_TB * TGP_PW;
-                const int strip = Tf < 2 ? Tf : 2;
-                syrk_strip64_kernel<1><<<(unsigned)((int64_t)2 * Tf * strip), 256, 0, st>>>(d_A, Np, k + 2, Tf, strip, Pf, nullptr);
-            }
-            // ---- R1: panel k+1's columns below its diagonal block (the previous panel's far strip touched them last)
-            if (have_prev) TGP_HIP(await(sr, 7, evFar));
-            if (T > 2) syrk_strip64_kernel<1><<<(unsigned)((int64_t)2 * (T - 2) * 2), 256, 0, sr>>>(d_A, Np, k + 1, T, 2, P0, nullptr, 2);
-            // ---- C: the next diagonal block (panel k-1's far strip touched it last)
-            if (have_prev) TGP_HIP(await(sc, 7, evFar));
-            syrk_small_kernel<1><<<dim3(16u, 2u), 256, 0, sc>>>(d_A, Np, k + 1, 2, P0, nullptr);
-            TGP_HIP(signal(sr, 6, evUa1));
-            TGP_HIP(signal(st, 7, evFar));
-            if (Tb > 0) {
-                const double m = (double)Tb * TGP_TB;
-                const double *Pb = P0 + (int64_t)4 * TGP_TB * TGP_PW;
-                rc = timed([&] {
-                    if (queued) {
-                        int nres = 1;
-                        if (queue_res > 0) {
-                            nres = queue_res > 3 ? 3 : queue_res;
-                        } else {
-                            const int64_t tiles = (int64_t)Tb * (Tb + 1) / 2;
-                            for (int r = 3; r > 1; --r) {
-                                const int64_t slots = 512 - 64 * r;
-                                if ((tiles + slots - 1) / slots * 65 <= 250) { nres = r; break; }
-                            }
-                        }
-                        syrk_dtv_queue_kernel<1><<<512 + 8, 256, 0, st>>>(d_A, Np, k + 3, Tb, (unsigned)(tilemap_grid(Tb) / 8), nres,
-                                                                       ctx->d_queue + TGP_QUEUE_WORDS * nqueue, Pb, nullptr);
-                        ++nqueue;
-                    } else {
-                        launch_syrk<1>(st, d_A, Np, k + 3, Tb, 0, Pb, nullptr);
-                    }
-                }, (double)TGP_PW * m * (m + 1.0));
-                if (rc) return rc;
-            }
-            have_prev = true;
-        }
-        TGP_HIP(signal(sc, 3, evP2));
-        TGP_HIP(signal(sr, 5, evTr));
-        TGP_HIP(await(st, 3, evP2));
-        TGP_HIP(await(st, 5, evTr));
-        return 0;
-    };
-    static const int df_t = [] { const char *e = getenv("TGP_DF_T"); return e ? atoi(e) : 0; }();      // hand-over of the pairs (tile rows)
-    auto run_pairs = [&](int kstart, bool pairs_from_scratch) -> int {
+    auto run_pairs = [&](int kstart) -> int {
         hipStream_t sd = ctx->side_stream;
         auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false) {       // F(k), U1(k), F(k+1)
             const int64_t mk = Np - (int64_t)TGP_PW * k;
@@ -816,69 +567,35 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             launch_syrk<1>(s, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
             factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, exclusive, n_data);
         };
-        if (pairs_from_scratch) {
-            factor_pair(st, kstart);
-            int rc = rider_follow_main(kstart + 2 < nP ? kstart + 2 : nP);
-            if (rc) return rc;
-        }
+        factor_pair(st, kstart);
         for (int k = kstart; k + 2 < nP; k += 2) {
             const int T2 = (int)((Np - (int64_t)TGP_PW * (k + 2)) / TGP_TB);       // tiles from block k+2
             const double *P0 = panel(k) + (int64_t)2 * TGP_PW * TGP_PW;
             const double *P1 = panel(k + 1) + (int64_t)TGP_PW * TGP_PW;
-            if (df_t > 0 && T2 <= df_t) {
-                // hand-over: this pair applied to everything right of it in one launch, then the diagonal-first schedule
-                launch_syrk<2>(st, d_A, Np, k + 2, T2, 0, P0, P1);
-                return run_diagfirst(k + 2);
-            }
             const int T3 = T2 - 4;
             // chain-bound steps: the bulk runs as a persistent grid that keeps one compute unit per shader engine clear
             // for the side stream, and the diagonal blocks insist on a compute unit of their own
-            const bool queued = T3 <= queue_t && T3 > small_t_pairs && nqueue < TGP_NQUEUE;
+            const bool queued = T3 <= queue_t && T3 > small_t() && nqueue < TGP_NQUEUE;
             {   // U2a: tile columns 0..3 (panels k+2, k+3)
                 const double rows = (double)T2 * TGP_TB, w = (T2 < 4 ? T2 : 4) * (double)TGP_TB;
                 const double elems = w * (rows - w) + w * (w + 1.0) / 2.0;
                 int rc = timed([&] { launch_syrk<2>(st, d_A, Np, k + 2, T2, 4, P0, P1); }, 2.0 * 2.0 * TGP_PW * elems);
                 if (rc) return rc;
             }
-            TGP_HIP(signal(st, 0, ctx->ev[4]));
-            TGP_HIP(await(sd, 0, ctx->ev[4]));
-            if (queued) TGP_HIP(head_start(sd));      // off by default, see above
+            TGP_HIP(tgp_signal(ctx, st, 0, ctx->ev[4]));
+            TGP_HIP(tgp_await(ctx, sd, 0, ctx->ev[4]));
             factor_pair(sd, k + 2, queued);
-            TGP_HIP(signal(sd, 1, ctx->ev[5]));
-            if (riding && !rider_paused) {
-                if (!sync_events) TGP_HIP(hipEventRecord(ctx->ev[5], sd));      // the rider follows an event
-                int rc = rider_follow(ctx->ev[5], k + 4 < nP ? k + 4 : nP);
-                if (rc) return rc;
-            }
+            TGP_HIP(tgp_signal(ctx, sd, 1, ctx->ev[5]));
             if (T3 > 0) {   // U2b: everything from block k+4 on
                 const double m = (double)T3 * TGP_TB;
                 const int64_t skip = (int64_t)4 * TGP_TB * TGP_PW;
                 int rc = timed([&] {
-                    if (queued) {
-                        // The grid covers every workgroup slot, so the chain finds room on the clear units only.  How many
-                        // of them (1 .. 3 per shader engine = 32 .. 96 CUs): as many as leave the bulk -- tiles x ~130 us
-                        // over the remaining slots -- shorter than the chain (~400 us per pair of panels): with 64 CUs
-                        // the panel GEMMs run one workgroup per CU (22 instead of 40 us) and the strips in one round
-                        int nres = 1;
-                        if (queue_res > 0) {
-                            nres = queue_res > 3 ? 3 : queue_res;
-                        } else {
-                            const int64_t tiles = (int64_t)T3 * (T3 + 1) / 2;
-                            for (int r = 3; r > 1; --r) {
-                                const int64_t slots = 512 - 64 * r;
-                                if ((tiles + slots - 1) / slots * 130 <= 400) { nres = r; break; }
-                            }
-                        }
-                        syrk_dtv_queue_kernel<2><<<512 + 8, 256, 0, st>>>(d_A, Np, k + 4, T3, (unsigned)(tilemap_grid(T3) / 8), nres,
-                                                                       ctx->d_queue + TGP_QUEUE_WORDS * nqueue, P0 + skip, P1 + skip);
-                        ++nqueue;
-                    } else {
-                        launch_syrk<2>(st, d_A, Np, k + 4, T3, 0, P0 + skip, P1 + skip);
-                    }
+                    if (queued) launch_syrk2_queued(ctx, st, d_A, Np, k + 4, T3, P0 + skip, P1 + skip, nqueue++);
+                    else launch_syrk<2>(st, d_A, Np, k + 4, T3, 0, P0 + skip, P1 + skip);
                 }, 2.0 * TGP_PW * m * (m + 1.0));
                 if (rc) return rc;
             }
-            TGP_HIP(await(st, 1, ctx->ev[5]));
+            TGP_HIP(tgp_await(ctx, st, 1, ctx->ev[5]));
         }
         return 0;
     };
@@ -903,14 +620,10 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
         auto seg_rows = [&](int kpanel, int first_block) {       // row of panel `kpanel` that belongs to `first_block`
             return (const double *)(panel(kpanel) + (int64_t)(first_block - kpanel) * TGP_PW * TGP_PW);
         };
-        auto small = [&](int T) {                                // steps with few tiles: the latency tile, one panel at a time
-            static const int small_t = [] { const char *e = getenv("TGP_SMALL_T"); return e ? atoi(e) : 8; }();
-            return T <= small_t;
-        };
         auto strip_update = [&](hipStream_t s, int k0, int j) {  // panel k0+j's columns -= sum_{i<j} P_{k0+i}
             const int ob = k0 + j;
             const int T = (int)((Np - (int64_t)TGP_PW * ob) / TGP_TB);
-            if (small(T)) {
+            if (T <= small_t()) {
                 for (int i = 0; i < j; ++i)
                     syrk_small_kernel<1><<<dim3((unsigned)(T * 8), 2u), 256, 0, s>>>(d_A, Np, ob, T, seg_rows(k0 + i, ob), nullptr);
                 return;
@@ -934,7 +647,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             }
         };
         auto bulk = [&](int k0, int ob, int T, int strip) {      // depth-1024 update from block `ob` on, T tile rows
-            if (small(T)) {
+            if (T <= small_t()) {
                 const int cols = strip == 0 ? T : (strip < T ? strip : T);
                 for (int i = 0; i < 4; i += 2)
                     syrk_small_kernel<2><<<dim3((unsigned)(T * 8), (unsigned)cols), 256, 0, st>>>(
@@ -950,10 +663,6 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
         // serial chain cost more than the per-tile overhead it saves: crossover at N ~ 24k): the tail runs in pairs.
         static const int tail_tiles = [] { const char *e = getenv("TGP_QUAD_TAIL_TILES"); return e ? atoi(e) : 128; }();
         factor_group(st, 0);
-        {
-            int rc = rider_follow_main(4 < nP ? 4 : nP);
-            if (rc) return rc;
-        }
         for (int k = 0; k + 4 < nP; k += 4) {
             const int T4 = (int)((Np - (int64_t)TGP_PW * (k + 4)) / TGP_TB);        // tiles from block k+4
             if (T4 <= tail_tiles) {
@@ -962,9 +671,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
                 int rc = timed([&] { bulk(k, k + 4, T4, 0); }, 4.0 * TGP_PW * m * (m + 1.0));
                 if (rc) return rc;
                 counting = false;
-                rider_paused = rider_env != 2;            // chain-bound tail: the rider takes what is left after the last panel
-                rc = run_pairs(k + 4, true);
-                rider_paused = false;
+                rc = run_pairs(k + 4);
                 counting = true;
                 if (rc) return rc;
                 break;
@@ -975,28 +682,20 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
                 int rc = timed([&] { bulk(k, k + 4, T4, 8); }, 2.0 * 4.0 * TGP_PW * elems);
                 if (rc) return rc;
             }
-            TGP_HIP(signal(st, 0, ctx->ev[4]));
-            TGP_HIP(await(sd, 0, ctx->ev[4]));
+            TGP_HIP(tgp_signal(ctx, st, 0, ctx->ev[4]));
+            TGP_HIP(tgp_await(ctx, sd, 0, ctx->ev[4]));
             factor_group(sd, k + 4);
-            TGP_HIP(signal(sd, 1, ctx->ev[5]));
-            if (riding && !rider_paused) {
-                if (!sync_events) TGP_HIP(hipEventRecord(ctx->ev[5], sd));      // the rider follows an event
-                int rc = rider_follow(ctx->ev[5], k + 8 < nP ? k + 8 : nP);
-                if (rc) return rc;
-            }
+            TGP_HIP(tgp_signal(ctx, sd, 1, ctx->ev[5]));
             const int T5 = T4 - 8;
             if (T5 > 0) {   // U4b: everything from block k+8 on
                 const double m = (double)T5 * TGP_TB;
                 int rc = timed([&] { bulk(k, k + 8, T5, 0); }, 4.0 * TGP_PW * m * (m + 1.0));
                 if (rc) return rc;
             }
-            TGP_HIP(await(st, 1, ctx->ev[5]));
+            TGP_HIP(tgp_await(ctx, st, 1, ctx->ev[5]));
         }
     } else if (mode == 2) {
-        int rc = run_pairs(0, true);
-        if (rc) return rc;
-    } else if (mode == 4) {
-        int rc = run_diagfirst(0);
+        int rc = run_pairs(0);
         if (rc) return rc;
     } else {
         for (int k = 0; k < nP; k += 2) {
@@ -1010,39 +709,9 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             const int T2 = T1 - 2;
             if (T2 > 0) {
                 const double m = (double)T2 * TGP_TB;
-                unsigned long long *d_st = nullptr;
-                if (want_stamps && k == 0) (void)hipMalloc((void **)&d_st, (size_t)tilemap_grid(T2) * 32);
-                if (d_st) (void)hipMemsetAsync(d_st, 0, (size_t)tilemap_grid(T2) * 32, st);
                 int rc = timed([&] { launch_syrk<2>(st, d_A, Np, k + 2, T2, 0, panel(k) + (int64_t)2 * TGP_PW * TGP_PW,
-                                                     panel(k + 1) + (int64_t)TGP_PW * TGP_PW, d_st); },
+                                                     panel(k + 1) + (int64_t)TGP_PW * TGP_PW); },
                                2.0 * TGP_PW * m * (m + 1.0));
-                if (rc) return rc;
-                if (d_st) {
-                    const int64_t nv = tilemap_grid(T2);
-                    std::vector<unsigned long long> h((size_t)nv * 4);
-                    (void)hipMemcpyAsync(h.data(), d_st, (size_t)nv * 32, hipMemcpyDeviceToHost, st);
-                    (void)hipStreamSynchronize(st);
-                    double a = 0, b = 0, e = 0, rt = 0; long cnt = 0;
-                    for (int64_t i = 0; i < nv; ++i) if (h[4 * i + 1]) { a += h[4 * i]; b += h[4 * i + 1]; e += h[4 * i + 2]; rt += h[4 * i + 3]; ++cnt; }
-                    fprintf(stderr, "[stamps] tiles %ld  prologue %.0f  loop %.0f  epilogue %.0f cycles (mean); loop clock %.3f GHz\n",
-                            cnt, a / cnt, b / cnt, e / cnt, b / rt * 0.1);
-                    (void)hipFree(d_st);
-                }
-            }
-        }
-    }
-    if (riding) {
-        // What the schedule factored without telling (the chain-bound tail, hand-overs): everything is final now.  The rest
-        // of the slabs in ONE build (ten launches whatever the number of super-blocks), then the remaining forward steps,
-        // on the main stream behind the rider's.
-        TGP_HIP(hipEventRecord(ctx->ev_df[7], ctx->rest_stream));
-        TGP_HIP(hipStreamWaitEvent(st, ctx->ev_df[7], 0));
-        const int S = rider->S, nS = (int)((Np + S - 1) / S);
-        if (rider_K < nS) {
-            int rc = launch_vslab_build_range(ctx, st, d_A, d_W, Np, S, rider->slabs, (int64_t)rider_K * S, Np);
-            if (rc) return rc;
-            for (; rider_K < nS; ++rider_K) {
-                rc = launch_potrs_big_fwd_step(ctx, st, d_A, Np, S, rider->slabs, rider_K, rider->d_b, rider->d_z);
                 if (rc) return rc;
             }
         }
@@ -1072,15 +741,9 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
 int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base) {
     hipStream_t st = ctx->stream;
     double *R1 = blk + (int64_t)TGP_TB * TGP_PW;
-    static const bool unfused = getenv("TGP_DIST_TRSM_UNFUSED") != nullptr;
     const bool excl = ctx->chain_exclusive != 0;      // a queued bulk update keeps compute units clear for this chain
     run_potrf128(st, blk, TGP_PW, W0, ctx->d_info, base, excl);
-    if (!unfused) {
-        diag_mid_kernel<<<1, 256, 0, st>>>(R1, W0);
-    } else {
-        gemm_col_kernel<0, TGP_TB><<<1, 256, 0, st>>>(R1, W0, R1);
-        gemm_col_kernel<1, TGP_PW><<<1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
-    }
+    diag_mid_kernel<<<1, 256, 0, st>>>(R1, W0);
     run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, ctx->d_info, base + TGP_TB, excl);
     TGP_HIP(hipGetLastError());
     return 0;
@@ -1089,20 +752,10 @@ int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int
 // rows (ntiles x 128, ld 256) <- rows L_kk^-T with L_kk given by its 256x256 block and W0, W1
 int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, const double *W0, const double *W1) {
     if (ntiles <= 0) return 0;
-    hipStream_t st = ctx->stream;
-    static const bool unfused = getenv("TGP_DIST_TRSM_UNFUSED") != nullptr;      // A/B: three launches
-    if (!unfused) {
-        panel_tall_kernel<<<ntiles, 256, 0, st>>>(rows, W0, Lkk + (int64_t)TGP_TB * TGP_PW, W1);
-    } else {
-        gemm_col_kernel<0, TGP_TB><<<ntiles, 256, 0, st>>>(rows, W0, rows);
-        gemm_col_kernel<1, TGP_PW><<<ntiles, 256, 0, st>>>(rows, Lkk + (int64_t)TGP_TB * TGP_PW, rows + TGP_TB);
-        gemm_col_kernel<0, TGP_TB><<<ntiles, 256, 0, st>>>(rows + TGP_TB, W1, rows + TGP_TB);
-    }
+    panel_tall_kernel<<<ntiles, 256, 0, ctx->stream>>>(rows, W0, Lkk + (int64_t)TGP_TB * TGP_PW, W1);
     TGP_HIP(hipGetLastError());
     return 0;
 }
-
-
 
 template <int NSEG>
 static void launch_distn(hipStream_t st, unsigned grid, double *d_Aloc, const int64_t *d_loff, int kpanel, int G, int g,
@@ -1112,6 +765,7 @@ static void launch_distn(hipStream_t st, unsigned grid, double *d_Aloc, const in
     for (int s = 0; s < NSEG; ++s) {
         S.P[s] = P[s];
         S.cmax[s] = cmax[s];
+        S.frg[s] = (int)dist_first_round(kpanel + s + 1, g, G);
     }
     if (nres > 0 && queue)
         syrk_distn_queue_kernel<NSEG><<<512 + 8, 256, 0, st>>>(d_Aloc, d_loff, kpanel, G, g, S, col_lo, ncol, nrows, M, grid / 8, nres, queue);
@@ -1119,80 +773,81 @@ static void launch_distn(hipStream_t st, unsigned grid, double *d_Aloc, const in
         syrk_distn_kernel<NSEG><<<grid, 256, 0, st>>>(d_Aloc, d_loff, kpanel, G, g, S, col_lo, ncol, nrows, M);
 }
 
+// `head_cols` > 0: the fused form (DistMap) -- tile columns [col_lo, col_lo + head_cols) first, then the rest up to col_hi,
+// one launch; tgp_head_flag() tells which flag / sequence number the launch publishes when the head is done.
 int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
-                      const double *const *d_P, const int *cmax, int col_lo, int col_hi, int queue_nres) {
-    TGP_ARG(nseg >= 1 && nseg <= 4);
+                      const double *const *d_P, const int *cmax, int col_lo, int col_hi, int queue_nres, int head_cols) {
+    TGP_ARG(nseg >= 1 && nseg <= 4 && head_cols >= 0);
     const int64_t nB = Np / TGP_PW;
     const int64_t nloc = dist_panel_blocks(kpanel + nseg, nB, g, G);      // local blocks > kpanel + nseg - 1
     const int64_t ncol_all = 2 * (nB - kpanel - nseg);
     if (col_hi < 0 || col_hi > ncol_all) col_hi = (int)ncol_all;
     if (col_lo < 0) col_lo = 0;
     const int64_t ncol = (int64_t)col_hi - col_lo;
-    if (nloc <= 0 || ncol <= 0) return 0;
-    // experiment (TGP_DIST_W1_SEGS=1, world of one only): the single-GPU kernel on the same work -- is the 5 % between the
-    // two drivers the kernel's or its surroundings'?
-    static const bool w1_segs = getenv("TGP_DIST_W1_SEGS") != nullptr;
-    if (w1_segs && G == 1 && nseg == 4 && queue_nres == 0) {
-        const int ob = kpanel + nseg + col_lo / 2;
-        const int T = (int)(ncol_all - col_lo);
-        const int strip = (col_hi < ncol_all) ? (int)ncol : 0;
-        SegPtrs<4> P;
-        for (int sgi = 0; sgi < 4; ++sgi) {
-            P.a[sgi] = d_P[sgi] + (int64_t)(ob - (kpanel + sgi + 1)) * TGP_PW * TGP_PW;
-            P.b[sgi] = nullptr;
-        }
-        const unsigned gs = strip == 0 ? (unsigned)tilemap_grid(T) : (unsigned)((int64_t)T * strip);
-        syrk_segs_kernel<4><<<gs, 256, 0, ctx->stream>>>(d_Aloc, Np, ob, T, strip, P);
-        TGP_HIP(hipGetLastError());
+    hipStream_t st = ctx->stream;
+    DistMap M;
+    M.nhead = M.head_cols = M.whole = 0;
+    M.done = M.flag = nullptr;
+    M.target = M.seq = 0;
+    if (head_cols > 0) {
+        // the waiter is released whatever this rank's share is (even none at all): the signal is part of the call's contract
+        hipError_t e = hipSuccess;
+        M.seq = tgp_next_seq(ctx, TGP_FLAG_HEAD, &e);
+        TGP_HIP(e);
+        M.flag = ctx->d_flags + 16 * TGP_FLAG_HEAD;
+        M.done = ctx->d_flags + 16 * TGP_FLAG_HEAD_COUNT;
+    }
+    if (nloc <= 0 || ncol <= 0) {
+        if (head_cols > 0) TGP_HIP(tgp_signal_value(ctx, st, TGP_FLAG_HEAD, M.seq));
         return 0;
     }
     // staircase of valid tiles: local tile row lt reaches global tile column gti(lt); super-tiles per group of 8 rows
     const int nrows = (int)(2 * nloc);
-    const int64_t s0 = kpanel + nseg, fb = dist_first_ge(s0, g, G);
-    DistMap M;
-    M.fb = (int)fb;
+    const int64_t s0 = kpanel + nseg, qfb = dist_first_round(s0, g, G);
+    M.qfb = (int)qfb;
     M.ginv = G == 1 ? 0u : (unsigned)((((uint64_t)1) << 32) / (uint64_t)G) + 1u;
     TGP_ARG(nB < 65536 && G >= 1);
     // Strips (the panel chain's updates of a few tile columns): a dense grid, one workgroup per (tile row, tile column).  The
     // super-tile map would start three empty workgroups for every useful one of a two-column strip, and beside a bulk
     // update that fills every slot it is slot grants, not arithmetic, that a strip waits for (rocprofv3, world of one at
     // N = 65 536: 748 / 561 / 375 us per strip of depth 768 / 512 / 256 against 468 / 345 / 239 us on the single-GPU path).
-    static const bool dense_strips = getenv("TGP_DIST_SPARSE_STRIPS") == nullptr;
-    if (dense_strips && ncol <= 8 && queue_nres == 0) {
+    unsigned grid = 0;
+    if (head_cols == 0 && ncol <= 8 && queue_nres == 0) {
         M.ngroups = 0;
         M.start[0] = 0;
-        const unsigned grid = (unsigned)((int64_t)nrows * ncol);
-        hipStream_t st0 = ctx->stream;
-        switch (nseg) {
-            case 1: launch_distn<1>(st0, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, 0, nullptr); break;
-            case 2: launch_distn<2>(st0, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, 0, nullptr); break;
-            case 3: launch_distn<3>(st0, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, 0, nullptr); break;
-            default: launch_distn<4>(st0, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, 0, nullptr); break;
+        grid = (unsigned)((int64_t)nrows * ncol);
+    } else {
+        if (head_cols > ncol) head_cols = (int)ncol;
+        M.head_cols = head_cols;
+        M.nhead = (nrows * head_cols + 7) / 8 * 8;
+        M.ngroups = (nrows + 7) / 8;
+        TGP_ARG(M.ngroups <= 257);
+        int total = 0;
+        for (int R = 0; R < M.ngroups; ++R) {
+            M.start[R] = total;
+            const int ltmax = (R * 8 + 7 < nrows ? R * 8 + 7 : nrows - 1);
+            const int64_t gti = 2 * (dist_block_of(qfb + (ltmax >> 1), g, G) - s0) + (ltmax & 1);     // last valid global column
+            int64_t reach = gti - (col_lo + head_cols) + 1;                                  // valid columns of this launch
+            if (reach > ncol - head_cols) reach = ncol - head_cols;
+            total += reach > 0 ? (int)((reach + 7) / 8) : 0;
         }
-        TGP_HIP(hipGetLastError());
-        return 0;
+        M.start[M.ngroups] = total;
+        M.whole = 64 * (total / 8);
+        grid = (unsigned)(M.nhead + 8 * (M.whole + 8 * (total % 8)));
+        if (grid == 0) return 0;
+        if (head_cols > 0) {
+            // every head workgroup counts itself in; the counter runs on from launch to launch (modulo 2^32: all of the
+            // previous launch's increments are in before this one starts, same stream)
+            ctx->head_count += (unsigned)M.nhead;
+            M.target = ctx->head_count;
+        }
     }
-    M.ngroups = (nrows + 7) / 8;
-    TGP_ARG(M.ngroups <= 257);
-    int total = 0;
-    for (int R = 0; R < M.ngroups; ++R) {
-        M.start[R] = total;
-        const int ltmax = (R * 8 + 7 < nrows ? R * 8 + 7 : nrows - 1);
-        const int64_t gti = 2 * (fb + (int64_t)(ltmax >> 1) * G - s0) + (ltmax & 1);     // last valid global column
-        int64_t reach = gti - col_lo + 1;                                                // valid columns of this launch
-        if (reach > ncol) reach = ncol;
-        total += reach > 0 ? (int)((reach + 7) / 8) : 0;
-    }
-    M.start[M.ngroups] = total;
-    if (total == 0) return 0;
-    const unsigned grid = (unsigned)(((total + 7) / 8) * 8 * 64);
-    hipStream_t st = ctx->stream;
     // queued form: one set of counters per launch, zeroed by tgp_dd_queue_reset at the start of a factorisation; beyond
     // TGP_NQUEUE launches (N > 131 072 in groups of four) the sets are reused in turn, each zeroed on this stream in front of
     // its launch -- the launch that used it TGP_NQUEUE launches ago is long finished (same stream)
     int nres = queue_nres > 3 ? 3 : queue_nres;
     unsigned *queue = nullptr;
-    if (nres > 0) {
+    if (nres > 0 && M.ngroups != 0) {
         queue = ctx->d_queue + TGP_QUEUE_WORDS * (ctx->dist_nqueue % TGP_NQUEUE);
         if (ctx->dist_nqueue >= TGP_NQUEUE) TGP_HIP(hipMemsetAsync(queue, 0, TGP_QUEUE_WORDS * sizeof(unsigned), st));
         ++ctx->dist_nqueue;

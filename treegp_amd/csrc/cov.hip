@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void cov_diag_big_kernel(const double *__restr
     const double *b = V + (r0 + (int64_t)tj * TGP_TB) * TGP_PW;          // slab panel 0, rows r0 + 128 tj ..
     double *c = T + (int64_t)(tj >> 1) * Mp * TGP_PW + (int64_t)ti * TGP_TB * TGP_PW + (tj & 1) * TGP_TB;
     const int nseg = (tj >> 1) + 1;                                      // V_K is lower triangular: columns k <= j
-    gemm_tile_128<0, TGP_PW, TGP_PW, TileDefault, 0>(a, b, c, nullptr, nullptr, nullptr, nseg, Mp * TGP_PW, Np * TGP_PW);
+    gemm_tile_128<0, TGP_PW, TGP_PW, TileDefault, 0>(a, b, c, nullptr, nullptr, nseg, Mp * TGP_PW, Np * TGP_PW);
 }
 
 template <int NS>                                                          // NS = S / 256 panels per super-block

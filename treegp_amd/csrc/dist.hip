@@ -1,5 +1,5 @@
 // Device-pointer entry points for the multi-GPU (one process per GPU) driver, treegp_amd/dist.py.
-// Row-block-cyclic layout over 256-row blocks: rank g of G owns blocks b = g, g+G, ...; its part
+// Row-block-cyclic layout over 256-row blocks, reflected every G blocks (dist_owner, tgp_internal.h); a rank's part
 // of panel p (blocks b >= p) is stored like the single-GPU panel, back to back, at d_loff[p].
 // Nothing here synchronises: every call only enqueues work on the context's stream (which the
 // driver points at torch's current stream with tgp_set_stream, so RCCL collectives order with it).
@@ -44,7 +44,7 @@ int tgp_dd_kbuild(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t 
 // owner of panel kpanel: factor its 256x256 diagonal block and pack [L_kk | W0 | W1] (98304 doubles)
 int tgp_dd_factor_diag(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int64_t Np, int kpanel, int G, int g,
                        double *d_W, double *d_bcast) {
-    TGP_ARG(d_Aloc && h_loff && d_W && d_bcast && kpanel % G == g);
+    TGP_ARG(d_Aloc && h_loff && d_W && d_bcast && G >= 1 && dist_owner(kpanel, G) == g);
     hipStream_t st = ctx->stream;
     double *blk = d_Aloc + h_loff[kpanel];
     double *W0 = d_W + (int64_t)(2 * kpanel) * TGP_TB * TGP_TB;
@@ -61,11 +61,11 @@ int tgp_dd_trsm(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int64_t Np,
     TGP_ARG(d_Aloc && h_loff && d_W && d_bcast);
     hipStream_t st = ctx->stream;
     double *W0 = d_W + (int64_t)(2 * kpanel) * TGP_TB * TGP_TB;
-    if (kpanel % G != g)
+    if (dist_owner(kpanel, G) != g)
         TGP_HIP(hipMemcpyAsync(W0, d_bcast + TGP_PW * TGP_PW, (size_t)2 * TGP_TB * TGP_TB * 8, hipMemcpyDeviceToDevice, st));
     const int64_t nB = Np / TGP_PW;
     const int64_t below = dist_panel_blocks(kpanel + 1, nB, g, G);
-    const int64_t skip = (kpanel % G == g) ? TGP_PW : 0;          // the owner's diagonal block comes first
+    const int64_t skip = (dist_owner(kpanel, G) == g) ? TGP_PW : 0;          // the owner's diagonal block comes first
     double *rows = d_Aloc + h_loff[kpanel] + skip * TGP_PW;
     return launch_trsm_rows(ctx, rows, (int)(2 * below), d_bcast, d_bcast + TGP_PW * TGP_PW,
                             d_bcast + TGP_PW * TGP_PW + TGP_TB * TGP_TB);
@@ -115,6 +115,27 @@ int tgp_dd_update_group_queued(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_lo
     return launch_syrk_distn(ctx, d_Aloc, d_loff, Np, kpanel, G, g, nseg, d_gathered, cmax, col_lo, col_hi, nres);
 }
 
+// The whole update after a group in ONE launch: the tile columns [0, head_cols) -- the next group's panels, which the panel
+// chain waits for -- come first in the workgroup order, the rest follows without a launch boundary (no second ramp and
+// tail: at 8 ranks and N = 65 536 a rank's launches hold 2 - 30 rounds of tiles and lost ~1.2 tile times each).  The
+// workgroup that finishes the last head tile publishes a sequence number; tgp_dd_wait_head parks another context's stream
+// (the chain's) on it.  Needs hand-offs by stream wait-value (tgp_handoff_mode(ctx) == 1); otherwise the caller splits
+// the update into two tgp_dd_update_group calls with an event between them.  nres > 0: the persistent-grid form.
+int tgp_dd_update_group_fused(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
+                              const double *const *d_gathered, const int *cmax, int head_cols, int nres) {
+    TGP_ARG(d_Aloc && d_loff && d_gathered && cmax && nseg >= 1 && nseg <= 4 && nres >= 0 && head_cols > 0);
+    for (int s = 0; s < nseg; ++s) TGP_ARG(d_gathered[s] && cmax[s] >= 0);
+    TGP_ARG(tgp_handoff_by_flags(ctx));
+    return launch_syrk_distn(ctx, d_Aloc, d_loff, Np, kpanel, G, g, nseg, d_gathered, cmax, 0, -1, nres, head_cols);
+}
+// the stream of `waiter` proceeds once the head of the last tgp_dd_update_group_fused launched through `ctx` is done
+int tgp_dd_wait_head(tgp_ctx *ctx, tgp_ctx *waiter) {
+    TGP_ARG(waiter && tgp_handoff_by_flags(ctx));
+    TGP_HIP(hipStreamWaitValue32(waiter->stream, ctx->d_flags + 16 * TGP_FLAG_HEAD, ctx->flag_seq[TGP_FLAG_HEAD],
+                                 hipStreamWaitValueGte, 0xffffffffu));
+    return 0;
+}
+
 // ---- replicated factor for the solves ---------------------------------------------------------------------------
 // Every rank sees every panel once (diagonal block in the broadcast, the rows below in the all-gather).  Keeping them,
 // in the single-GPU packed layout (17 GB at N = 65536, 69 GB at 131072: what 288 GB of HBM per GPU are for), lets each
@@ -124,8 +145,8 @@ namespace {
 __global__ __launch_bounds__(256) void keep_rows_kernel(const double *__restrict__ gathered, int cmax, int kpanel, int G,
                                                         double *__restrict__ panel) {
     const int64_t b = (int64_t)kpanel + 1 + blockIdx.x;
-    const int r = (int)(b % G);
-    const int64_t idx = (b - dist_first_ge(kpanel + 1, r, G)) / G;
+    const int r = dist_owner(b, G);
+    const int64_t idx = b / G - dist_first_round(kpanel + 1, r, G);
     const double2 *src = reinterpret_cast<const double2 *>(gathered + ((int64_t)r * cmax + idx) * TGP_PW * TGP_PW) + blockIdx.y * 1024;
     double2 *dst = reinterpret_cast<double2 *>(panel + (b - kpanel) * TGP_PW * TGP_PW) + blockIdx.y * 1024;
 #pragma unroll
@@ -158,8 +179,8 @@ int tgp_dd_fwd_update(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff,
     const int64_t nB = Np / TGP_PW;
     const int64_t below = dist_panel_blocks(kb + 1, nB, g, G);
     if (below <= 0) return 0;
-    const int64_t skip = (kb % G == g) ? TGP_PW : 0;
-    const int64_t lb0 = (dist_first_ge(kb + 1, g, G) - g) / G;          // local index of the first block > kb
+    const int64_t skip = (dist_owner(kb, G) == g) ? TGP_PW : 0;
+    const int64_t lb0 = dist_first_round(kb + 1, g, G);                 // local index of the first block > kb
     return launch_fwd_update_rows(ctx, d_Aloc + h_loff[kb] + skip * TGP_PW, below * TGP_PW, d_zk, d_yloc + lb0 * TGP_PW);
 }
 // backward sweep, every rank: s (256) = sum over local rows of blocks > kb of L[i, kb]^T a_i
@@ -167,8 +188,8 @@ int tgp_dd_bwd_partial(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff
                        const double *d_aloc, double *d_s) {
     const int64_t nB = Np / TGP_PW;
     const int64_t below = dist_panel_blocks(kb + 1, nB, g, G);
-    const int64_t skip = (kb % G == g) ? TGP_PW : 0;
-    const int64_t lb0 = (below > 0) ? (dist_first_ge(kb + 1, g, G) - g) / G : 0;
+    const int64_t skip = (dist_owner(kb, G) == g) ? TGP_PW : 0;
+    const int64_t lb0 = (below > 0) ? dist_first_round(kb + 1, g, G) : 0;
     return launch_gemv_t_rows(ctx, d_Aloc + h_loff[kb] + skip * TGP_PW, below * TGP_PW, d_aloc + lb0 * TGP_PW, d_s);
 }
 // backward sweep, block kb (owner): a_k (256) <- L_kk^-T (a_k - s)   (d_s may be NULL)

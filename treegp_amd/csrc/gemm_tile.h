@@ -20,29 +20,14 @@ constexpr int KB = 16;         // k-chunk depth
 //         aligned rows, so staging stores are ds_write_b64 pairs.
 //   PRE   MODE 1 only: load C into the accumulators (negated) in the prologue, together with the
 //         first operand chunk (one memory latency), instead of a 4-round read-modify-write epilogue.
-//   DMA   (A/B build only, -DTGP_TILE_DMA=1; measured SLOWER: 59.7 vs 63.0 TF on the depth-512 update)
-//         operands go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`), no VGPR staging and no
-//         ds_write.  Motivation: with the staging stores removed (wrong results, probe only) the kernel
-//         runs at 67.7 TF, i.e. the ds_write path costs 7 %; but 8 DMA pieces per wave and chunk cost
-//         more issue time than the 8 loads + 8 stores they replace.  A DMA piece lands as 1 KiB contiguous (8 rows x 128 B), so
-//         rows cannot be padded; bank conflicts are avoided by an XOR swizzle applied on the SOURCE side
-//         (the lane that fills 16-byte slot s of row r fetches k-pair s ^ ((r >> 1) & 7)), and fragments are
-//         read with one ds_read_b128 per operand tile and k-step pair: lane (r, kq) takes k = 8h + 2kq +
-//         {0, 1} for steps 2h, 2h+1 (any assignment of k to steps is valid as long as A and B agree).
-template <int LSV, bool PRE, bool DMAV = false>
+//   (An LDS-DMA variant of the staging -- `buffer_load ... lds`, XOR-swizzled source side -- was measured slower, 59.7 vs
+//   63.0 TF on the depth-512 update, and removed in round 4: DESIGN.md A.4, git history.)
+template <int LSV, bool PRE>
 struct TileCfg {
     static constexpr int LS = LSV;
     static constexpr bool PRELOAD = PRE;
-    static constexpr bool DMA = DMAV;
 };
-#ifndef TGP_TILE_DMA
-#define TGP_TILE_DMA 0
-#endif
-#if TGP_TILE_DMA
-using TileDefault = TileCfg<16, true, true>;
-#else
 using TileDefault = TileCfg<17, true>;
-#endif
 
 // buffer addressing (one wave-uniform 128-bit descriptor per operand, one 32-bit lane offset, the
 // row/column part of every access as a scalar offset): keeps the 64 C accesses and the staging
@@ -84,147 +69,6 @@ __device__ __forceinline__ void lds_put2(double *p, const double2 &v) {
     }
 }
 
-typedef __attribute__((address_space(3))) void lds_void;
-// one LDS-DMA piece: every lane moves 16 bytes from (rsrc, voff + soff) to lds_base + 16 * lane
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, double *lds_base, int voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds_base, 16, voff, soff, 0, 0);
-}
-
-template <int MODE, int LDB, int KDEPTH, typename CFG, int NSEG>
-__device__ __forceinline__ void gemm_tile_128_dma(const double *a_ptr, const double *b_ptr, double *c_ptr,
-                                                  const double *a1_ptr, const double *b1_ptr, int nseg_rt,
-                                                  int64_t seg_stride_a, int64_t seg_stride_b) {
-    constexpr int LDA = TGP_PW, LDC = TGP_PW;
-    constexpr bool PRELOAD = CFG::PRELOAD && MODE == 1;
-    __shared__ __attribute__((aligned(16))) double lds[2][2][128 * KB];   // [buf][A|B][row][16], k-pairs swizzled
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 1, wc = w & 1;
-    const int l15 = lane & 15, l4 = lane >> 4;
-
-    // staging: wave w fills rows 32w .. 32w+31 of each operand, 4 pieces of 8 rows; lane -> (row, slot)
-    const int prow = lane >> 3, slot = lane & 7;
-    int va[2], vb[2];
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-        const int row = 32 * w + 8 * par + prow;
-        const int pair = slot ^ ((row >> 1) & 7);
-        va[par] = (row * LDA + 2 * pair) * 8;
-        vb[par] = (row * LDB + 2 * pair) * 8;
-    }
-    const __amdgpu_buffer_rsrc_t ra_src = tile_rsrc(a_ptr, 128 * LDA * 8);
-    const __amdgpu_buffer_rsrc_t rb_src = tile_rsrc(b_ptr, 128 * LDB * 8);
-    const __amdgpu_buffer_rsrc_t ra1_src = tile_rsrc(NSEG > 1 ? a1_ptr : a_ptr, 128 * LDA * 8);
-    const __amdgpu_buffer_rsrc_t rb1_src = tile_rsrc(NSEG > 1 ? b1_ptr : b_ptr, 128 * LDB * 8);
-    const __amdgpu_buffer_rsrc_t rc_dst = tile_rsrc(c_ptr, 128 * LDC * 8);
-    auto stage = [&](int buf, __amdgpu_buffer_rsrc_t sa, __amdgpu_buffer_rsrc_t sb, int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double *da = &lds[buf][0][(32 * w + 8 * i) * KB];
-            double *db = &lds[buf][1][(32 * w + 8 * i) * KB];
-            dma16(sa, da, va[i & 1], ((i >> 1) * 16 * LDA + k0) * 8);
-            dma16(sb, db, vb[i & 1], ((i >> 1) * 16 * LDB + k0) * 8);
-        }
-    };
-    stage(0, ra_src, rb_src, 0);
-
-    const int vc = ((wr * 64 + l4) * LDC + wc * 64 + l15) * 8;
-    d4 acc[4][4];
-    if constexpr (PRELOAD) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[m][n][r] = buf_ld1(rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
-    } else {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's DMA pieces (and C) have landed
-    __syncthreads();
-    if constexpr (PRELOAD) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = -acc[m][n];
-    }
-
-    constexpr int cps = KDEPTH / KB;
-    const int nchunk = (NSEG > 0 ? NSEG : nseg_rt) * cps;
-    // fragment reads: row R = tile row, physical k-pair = (kq + 4h) ^ ((R >> 1) & 7), and (R >> 1) & 7 = l15 >> 1
-    const int fr = l15 >> 1;
-    const int p0 = 2 * ((l4 ^ (fr & 3)) + 4 * (fr >> 2));            // h = 0
-    const int p1 = 2 * ((l4 ^ (fr & 3)) + 4 * (1 - (fr >> 2)));      // h = 1
-    const int fa0 = (wr * 64 + l15) * KB + p0, fa1 = (wr * 64 + l15) * KB + p1;
-    const int fb0 = (wc * 64 + l15) * KB + p0, fb1 = (wc * 64 + l15) * KB + p1;
-    for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
-        const bool more = (c + 1 < nchunk);
-        if (more) {
-            const int cn = c + 1;
-            const int k0 = (NSEG != 1 ? (cn % cps) : cn) * KB;
-            const bool second = NSEG > 1 && cn >= cps;           // wave-uniform
-            __amdgpu_buffer_rsrc_t sa = second ? ra1_src : ra_src;
-            __amdgpu_buffer_rsrc_t sb = second ? rb1_src : rb_src;
-            if constexpr (NSEG == 0) {
-                const int seg = cn / cps;
-                sa = tile_rsrc(a_ptr + seg * seg_stride_a, 128 * LDA * 8);
-                sb = tile_rsrc(b_ptr + seg * seg_stride_b, 128 * LDB * 8);
-            }
-            stage(buf ^ 1, sa, sb, k0);
-        }
-        const double *As = lds[buf][0];
-        const double *Bs = lds[buf][1];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            double2 af[4], bf[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const double2 *>(&As[(h ? fa1 : fa0) + m * 16 * KB]);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) bf[n] = *reinterpret_cast<const double2 *>(&Bs[(h ? fb1 : fb0) + n * 16 * KB]);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m].x, bf[n].x, acc[m][n], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m].y, bf[n].y, acc[m][n], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the next chunk's pieces of this wave have landed
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        if constexpr (MODE == 1 && !PRELOAD) {
-            double old[4][4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) old[n][r] = buf_ld1(rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    buf_st1(old[n][r] - acc[m][n][r], rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
-        } else {
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    buf_st1((PRELOAD || MODE == 2) ? -acc[m][n][r] : acc[m][n][r], rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
-        }
-    }
-}
-
 // MODE 0: C = A B^T     MODE 1: C -= A B^T     MODE 2: C = -(A B^T)      (A: 128 x KDEPTH, B: 128 x KDEPTH, row-major)
 // A and C always live in 256-wide panels (ld 256); B is a panel (LDB 256) or a W block (LDB 128).
 // NSEG = 2: the contraction runs over two operand pairs back to back, C -= A0 B0^T + A1 B1^T (the
@@ -239,15 +83,8 @@ __device__ __forceinline__ double *tile128_lds_storage() {
 
 template <int MODE, int LDB, int KDEPTH, typename CFG = TileDefault, int NSEG = 1>
 __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double *b_ptr, double *c_ptr,
-                                              unsigned long long *stamps = nullptr, const double *a1_ptr = nullptr,
-                                              const double *b1_ptr = nullptr, int nseg_rt = 1,
+                                              const double *a1_ptr = nullptr, const double *b1_ptr = nullptr, int nseg_rt = 1,
                                               int64_t seg_stride_a = 0, int64_t seg_stride_b = 0) {
-    if constexpr (CFG::DMA) {
-        gemm_tile_128_dma<MODE, LDB, KDEPTH, CFG, NSEG>(a_ptr, b_ptr, c_ptr, a1_ptr, b1_ptr, nseg_rt, seg_stride_a, seg_stride_b);
-        return;
-    }
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tr1 = 0, tr2 = 0;
-    if (stamps) ts0 = __builtin_amdgcn_s_memtime();
     constexpr int LDA = TGP_PW, LDC = TGP_PW;
     constexpr int LS = CFG::LS;
     constexpr bool PRELOAD = CFG::PRELOAD && MODE == 1;
@@ -307,7 +144,6 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
             for (int n = 0; n < 4; ++n) acc[m][n] = -acc[m][n];
     }
 
-    if (stamps) { ts1 = __builtin_amdgcn_s_memtime(); tr1 = __builtin_amdgcn_s_memrealtime(); }
     constexpr int cps = KDEPTH / KB;               // chunks per segment
     const int nchunk = (NSEG > 0 ? NSEG : nseg_rt) * cps;
     const int fa = (wr * 64 + l15) * LS + l4;      // fragment read offsets
@@ -361,7 +197,6 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
         __syncthreads();
     }
 
-    if (stamps) { ts2 = __builtin_amdgcn_s_memtime(); tr2 = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         if constexpr (MODE == 1 && !PRELOAD) {
@@ -382,13 +217,6 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
                 for (int r = 0; r < 4; ++r)
                     buf_st1((PRELOAD || MODE == 2) ? -acc[m][n][r] : acc[m][n][r], rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
         }
-    }
-    if (stamps && threadIdx.x == 0) {
-        const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
-        stamps[0] = ts1 - ts0;
-        stamps[1] = ts2 - ts1;
-        stamps[2] = ts3 - ts2;
-        stamps[3] = tr2 - tr1;
     }
 }
 

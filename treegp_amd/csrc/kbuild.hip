@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void kbuild_slab_kernel(KParams p, const doubl
     }
 }
 
-// multi-GPU: rank g of G owns the 256-row blocks b = g, g+G, ...; blockIdx.y = local tile row,
+// multi-GPU: rank g of G owns one 256-row block per round of G (dist_block_of); blockIdx.y = local tile row,
 // blockIdx.x = global tile column (tiles right of the diagonal exit).
 template <int KE>
 __global__ __launch_bounds__(256) void kbuild_lower_dist_kernel(KParams p, const double *__restrict__ X, int64_t n,
@@ -174,12 +174,12 @@ __global__ __launch_bounds__(256) void kbuild_lower_dist_kernel(KParams p, const
                                                                 double *__restrict__ Aloc,
                                                                 const int64_t *__restrict__ loff, int G, int g) {
     const int64_t lt = blockIdx.y, tj = blockIdx.x;
-    const int64_t bi = g + (lt >> 1) * G;
+    const int64_t bi = dist_block_of(lt >> 1, g, G);
     const int64_t ti = 2 * bi + (lt & 1);
     if (tj > ti) return;
     const int64_t pj = tj >> 1;
-    const int64_t fb = dist_first_ge(pj, g, G);
-    double *tile = Aloc + loff[pj] + (((bi - fb) / G) * TGP_PW + (lt & 1) * TGP_TB) * TGP_PW + (tj & 1) * TGP_TB;
+    const int64_t idx = (lt >> 1) - dist_first_round(pj, g, G);       // bi among the rank's blocks >= pj
+    double *tile = Aloc + loff[pj] + ((idx * TGP_PW) + (lt & 1) * TGP_TB) * TGP_PW + (tj & 1) * TGP_TB;
     kbuild_tile<KE>(p, X, n, yerr, ti, tj, tile);
 }
 
@@ -189,7 +189,7 @@ int launch_kbuild_lower_dist(tgp_ctx *ctx, const tgp_kernel *k, const double *d_
     TGP_ARG(ke >= 0 && G >= 1 && g >= 0 && g < G);
     const KParams p = make_kparams(k);
     const int64_t nB = Np / TGP_PW;
-    const int64_t nloc = (nB > g) ? (nB - g + G - 1) / G : 0;
+    const int64_t nloc = dist_panel_blocks(0, nB, g, G);
     if (nloc == 0) return 0;
     dim3 grid((unsigned)(2 * nB), (unsigned)(2 * nloc)), block(256);
     switch (ke) {

@@ -27,10 +27,10 @@ struct tgp_ctx {
     hipStream_t stream = nullptr;      // the stream every kernel is launched on
     hipStream_t own_stream = nullptr;  // created by tgp_init
     hipStream_t side_stream = nullptr; // high-priority stream for the Cholesky look-ahead
-    hipStream_t rest_stream = nullptr; // diagonal-first schedule (chol.hip): the rest of a panel and its near strips
-    hipEvent_t ev_df[8] = {nullptr};   // its cross-stream events (no timing), created with the stream
-    unsigned *d_flags = nullptr;       // cross-stream hand-off flags (chol.hip: hand-offs by stream wait-value), 16 x 64 B
+    unsigned *d_flags = nullptr;       // cross-stream hand-off flags (handoff.hip: hand-offs by stream wait-value), 16 x 64 B
     unsigned flag_seq[16] = {0};       // last value signalled on each (monotonic over the context's life)
+    unsigned head_count = 0;           // value of the head-tile counter (flag word TGP_FLAG_HEAD_COUNT) after the last fused launch
+    int handoff = 0;                   // 0 undecided, 1 flags + stream wait-value, 2 events (tgp_handoff_by_flags)
     bool ext_stream = false;           // stream was set by tgp_set_stream
     std::string err;
     double timings[TGP_NTIMINGS] = {0};
@@ -92,17 +92,33 @@ __host__ __device__ inline int64_t padded_n(int64_t n) {
     return (n + TGP_PW - 1) / TGP_PW * TGP_PW;
 }
 
-// ---- multi-GPU row-block-cyclic geometry (blocks of 256 rows; rank g of G owns b = g, g+G, ...) ----
-// smallest block index >= s owned by rank r
-__host__ __device__ inline int64_t dist_first_ge(int64_t s, int r, int G) {
-    int64_t d = (r - s) % G;
-    if (d < 0) d += G;
-    return s + d;
+// ---- multi-GPU row-block-cyclic geometry (blocks of 256 rows) ----
+// The owner map is the block-cyclic deal REFLECTED every G blocks ("snake"): round q = b / G hands one block to every rank,
+// rank r's being q G + r in even rounds and q G + (G-1-r) in odd ones.  Block row b of the lower triangle carries b + 1 block
+// columns, so the plain deal b -> b % G gives rank G-1 the heaviest block of every round (4.1 % above the mean at 256 blocks
+// on 8 ranks, and the slowest rank sets the pace); the reflection pairs a heavy round with a light one: 0.2 %.
+// A rank's local index of block b is b / G either way.  G == 1: the identity.
+__host__ __device__ inline int dist_owner(int64_t b, int G) {
+    const int64_t q = b / G;
+    const int p = (int)(b - q * G);
+    return (q & 1) ? G - 1 - p : p;
 }
-// number of local 256-row blocks of rank g in panel p (blocks b >= p)
+// rank r's block of round q
+__host__ __device__ inline int64_t dist_block_of(int64_t q, int r, int G) { return q * G + ((q & 1) ? G - 1 - r : r); }
+// round of the smallest block >= s owned by rank r (= its local index)
+__host__ __device__ inline int64_t dist_first_round(int64_t s, int r, int G) {
+    const int64_t q = s / G;
+    return dist_block_of(q, r, G) >= s ? q : q + 1;
+}
+// smallest block index >= s owned by rank r
+__host__ __device__ inline int64_t dist_first_ge(int64_t s, int r, int G) { return dist_block_of(dist_first_round(s, r, G), r, G); }
+// number of local 256-row blocks of rank g in panel p (blocks p <= b < nB)
 __host__ __device__ inline int64_t dist_panel_blocks(int64_t p, int64_t nB, int g, int G) {
-    const int64_t fb = dist_first_ge(p, g, G);
-    return (fb < nB) ? (nB - 1 - fb) / G + 1 : 0;
+    if (nB <= 0) return 0;
+    const int64_t q0 = dist_first_round(p, g, G);
+    int64_t ql = (nB - 1) / G;
+    if (dist_block_of(ql, g, G) >= nB) --ql;
+    return ql >= q0 ? ql - q0 + 1 : 0;
 }
 
 // trailing-update tile enumeration (XCD-aware): see chol.hip.  Blocks b, b+8, ... share an XCD; an XCD works through
@@ -148,26 +164,22 @@ __host__ __device__ inline void tilemap(int64_t b, int64_t T, int &ti, int &tj) 
 
 // implemented across the .hip files
 int tgp_ensure_side_stream(tgp_ctx *ctx);
-int tgp_ensure_rest_stream(tgp_ctx *ctx);
 int tgp_ensure_scratch(tgp_ctx *ctx, size_t bytes);
 int tgp_ensure_scratch2(tgp_ctx *ctx, size_t bytes);
 int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,
                         const double *d_yerr, double *d_A);
 int launch_kernel_dense(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,
                         const double *d_Y, int64_t m, int self, double *d_out);
-// A right-hand side that rides along with the factorisation (chol.hip): as soon as a super-block of S columns of L is final,
-// a third stream builds its inverse slabs and takes the forward-substitution step through it -- both are memory-bound and
-// run beside the MFMA-bound trailing update.  When launch_potrf returns, d_z = L^-1 b is queued and only the backward sweep
-// (launch_potrs_big_bwd) is left.  `active` is cleared when the schedule in use does not carry riders (one-stream modes).
-struct PotrfRider {
-    double *d_b = nullptr;      // in: padded right-hand side (consumed)
-    double *d_z = nullptr;      // out: L^-1 b
-    double *slabs = nullptr;    // [V | Vt | TT] of the sweeps' step S, built on the way
-    int S = 0;
-    bool active = false;
-};
-int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_info = false, int64_t n_data = -1,
-                 PotrfRider *rider = nullptr);
+int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_info = false, int64_t n_data = -1);
+// cross-stream hand-offs (handoff.hip).  Flag ids: 0, 1 the look-ahead of launch_potrf; TGP_FLAG_HEAD the "head columns
+// done" signal of a fused multi-GPU bulk launch, TGP_FLAG_HEAD_COUNT the word its workgroups count themselves in on.
+#define TGP_FLAG_HEAD 8
+#define TGP_FLAG_HEAD_COUNT 9
+bool tgp_handoff_by_flags(tgp_ctx *ctx);
+unsigned tgp_next_seq(tgp_ctx *ctx, int id, hipError_t *err);
+hipError_t tgp_signal_value(tgp_ctx *ctx, hipStream_t from, int id, unsigned v);
+hipError_t tgp_signal(tgp_ctx *ctx, hipStream_t from, int id, hipEvent_t ev);
+hipError_t tgp_await(tgp_ctx *ctx, hipStream_t to, int id, hipEvent_t ev);
 bool potrs_big_step(int64_t Np, int *S);
 int acquire_slabs(tgp_ctx *ctx, int64_t Np, int S, double **slab_cache, int *slab_S, double **out, bool *need_build);
 int launch_potrs_big_fwd_step(tgp_ctx *ctx, hipStream_t st, const double *d_A, int64_t Np, int S, const double *slabs, int K,
@@ -178,7 +190,7 @@ int launch_kbuild_lower_dist(tgp_ctx *ctx, const tgp_kernel *k, const double *d_
 int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base);
 int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, const double *W0, const double *W1);
 int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
-                      const double *const *d_P, const int *cmax, int col_lo, int col_hi, int queue_nres = 0);
+                      const double *const *d_P, const int *cmax, int col_lo, int col_hi, int queue_nres = 0, int head_cols = 0);
 int launch_diag256_fwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y);
 int launch_diag256_bwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y, const double *s);
 int launch_fwd_update_rows(tgp_ctx *ctx, const double *Lrows, int64_t rows, const double *z, double *yrows);

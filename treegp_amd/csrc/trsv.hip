@@ -217,9 +217,9 @@ __global__ __launch_bounds__(1024) void logdet_dist_kernel(const double *__restr
                                                            int G, int g, double *out) {
     __shared__ double part[16];
     double s = 0.0;
-    const int64_t nloc = (nB > g) ? (nB - g + G - 1) / G : 0;
+    const int64_t nloc = dist_panel_blocks(0, nB, g, G);
     for (int64_t t = threadIdx.x; t < nloc * TGP_PW; t += 1024) {
-        const int64_t b = g + (t >> 8) * G;
+        const int64_t b = dist_block_of(t >> 8, g, G);
         const int64_t r = t & 255;
         if (b * TGP_PW + r < n) s += 2.0 * log(Aloc[loff[b] + r * TGP_PW + r]);
     }

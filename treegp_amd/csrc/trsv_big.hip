@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void vprod_kernel(const double *__restrict__ A
                                                     int S, int h, int qoff) {
     const Prod p = level_prod<KD, XPROD>(A, V, Vt, TT, Np, S, h, 128, qoff);
     if (!p.valid) return;
-    gemm_tile_128<XPROD ? 2 : 0, TGP_PW, KD, TileDefault, 0>(p.a, p.b, p.c, nullptr, nullptr, nullptr, p.nseg, p.sa, p.sb);
+    gemm_tile_128<XPROD ? 2 : 0, TGP_PW, KD, TileDefault, 0>(p.a, p.b, p.c, nullptr, nullptr, p.nseg, p.sa, p.sb);
 }
 
 // the same products on the latency tile (16 x 128 of C per workgroup, operands straight from L2): a 128 x 128 x 512 tile alone

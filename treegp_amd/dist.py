@@ -4,11 +4,13 @@ One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI). 
 no distributed code; this is the N-scaling axis of SURVEY.md 8(e) for the same seams as
 ``tgp_gp_solve`` / ``tgp_gp_predict`` (treegp/gp_interp.py:177-183).
 
-Layout: the N x N kernel matrix is cut into 256-row blocks; rank g of G owns block rows
-b = g, g+G, ... (their lower-triangular part, stored as packed 256-wide panels like the single-GPU
-factor).  Per panel k:
+Layout: the N x N kernel matrix is cut into 256-row blocks, dealt to the G ranks block-cyclically with
+the deal REFLECTED every G blocks (``owner``: ranks 0..G-1, then G-1..0, ...): block row b of the lower
+triangle carries b + 1 block columns, and the reflection evens out what the plain deal b % G piles on
+the last rank (max / mean work 1.041 -> 1.002 at 256 blocks on 8 ranks).  A rank stores the lower-
+triangular part of its block rows as packed 256-wide panels like the single-GPU factor.  Per panel k:
 
-    owner (k % G)   factor the 256x256 diagonal block            tgp_dd_factor_diag
+    owner(k)        factor the 256x256 diagonal block            tgp_dd_factor_diag
     broadcast       [L_kk | W0 | W1] = 768 KB                    dist.broadcast
     every rank      solve its rows of panel k (GEMMs with W)     tgp_dd_trsm
     all-gather      the panel, ((N - 256 k)/G) x 256 per rank    dist.all_gather_into_tensor
@@ -32,14 +34,49 @@ BLK = 256                      # block-row height = panel width
 BCAST_ELEMS = BLK * BLK + 2 * 128 * 128
 
 
+def owner(b, G):
+    """rank that owns block row b: round q = b // G deals ranks 0..G-1 in even rounds, G-1..0 in odd ones
+    (csrc/tgp_internal.h: dist_owner)"""
+    q, p = divmod(b, G)
+    return G - 1 - p if q & 1 else p
+
+
+def block_of(q, r, G):
+    """rank r's block of round q (= its q-th local block)"""
+    return q * G + (G - 1 - r if q & 1 else r)
+
+
+def first_round(s, r, G):
+    """round (= local index) of the smallest block >= s owned by rank r"""
+    q = s // G
+    return q if block_of(q, r, G) >= s else q + 1
+
+
 def first_ge(s, r, G):
     """smallest block index >= s owned by rank r"""
-    return s + ((r - s) % G)
+    return block_of(first_round(s, r, G), r, G)
 
 
 def panel_blocks(p, nB, g, G):
-    fb = first_ge(p, g, G)
-    return (nB - 1 - fb) // G + 1 if fb < nB else 0
+    """number of blocks p <= b < nB owned by rank g"""
+    if nB <= 0:
+        return 0
+    ql = (nB - 1) // G
+    if block_of(ql, g, G) >= nB:
+        ql -= 1
+    return max(0, ql - first_round(p, g, G) + 1)
+
+
+def panel_cmax(p, nB, G):
+    """most blocks p <= b < nB any rank holds (the per-rank slot count of an all-gathered panel).  With the reflected deal
+    a window shorter than G can hold two blocks of one rank (G-1 and G are both rank G-1's), so this is not ceil((nB-p)/G)."""
+    return max(panel_blocks(p, nB, r, G) for r in range(G)) if nB > p else 0
+
+
+def gathered_index(b, first, G):
+    """(rank, index) of block b inside an all-gathered panel [rank][cmax][256][256] that holds the blocks >= first"""
+    r = owner(b, G)
+    return r, b // G - first_round(first, r, G)
 
 
 class TorchComm(object):
@@ -236,7 +273,7 @@ class HipLocalOps(object):
         self.nB = self.Np // BLK
         self.loff = np.array([self.lib.tgp_dist_panel_off(p, self.Np, G, g) for p in range(self.nB + 1)], dtype=np.int64)
         self.nloc = panel_blocks(0, self.nB, g, G)
-        self.cmax0 = -(-max(self.nB - 1, 0) // G)
+        self.cmax0 = panel_cmax(1, self.nB, G)
         slack = (self.cmax0 + 1) * BLK * BLK                   # the padded all-gather send view may overrun
         self.A = torch.empty(int(self.loff[-1]) + slack, dtype=torch.float64, device=device)
         self.W = torch.empty(self.Np * 128, dtype=torch.float64, device=device)
@@ -312,7 +349,7 @@ class HipLocalOps(object):
                                        self._p(self.W), self._p(self.bcast)), "tgp_dd_trsm", self.ctx_side)
 
     def panel_send_view(self, k, cmax):
-        skip = BLK if k % self.G == self.g else 0
+        skip = BLK if owner(k, self.G) == self.g else 0
         o = int(self.loff[k]) + skip * BLK
         return self.A[o:o + cmax * BLK * BLK]
 
@@ -347,6 +384,26 @@ class HipLocalOps(object):
             return
         self._chk(self.lib.tgp_dd_update_group(ctx, self._p(self.A), self._p(self.d_loff), self.Np, k, self.G, self.g, ns,
                                                ptrs, cm, col_lo, col_hi), "tgp_dd_update_group", ctx)
+
+    def fused_ok(self):
+        """the whole update of a group as one launch that signals the panel chain from inside (tgp_dd_update_group_fused):
+        only where this process hands over between streams by flags + stream wait-value (a first-use trial decides,
+        csrc/handoff.hip); TGP_DIST_FUSED=0: two launches and an event, as before round 4"""
+        if os.environ.get("TGP_DIST_FUSED", "1") == "0":
+            return False
+        return int(self.lib.tgp_handoff_mode(self.ctx)) == 1
+
+    def update_group_fused(self, k, bufs, cmaxs, head_cols, queue_nres=0):
+        """main stream: everything right of the group k .. k+len(bufs)-1 in one launch, tile columns [0, head_cols) first"""
+        ns = len(bufs)
+        ptrs = (C.c_void_p * ns)(*[b.data_ptr() for b in bufs])
+        cm = (C.c_int * ns)(*[int(c) for c in cmaxs])
+        self._chk(self.lib.tgp_dd_update_group_fused(self.ctx, self._p(self.A), self._p(self.d_loff), self.Np, k, self.G, self.g,
+                                                     ns, ptrs, cm, int(head_cols), int(queue_nres)), "tgp_dd_update_group_fused")
+
+    def side_wait_head(self):
+        """the side stream proceeds once the head columns of the last fused launch are done"""
+        self._chk(self.lib.tgp_dd_wait_head(self.ctx, self.ctx_side), "tgp_dd_wait_head")
 
     @property
     def replicated(self):
@@ -441,10 +498,11 @@ class DistributedCholesky(object):
     def _local_update_flops(self, k):
         """2 * 256 flops per lower-triangle element of this rank's block rows > k"""
         elems = 0
-        b = first_ge(k + 1, self.g, self.G)
-        while b < self.nB:
+        q = first_round(k + 1, self.g, self.G)
+        while block_of(q, self.g, self.G) < self.nB:
+            b = block_of(q, self.g, self.G)
             elems += BLK * (b - k - 1) * BLK + BLK * (BLK + 1) // 2
-            b += self.G
+            q += 1
         return 2.0 * BLK * elems
 
     def factorize(self):
@@ -465,11 +523,11 @@ class DistributedCholesky(object):
 
         def factor_and_gather(k, buf):
             """panel k on the side stream: diagonal block on its owner, broadcast, local solves, all-gather"""
-            owner = k % G
-            if g == owner:
+            own = owner(k, G)
+            if g == own:
                 ops.factor_diag(k)
-            comm.broadcast(ops.bcast, owner)
-            if g != owner:
+            comm.broadcast(ops.bcast, own)
+            if g != own:
                 self.bytes_received += 8 * BCAST_ELEMS
             if keep:
                 ops.keep_diag(k)
@@ -477,7 +535,7 @@ class DistributedCholesky(object):
             rem = nB - k - 1
             if rem == 0:
                 return None, 0
-            cmax = -(-rem // G)                                  # most blocks > k any rank holds
+            cmax = panel_cmax(k + 1, nB, G)                      # most blocks > k any rank holds
             self.bytes_received += 8 * (G - 1) * cmax * BLK * BLK
             send = ops.panel_send_view(k, cmax)
             return comm.all_gather_start(buf[:G * cmax * BLK * BLK], send), cmax     # the handle knows where the panel lands
@@ -535,6 +593,7 @@ class DistributedCholesky(object):
         can_queue = queue_mode != 0 and hasattr(ops, "queue_reset")
         if can_queue:
             ops.queue_reset()
+        fused = hasattr(ops, "update_group_fused") and ops.fused_ok()
 
         def bulk_queue_units(k):
             """clear units per shader engine for the bulk after group k (0 = plain launch)"""
@@ -569,19 +628,26 @@ class DistributedCholesky(object):
                 wait_events.append((w0, w1))
             cm = [c for _, c in cur_w]
             cur = [w.tensor for w, _ in cur_w]                   # where each gathered panel of the group is (see _Done / _Work)
-            timed(lambda: ops.update_group(k, cur, cm, 0, 2 * GS))           # Ua: the next group's columns
-            ops.side_wait_main()
             units = bulk_queue_units(k)
+            if fused:
+                # Ua (the next group's columns) and Ub (the bulk) in ONE launch, Ua's tiles first; the launch itself
+                # releases the side stream when they are done: one ramp and one tail per group instead of two
+                timed(lambda: ops.update_group_fused(k, cur, cm, 2 * GS, queue_nres=units))
+                ops.side_wait_head()
+            else:
+                timed(lambda: ops.update_group(k, cur, cm, 0, 2 * GS))       # Ua: the next group's columns
+                ops.side_wait_main()
             if can_queue:
                 ops.chain_exclusive(units > 0)
             with ops.on_side():
                 nxt_w = side_group(k + GS, nxt)
-            if units > 0:
-                timed(lambda: ops.update_group(k, cur, cm, 2 * GS, -1, queue_nres=units))   # Ub, keeping units clear
-            else:
-                timed(lambda: ops.update_group(k, cur, cm, 2 * GS, -1))      # Ub: the bulk
+            if not fused:
+                if units > 0:
+                    timed(lambda: ops.update_group(k, cur, cm, 2 * GS, -1, queue_nres=units))   # Ub, keeping units clear
+                else:
+                    timed(lambda: ops.update_group(k, cur, cm, 2 * GS, -1))  # Ub: the bulk
             self.update_flops += GS * self._local_update_flops(k + GS - 1)
-            self.update_launches += 2
+            self.update_launches += 1 if fused else 2
             cur_w, k, flip = nxt_w, k + GS, 1 - flip
         ops.main_wait_side()                                     # the last chain has no gather to wait on
         if can_queue:
@@ -616,16 +682,16 @@ class DistributedCholesky(object):
         yloc = ops.zeros(max(nloc, 1) * BLK)
         yv = [yloc[lb * BLK:(lb + 1) * BLK] for lb in range(nloc)]
         for lb in range(nloc):
-            b = g + lb * G
+            b = block_of(lb, g, G)
             yv[lb].copy_(y_full[b * BLK:(b + 1) * BLK])
         z = ops.zeros(self.Np)
         zv = [z[k * BLK:(k + 1) * BLK] for k in range(nB)]
         for k in range(nB):                                      # L z = y
-            owner = k % G
-            if g == owner:
-                zv[k].copy_(yv[(k - g) // G])
+            own = owner(k, G)
+            if g == own:
+                zv[k].copy_(yv[k // G])
                 ops.fwd_diag(k, zv[k])
-            comm.broadcast(zv[k], owner)
+            comm.broadcast(zv[k], own)
             ops.fwd_update(k, zv[k], yloc)
         aloc = ops.zeros(max(nloc, 1) * BLK)
         av = [aloc[lb * BLK:(lb + 1) * BLK] for lb in range(nloc)]
@@ -633,13 +699,13 @@ class DistributedCholesky(object):
         for k in range(nB - 1, -1, -1):                          # L^T a = z
             ops.bwd_partial(k, aloc, s)
             comm.all_reduce_sum(s)
-            if g == k % G:
-                ak = av[(k - g) // G]
+            if g == owner(k, G):
+                ak = av[k // G]
                 ak.copy_(zv[k])
                 ops.bwd_diag(k, ak, s)                           # a_k = L_kk^-T (z_k - s)
         alpha = ops.zeros(self.Np)
         for lb in range(nloc):
-            b = g + lb * G
+            b = block_of(lb, g, G)
             alpha[b * BLK:(b + 1) * BLK].copy_(av[lb])
         comm.all_reduce_sum(alpha)
         return alpha
