@@ -245,6 +245,19 @@ def configs_measured(lib, ctx, ops, _lib):
     return out
 
 
+def collective_backend():
+    """torch.distributed backend of this run and the version of the library under it (RCCL for "nccl" on ROCm)"""
+    import torch
+    import torch.distributed as dist
+    rec = {"backend": dist.get_backend(), "torch": torch.__version__, "hip": getattr(torch.version, "hip", None)}
+    if rec["backend"] == "nccl":
+        try:
+            rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as ex:          # noqa: BLE001  (a version query must not cost the line)
+            rec["rccl_version"] = "unavailable: %s" % type(ex).__name__
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -424,10 +437,19 @@ def main():
         if per_rank is not None:
             np_ = (n + 255) // 256 * 256
             out["per_rank_ms_per_step"] = per_rank
+            # bytes_received (per rank, per step) is COUNTED by the communicator from the tensors it was handed during the
+            # factorisation (diagonal-block broadcasts, panel exchanges); the line below is the factorisation's ideal
+            # volume 4 N^2 (G-1)/G -- the counted figure is larger by the padding of the gathered panels to the fullest rank's
+            # block count and by the 768 KB broadcast per panel
             out["bytes_received_expected"] = 4.0 * np_ * np_ * (world - 1) / world if world > 1 else 0.0
             out["per_rank_note"] = ("chol_ms = factorisation wall on the rank's main stream; bulk_ms = its trailing-update kernels; "
                                     "chain_ms = its look-ahead stream (diagonal blocks, broadcasts, local solves, all-gathers, strips); "
-                                    "gather_wait_ms = main stream stalled behind the chain between two bulk updates")
+                                    "gather_wait_ms = main stream stalled behind the chain between two bulk updates; "
+                                    "bytes_received = counted from the tensors handed to the collectives")
+            out["gather_probe"] = getattr(engine.comm, "gather_probe", None)
+            out["collective_backend"] = collective_backend()
+            out["owner_map"] = "256-row blocks dealt block-cyclically, reflected every G blocks"
+            out["cpu_baseline"] = "see n_gpus=1 line"
         if "api_predict_ms" in acc:
             out["api_ms_per_step"] = {"initialize": acc["api_initialize_ms"] / K, "predict": acc["api_predict_ms"] / K}
         if acc.get("syrk_ms", 0) > 0:

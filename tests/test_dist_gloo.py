@@ -104,6 +104,48 @@ def test_distributed_cholesky_gloo_point_to_point_panel_exchange(tmp_path):
     assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
 
 
+def _probe_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("TGP_DIST_GATHER", None)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+        from treegp_amd.dist import TorchComm
+        comm = TorchComm()
+        rec = comm.probe_gather(elems=1 << 15, reps=2)
+        assert rec["chosen"] in ("allgather", "p2p") and comm.gather_mode == rec["chosen"]
+        assert rec["allgather_GBps"] > 0 and rec["p2p_GBps"] > 0 and comm.bytes_in == 0      # the probe's traffic is not the solve's
+        # the chosen exchange delivers, and its bytes are counted from the tensors handed over
+        inp = torch.full((1000,), float(rank), dtype=torch.float64)
+        out = torch.empty(1000 * world, dtype=torch.float64)
+        comm.all_gather_start(out, inp).wait()
+        assert all(float(out[r * 1000]) == r for r in range(world)) and comm.bytes_in == 8 * 1000 * (world - 1)
+        t = torch.full((10,), float(rank))
+        comm.broadcast(t, 1)
+        assert comm.bytes_in == 8 * 1000 * (world - 1) + (0 if rank == 1 else 40)
+        # an override in rank 0's environment wins on every rank and nothing is timed
+        if rank == 0:
+            os.environ["TGP_DIST_GATHER"] = "p2p"
+        rec2 = TorchComm().probe_gather()
+        assert rec2 == {"skipped": "TGP_DIST_GATHER", "chosen": "p2p"}
+        json.dump(rec, open(os.path.join(out_dir, "probe%d.json" % rank), "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_panel_exchange_probe_gloo(tmp_path):
+    """TorchComm.probe_gather (what dist.enable() runs on worlds of more than one rank): both panel exchanges timed on every
+    rank, rank 0's clock decides, every rank ends with the same choice and the same record; four processes."""
+    import json
+    world = 4
+    mp.spawn(_probe_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    recs = [json.load(open(os.path.join(str(tmp_path), "probe%d.json" % r))) for r in range(world)]
+    assert all(r["chosen"] == recs[0]["chosen"] for r in recs)
+    assert all(r["allgather_GBps"] == recs[0]["allgather_GBps"] and r["p2p_GBps"] == recs[0]["p2p_GBps"] for r in recs)
+
+
 def _pair_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -298,6 +298,13 @@ def test_bench_self_launch_rehearsal(G):
     for key in ("chol_ms", "bulk_ms", "chain_ms", "gather_wait_ms", "trsv_ms", "predict_ms", "bytes_received"):
         assert len(pr[key]) == G and all(v >= 0 for v in pr[key]), key
     assert all(v > 0 for v in pr["chain_ms"]) and all(v > 0 for v in pr["bulk_ms"])
+    # counted from the tensors handed to the collectives: the ideal volume 4 N^2 (G-1)/G give or take the diagonal blocks
+    # (not exchanged), the padding of the gathered panels and the broadcasts (on top)
+    assert all(0.9 * out["bytes_received_expected"] <= v <= 1.5 * out["bytes_received_expected"] for v in pr["bytes_received"])
+    gp = out["gather_probe"]                       # dist.enable() timed both panel exchanges and rank 0 chose
+    assert gp["chosen"] in ("allgather", "p2p") and gp["allgather_GBps"] > 0 and gp["p2p_GBps"] > 0
+    assert out["collective_backend"]["backend"] == "gloo" and out["cpu_baseline"] == "see n_gpus=1 line"
+    assert "reflected" in out["owner_map"]
     # every rank receives the panels it does not own: ~ 4 N^2 (G-1)/G bytes (+ the diagonal-block broadcasts, + padding)
     exp = out["bytes_received_expected"]
     assert all(0.8 * exp < v < 1.6 * exp for v in pr["bytes_received"]), (pr["bytes_received"], exp)
@@ -386,3 +393,6 @@ def test_bench_multi_gpu_path_on_rccl_world_of_one():
     assert out["config"]["through_api"] and out["config"]["meanify"] and out["config"]["parallelism"] == "rowcyclic1"
     assert out["roofline"]["kernel"].startswith("syrk_distn") and 0.3 < out["roofline"]["frac"] < 1.0
     assert len(out["per_rank_ms_per_step"]["chain_ms"]) == 1 and out["per_rank_ms_per_step"]["bytes_received"] == [0.0]
+    assert out["gather_probe"]["skipped"] == "world of one"            # nothing to time with one rank: skipped cleanly
+    cb = out["collective_backend"]
+    assert cb["backend"] == "nccl" and cb["rccl_version"][0].isdigit(), cb

@@ -395,8 +395,14 @@ def test_multi_gpu_route_selection(monkeypatch):
             dist.engine_for(5)                                           # no engine, no process group: loud
     assert dist.engine_for(5) is None                                    # (the scope was left properly)
     monkeypatch.setenv("TGP_DIST", "1")
-    with pytest.raises(RuntimeError, match="TGP_DIST=1"):
-        dist.engine_for(10 ** 6)                                         # asked for by environment, torch.distributed not up
+    monkeypatch.setattr(dist, "_warned_no_group", False)
+    assert dist.engine_for(100) is None                                  # below the threshold: nothing is demanded, nothing said
+    with pytest.warns(RuntimeWarning, match="TGP_DIST=1"):
+        assert dist.engine_for(10 ** 6) is None                          # asked for by environment, torch.distributed not up:
+    import warnings                                                      # one warning, then the single-GPU path, quietly
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert dist.engine_for(10 ** 6) is None
     monkeypatch.delenv("TGP_DIST")
     with pytest.raises(ValueError):
         dist.scope("gpu")

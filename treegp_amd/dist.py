@@ -89,18 +89,72 @@ class TorchComm(object):
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self.native_gather = dist.get_backend(group) == "nccl"
-        # TGP_DIST_GATHER=p2p: the panel exchange as one send + one receive per peer instead of all_gather_into_tensor.  xGMI is
-        # point-to-point: a ring all-gather moves (G-1)/G of every panel through ONE link per rank, direct sends use all G-1
-        # links at once.  Off by default until an 8-GPU run says which of the two RCCL's all-gather is on this topology
-        # (DESIGN 7); exercised under gloo on CPUs (tests/test_dist_gloo.py) and, degenerate, with one rank on RCCL.
+        # The panel exchange: all_gather_into_tensor, or ("p2p") one send + one receive per peer.  xGMI is point-to-point: a
+        # ring all-gather moves (G-1)/G of every panel through ONE link per rank, direct sends use all G-1 links at once;
+        # which of the two RCCL's all-gather is on a given node is measured, not assumed: probe_gather() (called by
+        # dist.enable() on worlds of more than one rank) times both on a representative panel and rank 0's choice is
+        # broadcast.  TGP_DIST_GATHER=allgather|p2p overrides the probe.
         self.gather_mode = os.environ.get("TGP_DIST_GATHER", "allgather")
+        self.gather_probe = None             # what probe_gather() measured and chose (goes into the bench line)
+        self.bytes_in = 0                    # payload bytes this rank has received through the collectives below
         self.device = None                   # where host-side reductions have to be staged (RCCL: on the GPU)
         if self.native_gather:
             import torch
             self.device = torch.device("cuda", torch.cuda.current_device())
 
+    def probe_gather(self, elems=None, reps=3):
+        """Time the two panel exchanges on one representative panel (default 2 Mi doubles = 16 MiB per rank, the size of
+        a rank's share of a panel at N = 65 536 on 8 ranks), `reps` times each after one warm-up; rank 0 decides
+        (the faster by its own clock), the decision is broadcast so that every rank issues the same calls.
+        Collective.  Returns and stores the record; TGP_DIST_GATHER set: no timing, the override is recorded."""
+        import time
+        import torch
+        env = os.environ.get("TGP_DIST_GATHER")
+        if self.size == 1:
+            self.gather_probe = {"skipped": "world of one", "chosen": self.gather_mode}
+            return self.gather_probe
+        dev = self.device or torch.device("cpu")
+        code = torch.zeros(1, dtype=torch.float64, device=dev)
+        if self.rank == 0:
+            code[0] = {"allgather": 1.0, "p2p": 2.0}.get(env, 0.0)      # rank 0's environment decides whether to probe at all
+        self.dist.broadcast(code, src=0, group=self.group)
+        if int(code.item()) != 0:
+            self.gather_mode = "allgather" if int(code.item()) == 1 else "p2p"
+            self.gather_probe = {"skipped": "TGP_DIST_GATHER", "chosen": self.gather_mode}
+            return self.gather_probe
+        n = int(elems) if elems else (1 << 21)
+        inp = torch.full((n,), float(self.rank), dtype=torch.float64, device=dev)
+        out = torch.empty(n * self.size, dtype=torch.float64, device=dev)
+        sync = torch.cuda.synchronize if self.native_gather else (lambda: None)
+        res = {}
+        keep_bytes = self.bytes_in
+        for mode in ("allgather", "p2p"):
+            self.gather_mode = mode
+            ts = []
+            for it in range(reps + 1):
+                self.dist.barrier(group=self.group)
+                sync()
+                t0 = time.perf_counter()
+                self.all_gather_start(out, inp).wait()
+                sync()
+                ts.append(time.perf_counter() - t0)
+            ok = all(float(out[r * n]) == float(r) and float(out[(r + 1) * n - 1]) == float(r) for r in range(self.size))
+            if not ok:
+                raise RuntimeError("panel exchange %r delivered wrong data in the probe" % mode)
+            res[mode] = 8.0 * n * (self.size - 1) / min(ts[1:]) / 1e9       # payload received per rank and second
+        self.bytes_in = keep_bytes
+        t = torch.tensor([res["allgather"], res["p2p"]], dtype=torch.float64, device=dev)
+        self.dist.broadcast(t, src=0, group=self.group)                 # rank 0's clock decides for everybody
+        ag, pp = float(t[0]), float(t[1])
+        self.gather_mode = "p2p" if pp > 1.05 * ag else "allgather"     # the library collective unless direct sends clearly win
+        self.gather_probe = {"allgather_GBps": ag, "p2p_GBps": pp, "chosen": self.gather_mode, "payload_MB_per_rank": 8.0 * n / 1e6,
+                             "reps": reps, "this_rank": {"allgather_GBps": res["allgather"], "p2p_GBps": res["p2p"]}}
+        return self.gather_probe
+
     def broadcast(self, t, src):
         self.dist.broadcast(t, src=src, group=self.group)
+        if src != self.rank:
+            self.bytes_in += t.numel() * t.element_size()
 
     def all_reduce_sum(self, t):
         self.dist.all_reduce(t, group=self.group)
@@ -114,6 +168,7 @@ class TorchComm(object):
         if self.gather_mode == "p2p" and self.size > 1 and (self.native_gather or not inp.is_cuda):
             return self._p2p_gather(out, inp)
         if self.native_gather:
+            self.bytes_in += (self.size - 1) * inp.numel() * inp.element_size()
             return _Work(self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True), out)
         self.all_gather(out, inp)
         return _Done(out)
@@ -127,10 +182,12 @@ class TorchComm(object):
             ops.append(dist.P2POp(dist.isend, inp, dst, group=self.group))
             ops.append(dist.P2POp(dist.irecv, out[src * n:(src + 1) * n], src, group=self.group))
         out[self.rank * n:(self.rank + 1) * n].copy_(inp)
+        self.bytes_in += (self.size - 1) * n * inp.element_size()
         return _Works(dist.batch_isend_irecv(ops), out, stream_ordered=self.native_gather)
 
     def all_gather(self, out, inp):
         """out (size * len(inp)) <- concatenation of every rank's inp"""
+        self.bytes_in += (self.size - 1) * inp.numel() * inp.element_size()
         if self.native_gather:
             self.dist.all_gather_into_tensor(out, inp, group=self.group)
         else:
@@ -493,7 +550,9 @@ class DistributedCholesky(object):
         self.update_launches = 0
         self.chain_ms = 0.0           # side stream: panel chains (diagonal blocks, broadcasts, local solves, gathers, strips)
         self.wait_ms = 0.0            # main stream: stalled behind the chain / the gathers between two bulk updates
-        self.bytes_received = 0       # broadcast + all-gather payload this rank received (expected ~ 4 N^2 B (G-1)/G)
+        self.bytes_received = 0       # payload this rank received during the last factorize(): counted by the communicator from
+                                      # the tensors handed to its collectives (TorchComm.bytes_in); for communicators that do
+                                      # not count (tests' in-process ones) the schedule's own sum, ~ 4 N^2 B (G-1)/G
 
     def _local_update_flops(self, k):
         """2 * 256 flops per lower-triangle element of this rank's block rows > k"""
@@ -518,6 +577,7 @@ class DistributedCholesky(object):
         ops, comm, G, g, nB, GS = self.ops, self.comm, self.G, self.g, self.nB, self.group
         events, chain_events, wait_events = [], [], []
         self.update_flops, self.update_launches, self.bytes_received = 0.0, 0, 0
+        bytes_in0 = getattr(comm, "bytes_in", None)
         # also build the replicated factor for the solves (a world of one's share already is that factor: no copies)
         keep = bool(getattr(ops, "replicated", False)) and bool(getattr(ops, "keep_copies", True))
 
@@ -660,6 +720,8 @@ class DistributedCholesky(object):
         self.update_ms = sum(a.elapsed_time(b) for a, b in events) if events else 0.0
         self.chain_ms = sum(a.elapsed_time(b) for a, b in chain_events) if chain_events else 0.0
         self.wait_ms = sum(a.elapsed_time(b) for a, b in wait_events) if wait_events else 0.0
+        if bytes_in0 is not None:
+            self.bytes_received = comm.bytes_in - bytes_in0
         t = ops.zeros(1)
         t[0] = -(float(mine) if mine > 0 else big)
         comm.all_reduce_max(t)
@@ -942,6 +1004,8 @@ def enable(comm=None, device=None, min_n=None, profile=False, thread_local=False
     global _process_engine
     from . import ops as _ops
     eng = DistEngine(comm=comm, device=device, min_n=min_n, profile=profile)
+    if hasattr(eng.comm, "probe_gather") and eng.comm.gather_probe is None:
+        eng.comm.probe_gather()               # which panel exchange this node's links favour (collective; rank 0 decides)
     if thread_local:
         _tls.engine = eng
     else:
@@ -960,15 +1024,28 @@ def disable():
     _ops.set_pair_comm(None)
 
 
-def _current_engine():
-    global _process_engine
+_warned_no_group = False
+
+
+def _current_engine(n=None):
+    """The enabled engine of this thread / process.  TGP_DIST=1 enables one implicitly on first need -- a solve of at least
+    TGP_DIST_MIN_N points (`n`; None: any) -- when torch.distributed is initialised; when it is not (a plain single-GPU
+    script run with the variable exported globally) the process stays on its one GPU, with one warning."""
+    global _process_engine, _warned_no_group
     eng = getattr(_tls, "engine", None) or _process_engine
     if eng is None and os.environ.get("TGP_DIST") == "1":
+        if n is not None and n < int(os.environ.get("TGP_DIST_MIN_N", DEFAULT_MIN_N)):
+            return None                               # below the threshold no engine is needed: do not demand one
         import sys
         td = sys.modules.get("torch.distributed")
         if td is None or not (td.is_available() and td.is_initialized()):
-            raise RuntimeError("TGP_DIST=1 but torch.distributed is not initialised in this process "
-                               "(init_process_group first, or call treegp_amd.dist.enable(comm))")
+            if not _warned_no_group:
+                import warnings
+                warnings.warn("TGP_DIST=1 but torch.distributed is not initialised in this process: staying on the "
+                              "single-GPU path (init_process_group first, or call treegp_amd.dist.enable(comm))",
+                              RuntimeWarning, stacklevel=3)
+                _warned_no_group = True
+            return None
         eng = enable()
     return eng
 
@@ -1008,5 +1085,5 @@ def engine_for(n):
             else:
                 raise RuntimeError('backend="dist" needs treegp_amd.dist.enable(comm) or an initialised torch.distributed')
         return eng
-    eng = _current_engine()
+    eng = _current_engine(n)
     return eng if (eng is not None and n >= eng.min_n) else None
