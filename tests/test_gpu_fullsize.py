@@ -52,6 +52,47 @@ def test_config4_size_residual_and_subset(n):
     assert np.isfinite(logdet)
 
 
+@pytest.mark.parametrize("n", [32768, 65536])
+def test_alpha_and_predictions_against_an_independent_fp64_solver(n):
+    """Forward error at configs[2] / configs[3] size, not just the backward residual: the same problem solved by a chain that
+    shares nothing with libtgp.so -- K built by torch elementwise ops in fp64, factorised by torch.linalg.cholesky
+    (rocSOLVER), solved by torch.cholesky_solve -- and alpha (1e-9 of its scale), the log-determinant and 4096 predicted
+    values (1e-10 of the field's scale, the north star's bound) compared.  Test-only use of the vendor solver: the package
+    never calls it.  32 GiB dense + the factor's copy at N = 65 536 sit beside the packed factor in 288 GB."""
+    import torch
+    _lib, ops, spec, kw, X, y, y_err, Xs = _setup(n, 4096)
+    alpha, logdet, ydota, _ = ops.gp_solve(spec, X, y, y_err)
+    yp = ops.gp_predict(spec, X, alpha, Xs)
+    dev = torch.device("cuda", 0)
+    tX, tXs = torch.from_numpy(X).to(dev), torch.from_numpy(Xs).to(dev)
+    a, b, c = kw["a"], kw["b"], kw["c"]
+
+    def kern(P, Q):                                  # exp(-(1/2) d^T invLam d), d = p - q   (treegp/kernels.py:114-126)
+        d0 = P[:, None, 0] - Q[None, :, 0]
+        d1 = P[:, None, 1] - Q[None, :, 1]
+        return torch.exp(-0.5 * (a * d0 * d0 + 2.0 * b * d0 * d1 + c * d1 * d1))
+
+    K = torch.empty((n, n), dtype=torch.float64, device=dev)
+    for s in range(0, n, 4096):
+        K[s:s + 4096] = kern(tX[s:s + 4096], tX)
+    K.diagonal().copy_(kw["amp"] + torch.from_numpy(y_err ** 2).to(dev))      # diag := amp (kernels.py:121), + y_err^2 (gp_interp.py:180)
+    L, info = torch.linalg.cholesky_ex(K)
+    assert int(info) == 0
+    del K
+    a_ref = torch.cholesky_solve(torch.from_numpy(y).to(dev)[:, None], L)[:, 0]
+    ld_ref = float(2.0 * torch.log(L.diagonal()).sum())
+    del L
+    yp_ref = (kern(tXs, tX) @ a_ref).cpu().numpy()
+    a_ref = a_ref.cpu().numpy()
+    torch.cuda.empty_cache()
+    err_a = np.abs(alpha - a_ref).max() / np.abs(a_ref).max()
+    err_p = np.abs(yp - yp_ref).max() / np.abs(yp_ref).max()
+    print("N=%d: alpha %.2e  predict %.2e  logdet %.2e (relative)" % (n, err_a, err_p, abs(logdet - ld_ref) / abs(ld_ref)))
+    assert err_a <= 1e-9, err_a
+    assert err_p <= 1e-10, err_p
+    np.testing.assert_allclose(logdet, ld_ref, rtol=1e-11)
+
+
 def test_config3_size_vonkarman_residual():
     """configs[2]: N=32768 von Karman kernel: device residual + subset of K against the oracle."""
     from oracle import gp_oracle as O
