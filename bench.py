@@ -64,7 +64,17 @@ def cpu_baseline(n_s, m_s, n_headline):
            "cross_kernel": med["cross_kernel"] * (m_h * n_headline) / (m_s * n_s),
            "matvec": med["matvec"] * (m_h * n_headline) / (m_s * n_s)}
     ext_total = sum(ext.values())
+    # BASELINE.md section 3's other sizes: configs[0] in full, configs[2] sampled (von Karman K build per element + dpotrf)
+    c0 = R.config0_passes(threads)
+    c2 = R.config2_sample(threads)
+    key32 = [k for k in c2 if k.startswith("extrapolated_n")][0]
+    c2[key32]["cholesky_s_at_configs1_gflops"] = 32768 ** 3 / 3.0 / (gf * 1e9)      # dpotrf at N = 32768 at configs[1]'s measured rate
     return {
+        "configs": {"configs[0]": dict(c0, sample="in full: 1-D AnisotropicRBF N=512 / M=1024, the reference's call sequence, "
+                                                  "1 warm-up + 5 passes, median per phase"),
+                    "configs[2]": dict(c2, sample="SAMPLED at N=%d of 32768: von Karman K build (pdist + scipy.special.kv + squareform, "
+                                                  "single-threaded), dpotrf, cho_solve; the N=32768 figures are labelled "
+                                                  "extrapolations" % c2["n_sample"])},
         "value": (n_s + m_s) / med["total"], "unit": "points/s", "cores": max(int(round(eff)), 1), "blas_threads": int(threads),
         "kind": "port",
         "sample": "configs[1] in full: same star-field recipe at N=%d train / M=%d predict; the reference's SciPy calls "
@@ -159,7 +169,7 @@ def configs_measured(lib, ctx, ops, _lib):
         if it == 0:
             continue                                       # warm-up (workspace allocation)
         for k, v in (("kbuild_ms", tm[0]), ("chol_ms", tm[1]), ("trsv_ms", tm[2]), ("predict_ms", tp), ("wall_ms", wall),
-                     ("syrk_ms", tm[5]), ("syrk_flops", tm[7])):
+                     ("syrk_ms", tm[5]), ("syrk_flops", tm[7]), ("sweeps", tm[10])):
             acc[k] = acc.get(k, 0.0) + v / reps
     # likelihood-only evaluations (no alpha): what one step of an ML fit costs
     t0 = time.perf_counter()
@@ -193,11 +203,25 @@ def configs_measured(lib, ctx, ops, _lib):
                 "gp_solves_per_sec": 1e3 / (acc["kbuild_ms"] + acc["chol_ms"] + acc["trsv_ms"]),
                 "likelihood_evaluations_per_sec": 1e3 / lik_ms,
                 "cholesky_tflops_fp64": chol_tf, "cholesky_frac_mfma_peak": chol_tf / FP64_MFMA_PEAK_TFLOPS,
-                "trsv_frac_hbm": (8.0 * npad * (npad + 1)) / (acc["trsv_ms"] * 1e-3) / 8e12,      # both sweeps: L read twice
+                "trsv_frac_hbm": (acc["sweeps"] * 4.0 * npad * (npad + 1)) / (acc["trsv_ms"] * 1e-3) / 8e12,      # L read once per sweep that ran
+                "sweeps_per_solve": int(round(acc["sweeps"])),
                 "predict_pairs_per_sec": float(m) * n / (acc["predict_ms"] * 1e-3),
                 "predict_points_per_sec": m / (acc["predict_ms"] * 1e-3)})
     for b in bufs + [da, dys]:
         b.free()
+    # the same configuration through the drop-in API (host arrays in, NumPy out)
+    from treegp_amd.synthetic import headline_kernel_string
+    api1 = api_route(X, y, y_err, Xs, headline_kernel_string(), passes=5)
+    api1["host_tax_ms"] = api1["total"] - (acc["kbuild_ms"] + acc["chol_ms"] + acc["trsv_ms"] + acc["predict_ms"])
+    out[-1]["api_route_ms"] = api1
+    # (0) configs[0]: the reference's own CPU-runnable case on the GPU, through the API (plumbing; the device is idle most of it)
+    rng0 = np.random.default_rng(20240613)
+    X0 = rng0.uniform(-10.0, 10.0, (512, 1))
+    y0 = np.sin(X0[:, 0]) + 0.1 * rng0.standard_normal(512)
+    e0 = 0.1 * rng0.uniform(0.8, 1.2, 512)
+    api0 = api_route(X0, y0, e0, np.linspace(-10.0, 10.0, 1024)[:, None], "1.0**2 * AnisotropicRBF(scale_length=[2.0])", passes=5)
+    out.insert(0, {"config": "configs[0]: 1-D AnisotropicRBF N=512, predict 1024, through the API", "api_route_ms": api0,
+                   "points_per_sec": 1536.0 / (api0["total"] * 1e-3)})
     # (ii) configs[2]: 2-D VonKarman N = 32768 with the two-pcf hyper-parameter fit
     n = 32768
     X, y, y_err, Xs = star_field(n, n)
@@ -210,7 +234,7 @@ def configs_measured(lib, ctx, ops, _lib):
         best = min(best, _lib.timings(ctx)[0])
     for b in (dX, de, dA):
         b.free()
-    VK_CEILING, LDS_ATOMIC_CEILING = 1.745e11, 1.04e11      # profiles/r02_vk_ceiling.txt, r02_lds_atomic_ceiling.txt
+    VK_CEILING = 1.745e11                                    # profiles/r02_vk_ceiling.txt
     elems = n * (n + 1) / 2.0
     gp = treegp_amd.GPInterpolation(kernel="1.0**2 * VonKarman(length_scale=0.1)", optimizer="two-pcf", nbins=20, normalize=True)
     gp.initialize(X, y, y_err)
@@ -239,10 +263,29 @@ def configs_measured(lib, ctx, ops, _lib):
                 "kbuild_frac_of_vk_ceiling": elems / (best * 1e-3) / VK_CEILING,
                 "two_pcf_fit_ms": fit_ms, "solve_plus_predict_32768_ms": solve_predict_ms,
                 "kk_log_ms_incl_copies": kk_ms, "kk_log_pairs_per_sec": n * (n - 1) / 2.0 / (kk_ms * 1e-3),
-                # > 1 by design: the crowded bins accumulate in registers, so fewer atomics than the ceiling's one-per-sum are issued
-                "kk_log_over_lds_atomic_ceiling": n * (n - 1) / 2.0 / (kk_ms * 1e-3) / LDS_ATOMIC_CEILING,
+                # (round 4: the ratio to the one-LDS-atomic-per-sum rate was dropped -- the kernel accumulates the crowded bins in
+                # registers and issues far fewer atomics, so that rate does not bound it; pairs/s stands alone)
                 "bootstrap_444_resamples_21x21_ms": {"device_incl_copies": boot_dev, "wall": boot_wall}})
     return out
+
+
+def api_route(X, y, y_err, Xs, kernel_string, passes=5):
+    """initialize() + predict() of treegp_amd.GPInterpolation from host arrays, `passes` timed passes after one warm-up (the
+    first pass sizes the host-boundary buffers): median milliseconds per phase, plus the spread."""
+    import treegp_amd
+    gp1 = treegp_amd.GPInterpolation(kernel=kernel_string, optimizer="none", normalize=True, white_noise=0.0, backend="single")
+    rows = []
+    for it in range(passes + 1):
+        t0 = time.perf_counter()
+        gp1.initialize(X, y, y_err)
+        t1 = time.perf_counter()
+        gp1.predict(Xs)
+        t2 = time.perf_counter()
+        if it:
+            rows.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t2 - t0) * 1e3))
+    rows = np.array(rows)
+    return {"initialize": float(np.median(rows[:, 0])), "predict": float(np.median(rows[:, 1])), "total": float(np.median(rows[:, 2])),
+            "total_min": float(rows[:, 2].min()), "total_max": float(rows[:, 2].max()), "passes": passes}
 
 
 def collective_backend():
@@ -356,7 +399,8 @@ def main():
                 raise RuntimeError("tgp_d_gp_predict rc=%d" % rc)
             tp = _lib.timings(ctx)[3]
             for k, v in (("kbuild_ms", tm[0]), ("chol_ms", tm[1]), ("trsv_ms", tm[2]), ("predict_ms", tp),
-                         ("syrk_ms", tm[5]), ("syrk_launches", tm[6]), ("syrk_flops", tm[7]), ("kbuild_bytes", tm[8])):
+                         ("syrk_ms", tm[5]), ("syrk_launches", tm[6]), ("syrk_flops", tm[7]), ("kbuild_bytes", tm[8]),
+                         ("sweeps", tm[10])):
                 acc[k] = acc.get(k, 0.0) + v
     else:
         # the drop-in API itself (treegp/gp_interp.py:196-227, 143-194): initialize() takes the data -- mean function at
@@ -377,7 +421,8 @@ def main():
             if engine is None:
                 tm = _lib.timings(ctx)       # of the last calls on the process-wide context: the solve, then the predict
                 for k, v in (("kbuild_ms", tm[0]), ("chol_ms", tm[1]), ("trsv_ms", tm[2]), ("predict_ms", tm[3]),
-                             ("syrk_ms", tm[5]), ("syrk_launches", tm[6]), ("syrk_flops", tm[7]), ("kbuild_bytes", tm[8])):
+                             ("syrk_ms", tm[5]), ("syrk_launches", tm[6]), ("syrk_flops", tm[7]), ("kbuild_bytes", tm[8]),
+                             ("sweeps", tm[10])):
                     acc[k] = acc.get(k, 0.0) + v
 
     for _ in range(args.warmup):
@@ -484,14 +529,17 @@ def main():
                                           "frac": out["kbuild_GBps"] / 8000.0, "traffic": kb_t, "traffic_source": kb_src,
                                           "algorithmic_bytes": kb_bytes / K,
                                           "kernel": "kbuild_slab_kernel<GAUSS>", "avg_launch_ms": acc["kbuild_ms"] / K}
-            # SURVEY 8(d) prices the solves at two reads of the packed factor (forward + backward sweep, ~8 Np^2 B).  From
-            # round 3 the right-hand side rides through the factorisation as an extra matrix row (L^-1 y comes out of it), so
-            # only the backward sweep is left: ONE read of L, ~4 Np^2 B, is the algorithmic traffic of what runs here
-            tr_bytes = (1 if acc.get("sweeps_per_solve", 2) == 1 else 2) * 8.0 * (npad * (npad + 1) / 2.0)
+            # SURVEY 8(d) prices the solves at two reads of the packed factor (forward + backward sweep, ~8 Np^2 B).  When n is not a
+            # multiple of 256 the right-hand side rides through the factorisation as an extra matrix row (L^-1 y comes out of it)
+            # and only the backward sweep is left: ONE read of L.  The sweeps that really ran are counted by the library
+            # (tgp_last_timings[10]); the multi-GPU route's replicated solve always runs both.
+            sweeps = int(round(acc["sweeps"] / K)) if acc.get("sweeps", 0) > 0 else 2
+            tr_bytes = sweeps * 8.0 * (npad * (npad + 1) / 2.0)
             tr_rate = tr_bytes * K / (acc["trsv_ms"] * 1e-3) / 1e9
             out["roofline_trsv"] = {"bound": "hbm", "achieved": tr_rate, "peak": 8000.0, "unit": "GB/s", "frac": tr_rate / 8000.0,
-                                    "traffic": None, "algorithmic_bytes": tr_bytes,
-                                    "kernel": "potrs: forward + backward sweep", "avg_ms": acc["trsv_ms"] / K}
+                                    "traffic": None, "algorithmic_bytes": tr_bytes, "sweeps_per_solve": sweeps,
+                                    "kernel": "potrs: forward + backward sweep" if sweeps == 2 else "potrs: backward sweep (L^-1 y from the augmented row)",
+                                    "avg_ms": acc["trsv_ms"] / K}
             # the fused predict is fp64-VALU-bound, 30 algorithmic flops per (query, training point) pair
             m_rank = m if world == 1 else -(-m // world)
             pr_tf = 30.0 * m_rank * n * K / (acc["predict_ms"] * 1e-3) / 1e12
@@ -503,21 +551,12 @@ def main():
                                        "valu_issue_frac_at_2p4ghz": m_rank * n * K / (acc["predict_ms"] * 1e-3) * 16.4 / (256 * 4 * 16 * 2.4e9)}
             out["phases_ms_per_step"] = {k: acc[k] / K for k in ("kbuild_ms", "chol_ms", "trsv_ms", "predict_ms", "syrk_ms")}
         if not use_dist and not api and not args.no_configs:
-            # the same workload once more through the drop-in API on this one GPU (host buffers in, NumPy out): what the
-            # N > 1 lines, which always step through GPInterpolation, are to be compared with
-            import treegp_amd
-            gp1 = treegp_amd.GPInterpolation(kernel=headline_kernel_string(), optimizer="none", normalize=True, white_noise=0.0,
-                                             backend="single")
-            api_ms = {}
-            for it in range(2):                               # the first pass warms the host-boundary buffers
-                t0 = time.perf_counter()
-                gp1.initialize(X, y, y_err)
-                t1 = time.perf_counter()
-                gp1.predict(Xs)
-                t2 = time.perf_counter()
-                api_ms = {"initialize": (t1 - t0) * 1e3, "predict": (t2 - t1) * 1e3, "total": (t2 - t0) * 1e3}
-            out["api_route_ms_per_step_one_gpu"] = api_ms
-            del gp1
+            # the same workloads once more through the drop-in API on this one GPU (host buffers in, NumPy out): what the
+            # N > 1 lines, which always step through GPInterpolation, are to be compared with.  Medians of 5 passes after a
+            # warm-up; `host_tax_ms` = API total minus the device-resident step of the same size measured above / below.
+            out["api_route_ms"] = {"headline": api_route(X, y, y_err, Xs, headline_kernel_string(), passes=5)}
+            out["api_route_ms"]["headline"]["host_tax_ms"] = out["api_route_ms"]["headline"]["total"] - ms_step
+            out["api_route_ms_per_step_one_gpu"] = {k: out["api_route_ms"]["headline"][k] for k in ("initialize", "predict", "total")}
         if not use_dist and not args.no_configs:
             out["configs_measured"] = configs_measured(lib, ctx, ops, _lib)
         if not use_dist and args.cpu_sample > 0:

@@ -15,6 +15,7 @@ treegp user gets today:
 import time
 
 import numpy as np
+from scipy import special
 from scipy.linalg import cho_solve, cholesky
 from scipy.spatial.distance import cdist, pdist, squareform
 
@@ -134,3 +135,76 @@ def timed_passes(X, y, y_err, Xs, invLam, amp, threads, passes=5, budget_s=90.0)
                 break
     med = {k: float(np.median([r[k] for r in rows])) for k in rows[0]}
     return med, len(rows)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the other BASELINE.json configs of BASELINE.md section 3
+# ---------------------------------------------------------------------------------------------------
+def config0_passes(threads, passes=5):
+    """configs[0] in full -- 1-D AnisotropicRBF, N = 512 training / 1024 prediction points, the reference's own
+    CPU-runnable case (tests/test_gp_interp.py style: X ~ U(-10, 10), scale_length 2, noise 0.1, X* = linspace):
+    1 warm-up + `passes` timed passes of the same call sequence, median per phase."""
+    from threadpoolctl import threadpool_limits
+    rng = np.random.default_rng(20240613)
+    n, m = 512, 1024
+    X = rng.uniform(-10.0, 10.0, (n, 1))
+    y = np.sin(X[:, 0]) + 0.1 * rng.standard_normal(n)
+    y_err = 0.1 * rng.uniform(0.8, 1.2, n)
+    Xs = np.linspace(-10.0, 10.0, m)[:, None]
+    invLam = np.array([[1.0 / 2.0 ** 2]])                   # scale_length=[2.0]  (kernels.py:95-112)
+    rows = []
+    with threadpool_limits(limits=int(threads), user_api="blas"):
+        solve_predict(X, y - y.mean(), y_err, Xs, invLam, 1.0, timings={})
+        for _ in range(passes):
+            tm = {}
+            solve_predict(X, y - y.mean(), y_err, Xs, invLam, 1.0, timings=tm)
+            rows.append(tm)
+    med = {k: float(np.median([r[k] for r in rows])) for k in rows[0]}
+    return {"n_train": n, "m_predict": m, "passes": passes, "phases_s": med, "value": (n + m) / med["total"], "unit": "points/s"}
+
+
+def von_karman_self(X, length_scale):
+    """VonKarman.__call__(X) call for call (kernels.py:249-262): pdist(euclidean), scipy.special.kv on the
+    non-zero separations, squareform, the limit on the diagonal."""
+    dists = pdist(X, metric="euclidean")
+    Filter = dists != 0.0
+    K = np.zeros_like(dists)
+    K[Filter] = (dists[Filter] / length_scale) ** (5.0 / 6.0) * special.kv(5.0 / 6.0, 2 * np.pi * dists[Filter] / length_scale)
+    K = squareform(K)
+    lim0 = special.gamma(5.0 / 6.0) / (2 * (np.pi ** (5.0 / 6.0)))
+    np.fill_diagonal(K, lim0)
+    K /= lim0
+    return K
+
+
+def config2_sample(threads, n_s=2048, n_full=32768, passes=5, length_scale=0.1):
+    """configs[2] SAMPLED: the von Karman K build (single-threaded pdist + kv + squareform), dpotrf and cho_solve at
+    n_s points of the same star-field recipe, median of `passes` after a warm-up; per-element / per-flop rates and a
+    LABELLED extrapolation to N = n_full (K build by N^2, dpotrf by N^3 at the measured GFLOP/s of the larger
+    configs[1] factorisation when the caller supplies it)."""
+    from threadpoolctl import threadpool_limits
+    rng = np.random.default_rng(20240613)
+    X = rng.uniform(0.0, 1.0, (n_s, 2))
+    y = rng.standard_normal(n_s)
+    y_err = 0.03 * rng.uniform(0.8, 1.2, n_s)
+    rows = []
+    with threadpool_limits(limits=int(threads), user_api="blas"):
+        for it in range(passes + 1):
+            t0 = time.perf_counter()
+            K = von_karman_self(X, length_scale) + np.eye(n_s) * y_err ** 2
+            t1 = time.perf_counter()
+            factor = (cholesky(K, overwrite_a=True, lower=False), False)
+            t2 = time.perf_counter()
+            cho_solve(factor, y, overwrite_b=False)
+            t3 = time.perf_counter()
+            if it:
+                rows.append({"kbuild": t1 - t0, "cholesky": t2 - t1, "cho_solve": t3 - t2})
+    med = {k: float(np.median([r[k] for r in rows])) for k in rows[0]}
+    ns_per_element = med["kbuild"] / (n_s * (n_s - 1) / 2.0) * 1e9
+    return {"n_sample": n_s, "passes": passes, "phases_s": med,
+            "kbuild_ns_per_element": ns_per_element, "kbuild_elements_per_sec": 1e9 / ns_per_element,
+            "dpotrf_gflops_at_sample": n_s ** 3 / 3.0 / med["cholesky"] / 1e9,
+            "extrapolated_n%d" % n_full: {
+                "label": "EXTRAPOLATED, not measured: K build x (N/%d)^2 (single-threaded pdist + scipy.special.kv + "
+                         "squareform), cho_solve x (N/%d)^2" % (n_s, n_s),
+                "kbuild_s": med["kbuild"] * (n_full / n_s) ** 2, "cho_solve_s": med["cho_solve"] * (n_full / n_s) ** 2}}

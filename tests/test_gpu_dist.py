@@ -359,7 +359,17 @@ def test_bench_line_schema_single_gpu():
     assert cb["kind"] == "port" and 1 <= cb["cores"] <= cb["blas_threads"] and cb["passes"] >= 3
     assert out["api_route_ms_per_step_one_gpu"]["total"] > 0.9 * out["ms_per_step"]       # the same work through GPInterpolation
     # configs[1] and configs[2] ride on the same line
-    c1, c2 = out["configs_measured"]
+    c0, c1, c2 = out["configs_measured"]
+    assert "N=512" in c0["config"] and c0["api_route_ms"]["total"] > 0 and c0["api_route_ms"]["passes"] >= 5
+    assert c1["api_route_ms"]["passes"] >= 5 and c1["api_route_ms"]["host_tax_ms"] < c1["api_route_ms"]["total"]
+    assert c1["sweeps_per_solve"] == 2 and out["roofline_trsv"]["sweeps_per_solve"] == 2
+    hl = out["api_route_ms"]["headline"]
+    assert hl["passes"] >= 5 and hl["total_min"] <= hl["total"] <= hl["total_max"]
+    cfgs = out["cpu_baseline"]["configs"]
+    assert cfgs["configs[0]"]["n_train"] == 512 and cfgs["configs[0]"]["passes"] >= 5 and cfgs["configs[0]"]["value"] > 0
+    c2b = cfgs["configs[2]"]
+    assert c2b["n_sample"] >= 2048 and c2b["kbuild_ns_per_element"] > 0 and "EXTRAPOLATED" in c2b["extrapolated_n32768"]["label"]
+    assert "kk_log_over_lds_atomic_ceiling" not in c2 and c2["kk_log_pairs_per_sec"] > 0
     for key in ("ms", "gp_solves_per_sec", "likelihood_evaluations_per_sec", "cholesky_tflops_fp64", "cholesky_frac_mfma_peak",
                 "trsv_frac_hbm", "predict_pairs_per_sec", "phases_ms"):
         assert key in c1, key

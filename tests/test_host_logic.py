@@ -444,3 +444,39 @@ def test_reflected_block_cyclic_owner_map_partitions_and_balances():
         assert max(work) / (sum(work) / G) < tol, (G, nB, max(work) / (sum(work) / G))
         plain = [sum(b + 0.5 for b in range(r, nB, G)) for r in range(G)]
         assert max(plain) / (sum(plain) / G) > max(work) / (sum(work) / G)
+
+
+def test_device_errors_inside_one_likelihood_evaluation(monkeypatch):
+    """treegp/log_likelihood.py:38-39 turns any failure of one evaluation into -inf.  Here: run-time device errors (rc -2)
+    likewise, with a RuntimeWarning; argument errors (rc -1) raise; TGP_ML_STRICT=1 raises both."""
+    import warnings
+    from treegp_amd import _lib, ops
+    import sys
+    import treegp_amd  # noqa: F401
+    from treegp_amd.kernels import eval_kernel
+    mod = sys.modules["treegp_amd.log_likelihood"]
+
+    def failing(rc):
+        def f(*a, **k):
+            err = _lib.TgpError("tgp_gp_solve failed (%d): hipMalloc: out of memory" % rc)
+            err.rc = rc
+            raise err
+        return f
+
+    monkeypatch.setattr(ops, "_dist_engine", lambda n, ctx: None)
+    ll = mod.log_likelihood(np.zeros((10, 2)), np.zeros(10), np.ones(10))
+    k = eval_kernel("1.0**2 * AnisotropicRBF(invLam=array([[30., 4.], [4., 20.]]))")
+    monkeypatch.delenv("TGP_ML_STRICT", raising=False)
+    monkeypatch.setattr(ops, "gp_solve", failing(-2))
+    with pytest.warns(RuntimeWarning, match="counts as -inf"):
+        assert ll.log_likelihood(k) == -np.inf
+    with pytest.warns(RuntimeWarning):
+        val, grad = ll.log_likelihood_gradient(k)
+    assert val == -np.inf and np.all(grad == 0)
+    monkeypatch.setattr(ops, "gp_solve", failing(-1))
+    with pytest.raises(_lib.TgpError):
+        ll.log_likelihood(k)
+    monkeypatch.setattr(ops, "gp_solve", failing(-2))
+    monkeypatch.setenv("TGP_ML_STRICT", "1")
+    with pytest.raises(_lib.TgpError):
+        ll.log_likelihood(k)

@@ -217,7 +217,9 @@ def check(ctx, rc, what):
     """rc < 0 -> TgpError with the library's message; rc > 0 is returned to the caller."""
     if rc < 0:
         msg = load_library().tgp_last_error(ctx)
-        raise TgpError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+        err = TgpError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+        err.rc = rc                    # -1: bad argument; -2: a HIP call failed (out of memory, device error, ...)
+        raise err
     return rc
 
 

@@ -393,7 +393,19 @@ class HipLocalOps(object):
         return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
 
     # -- factorisation ---------------------------------------------------------------------------
+    def detach_replica(self):
+        """the replicated factor and W have been handed out (a borrowed tgp_factor): forget them, allocate anew on demand"""
+        self.Afull = None
+        self.W = None
+
+    def ensure_replica(self):
+        if self.W is None:
+            self.W = self.torch.empty(self.Np * 128, dtype=self.torch.float64, device=self.device)
+        if self.keep_copies and self.Afull is None:
+            self.Afull = self.torch.empty(int(self.lib.tgp_panel_elems(self.Np)), dtype=self.torch.float64, device=self.device)
+
     def kbuild(self, dX, dyerr):
+        self.ensure_replica()
         self._chk(self.lib.tgp_dd_kbuild(self.ctx, C.byref(self.kc), self._p(dX), self.n, self._p(dyerr), self._p(self.A),
                                          self._p(self.d_loff), self.G, self.g), "tgp_dd_kbuild")
 
@@ -441,6 +453,9 @@ class HipLocalOps(object):
             return
         self._chk(self.lib.tgp_dd_update_group(ctx, self._p(self.A), self._p(self.d_loff), self.Np, k, self.G, self.g, ns,
                                                ptrs, cm, col_lo, col_hi), "tgp_dd_update_group", ctx)
+
+    def timing_event(self):
+        return self.torch.cuda.Event(enable_timing=True)
 
     def fused_ok(self):
         """the whole update of a group as one launch that signals the panel chain from inside (tgp_dd_update_group_fused):
@@ -576,6 +591,8 @@ class DistributedCholesky(object):
         at 512 and 3.5 % at 1024 -- the single-GPU driver's schedule, with collectives."""
         ops, comm, G, g, nB, GS = self.ops, self.comm, self.G, self.g, self.nB, self.group
         events, chain_events, wait_events = [], [], []
+        # the chain is timed in every run that can act on it (rank-local events, a few microseconds per group)
+        chain_timer = self.timer or getattr(ops, "timing_event", None)
         self.update_flops, self.update_launches, self.bytes_received = 0.0, 0, 0
         bytes_in0 = getattr(comm, "bytes_in", None)
         # also build the replicated factor for the solves (a world of one's share already is that factor: no copies)
@@ -604,14 +621,14 @@ class DistributedCholesky(object):
 
         def side_group(k, bufs):
             """panels k .. k+GS-1 (those that exist) on the side stream; returns [(gather handle, cmax)] per panel"""
-            if self.timer is not None:
-                c0 = self.timer()
+            if chain_timer is not None:
+                c0 = chain_timer()
                 c0.record()                                      # on the side stream (the caller's `with ops.on_side()`)
             try:
                 return _side_group(k, bufs)
             finally:
-                if self.timer is not None:
-                    c1 = self.timer()
+                if chain_timer is not None:
+                    c1 = chain_timer()
                     c1.record()
                     chain_events.append((c0, c1))
 
@@ -648,11 +665,24 @@ class DistributedCholesky(object):
         # persistent grid that keeps compute units clear for the chain, whose diagonal blocks then take a unit of their own.
         # TGP_DIST_QUEUE: -1 decide per step (default), 0 never, 1..3 always with that many units per shader engine.
         # Rank-local decisions: no collective depends on them.
+        # How long a group's chain takes is MEASURED, not assumed: the side stream's span of every group is timed (it
+        # contains the broadcasts and panel exchanges of a real node), and a step is chain-bound when the last chain that
+        # has finished took longer than this step's bulk would with every slot.  TGP_DIST_CHAIN_US=<us per panel> replaces
+        # the measurement by a constant (tests; rounds 2-3 used 600, tuned on one GPU without communication, which
+        # cost 3.7 % at 8 ranks because it kept units clear for a chain that did not need them).
         queue_mode = int(os.environ.get("TGP_DIST_QUEUE", "-1"))
-        chain_us = float(os.environ.get("TGP_DIST_CHAIN_US", "600")) * GS       # one group's chain beside the bulk
+        chain_env = os.environ.get("TGP_DIST_CHAIN_US")
         can_queue = queue_mode != 0 and hasattr(ops, "queue_reset")
         if can_queue:
             ops.queue_reset()
+
+        def chain_us_estimate():
+            if chain_env is not None:
+                return float(chain_env) * GS
+            for c0, c1 in reversed(chain_events):                # the most recent chain that is known to have finished
+                if c1.query():
+                    return 1e3 * c0.elapsed_time(c1)
+            return 0.0                                           # nothing measured yet: plain launches
         fused = hasattr(ops, "update_group_fused") and ops.fused_ok()
 
         def bulk_queue_units(k):
@@ -665,6 +695,7 @@ class DistributedCholesky(object):
             if tiles < 64:
                 return 0
             tile_us = 63.0 * GS                                   # measured: 126 us per 128 x 128 tile at depth 512
+            chain_us = chain_us_estimate()
             for r in (3, 2, 1):
                 if tiles * tile_us / (512 - 64 * r) <= chain_us:
                     return r
@@ -893,6 +924,8 @@ class DistEngine(object):
         self.ctx = self._owned_ctx.handle
         self.streams = RankStreams(device)
         self._solver = None                   # (n, HipLocalOps, DistributedCholesky) of the last problem size
+        self._replicate = {}                  # Np -> the collective replicate decision taken for that size (sticky: the same on
+                                              # every rank and unaffected by factors handed out since)
         self.acc = {}                         # profile=True: phase times (ms, this rank) summed over calls; reset by the caller
 
     # -- plumbing -------------------------------------------------------------------------------------------------
@@ -907,7 +940,12 @@ class DistEngine(object):
             Np = int(self.lib.tgp_padded_n(n))
             replicate = None
             if G > 1:
-                replicate = agree_replicate(self.comm, lambda env: local_replicate_vote(self.lib, Np, G, self.device, env))
+                # decided once per engine and size: a kept factor that is still alive (GPInterpolation._factor) lowers the free
+                # memory the next vote would see, and a decision that flips under the caller turns return_cov from working into
+                # NotImplementedError after all the collective work is done
+                if Np not in self._replicate:
+                    self._replicate[Np] = agree_replicate(self.comm, lambda env: local_replicate_vote(self.lib, Np, G, self.device, env))
+                replicate = self._replicate[Np]
             ops = HipLocalOps(self.ctx, spec, n, G, g, self.device, replicate=replicate, streams=self.streams)
             timer = (lambda: torch.cuda.Event(enable_timing=True)) if self.profile else None
             chol = DistributedCholesky(ops, self.comm, timer=timer)
@@ -963,8 +1001,14 @@ class DistEngine(object):
             h = C.c_void_p()
             self._lib.check(self.ctx, self.lib.tgp_factor_borrow(self.ctx, o._p(o.Afull), o._p(o.W), n, C.byref(h)),
                             "tgp_factor_borrow")
-            factor = _ops.Factor(self.ctx, h, n, keepalive=(o.A, o.Afull, o.W, self._owned_ctx))
-            self._solver = None                              # the buffers now belong to the handle
+            if o.keep_copies:
+                # G > 1: the handle takes the replica and the inverted diagonal blocks; the rank's share, the gather buffers
+                # and the solver stay cached, and the next factorisation gets a fresh replica (HipLocalOps.ensure_replica)
+                factor = _ops.Factor(self.ctx, h, n, keepalive=(o.Afull, o.W, self._owned_ctx))
+                o.detach_replica()
+            else:
+                factor = _ops.Factor(self.ctx, h, n, keepalive=(o.A, o.Afull, o.W, self._owned_ctx))
+                self._solver = None                          # world of one: the share IS the factor and now belongs to the handle
         return (a if want_alpha else None), logdet, float(np.dot(y, a)), factor
 
     def gp_predict(self, spec, X, alpha, Xs):

@@ -20,6 +20,7 @@ import numpy as np
 from scipy import optimize
 
 from . import _lib, ops
+from ._lib import TgpError
 from .kernels import kernel_to_spec, spec_jacobian
 
 _FD_STEP = 1e-8                  # scipy.optimize.minimize(method="L-BFGS-B") default `eps` (absolute forward step)
@@ -35,6 +36,20 @@ def _contexts(count):
             _lib.load_library().tgp_set_lookahead(ctx, 0)     # side by side: one stream each (hardware queues are few)
             _ctx_pool.append(ctx)
         return _ctx_pool[:count]
+
+
+def _rejects_theta(ex):
+    """What a library error inside ONE likelihood evaluation means for the fit.  The reference catches everything
+    (``except BaseException``, log_likelihood.py:38) so that any failure is a rejected theta and L-BFGS-B carries on.  Here a
+    run-time device error (rc -2: out of device memory, a failed HIP call) is treated the same way, with a RuntimeWarning so
+    that it cannot pass unnoticed; an argument error (rc -1) is a bug in the caller and always propagates.  TGP_ML_STRICT=1:
+    every TgpError propagates (departures)."""
+    if os.environ.get("TGP_ML_STRICT") == "1" or getattr(ex, "rc", -1) != -2:
+        return False
+    import warnings
+    warnings.warn("likelihood evaluation failed on the device and counts as -inf (set TGP_ML_STRICT=1 to raise): %s" % ex,
+                  RuntimeWarning, stacklevel=3)
+    return True
 
 
 class log_likelihood(object):
@@ -71,8 +86,11 @@ class log_likelihood(object):
                 _, log_det, chi2, _ = ops.gp_solve(spec, self.X, self.y, self.y_err, want_alpha=False, ctx=ctx)
             ll = -0.5 * chi2 - (0.5 * self.ndata) * np.log(2.0 * np.pi) - 0.5 * log_det
         except (np.linalg.LinAlgError, FloatingPointError, ValueError):
-            # the mathematical failures the reference turns into -inf (log_likelihood.py:38-39).  A TgpError -- bad argument,
-            # HIP error, out of device memory -- is NOT one of them: it propagates instead of posing as a bad theta
+            # the mathematical failures the reference turns into -inf (log_likelihood.py:38-39)
+            ll = -np.inf
+        except TgpError as ex:
+            if not _rejects_theta(ex):
+                raise
             ll = -np.inf
         if not np.isfinite(ll):
             ll = -np.inf
@@ -96,7 +114,11 @@ class log_likelihood(object):
                     factor.free()
             ll = -0.5 * chi2 - (0.5 * self.ndata) * np.log(2.0 * np.pi) - 0.5 * log_det
         except (np.linalg.LinAlgError, FloatingPointError, ValueError):
-            return -np.inf, np.zeros(ntheta)              # TgpError (device / argument errors) propagates, see log_likelihood
+            return -np.inf, np.zeros(ntheta)
+        except TgpError as ex:
+            if not _rejects_theta(ex):
+                raise
+            return -np.inf, np.zeros(ntheta)
         if not np.isfinite(ll):
             return -np.inf, np.zeros(ntheta)
         return ll, jac.dot(g4)
