@@ -286,6 +286,12 @@ int tgp_dd_update_group_queued(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_lo
 int tgp_dd_update_group_fused(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
                               const double *const *d_gathered, const int *cmax, int head_cols, int nres);
 int tgp_dd_wait_head(tgp_ctx *ctx, tgp_ctx *waiter);
+/* replicated finish of the factorisation: after ONE all-gather of every rank's share of the trailing matrix from panel k0 on
+ * (d_gathered: [G][stride] doubles, a rank's region exactly as it stores it), assemble the packed lower matrix of order
+ * Np - 256 k0 at d_tail (the replicated factor's tail, or a buffer of tgp_panel_elems(Np - 256 k0)); the caller factors it
+ * with tgp_d_potrf and tgp_dd_tail_scatter copies this rank's blocks of the result back into its share.               */
+int tgp_dd_tail_assemble(tgp_ctx *ctx, const double *d_gathered, int64_t stride, int64_t Np, int k0, int G, double *d_tail);
+int tgp_dd_tail_scatter(tgp_ctx *ctx, const double *d_tail, int64_t Np, int k0, int G, int g, double *d_Aloc, const int64_t *d_loff);
 /* how this context's streams hand over to each other: 1 = flags + hipStreamWaitValue32, 2 = events (chosen by a first-use
  * trial per device, or TGP_SYNC_EVENTS=1 / 0) */
 int tgp_handoff_mode(tgp_ctx *ctx);

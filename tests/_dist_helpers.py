@@ -5,7 +5,7 @@ import threading
 import numpy as np
 import torch
 
-from treegp_amd.dist import BLK, BCAST_ELEMS, block_of, gathered_index, panel_blocks, panel_cmax
+from treegp_amd.dist import BLK, BCAST_ELEMS, block_of, gathered_index, owner, panel_blocks, panel_cmax
 
 
 class ThreadComm(object):
@@ -229,6 +229,39 @@ class NumpyLocalOps(object):
     def info(self):
         i, self._info = self._info, 0
         return i
+
+    # -- replicated finish: the layout of a rank's share from panel k0 on (panels in order, own blocks >= p in order) ----
+    def _tail_blocks(self, k0, r):
+        return [(p, b) for p in range(k0, self.nB) for b in range(p, self.nB) if owner(b, self.G) == r]
+
+    def tail_elems(self, k0, r):
+        return len(self._tail_blocks(k0, r)) * BLK * BLK
+
+    def tail_send_view(self, k0, stride):
+        out = torch.zeros(stride, dtype=torch.float64)
+        for i, (p, b) in enumerate(self._tail_blocks(k0, self.g)):
+            out[i * BLK * BLK:(i + 1) * BLK * BLK] = torch.from_numpy(self.rows[b][:, p * BLK:(p + 1) * BLK].ravel())
+        return out
+
+    def tail_finish(self, k0, gathered, stride):
+        m = self.Np - BLK * k0
+        T = np.zeros((m, m))
+        P = gathered.numpy()
+        for r in range(self.G):
+            for i, (p, b) in enumerate(self._tail_blocks(k0, r)):
+                o = r * stride + i * BLK * BLK
+                T[(b - k0) * BLK:(b - k0 + 1) * BLK, (p - k0) * BLK:(p - k0 + 1) * BLK] = P[o:o + BLK * BLK].reshape(BLK, BLK)
+        T = np.tril(T) + np.tril(T, -1).T
+        try:
+            L = np.linalg.cholesky(T)
+        except np.linalg.LinAlgError:
+            return BLK * k0 + 1
+        for b in self.blocks:
+            if b >= k0:
+                self.rows[b][:, k0 * BLK:] = L[(b - k0) * BLK:(b - k0 + 1) * BLK, :]
+        if self.Lfull is not None:
+            self.Lfull[k0 * BLK:, k0 * BLK:] = L
+        return 0
 
     def fwd_diag(self, k, yk):
         L = np.tril(self.rows[k][:, k * BLK:(k + 1) * BLK])

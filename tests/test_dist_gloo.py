@@ -18,9 +18,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, out_dir, group=None, gather=None):
+def _worker(rank, world, port, n, out_dir, group=None, gather=None, finish=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if finish is not None:
+        os.environ["TGP_DIST_FINISH"] = str(finish)
     if group is not None:
         os.environ["TGP_DIST_GROUP"] = str(group)
     if gather is not None:
@@ -93,6 +95,15 @@ def test_distributed_cholesky_gloo_groups_of_four(tmp_path, world, n, group):
     """the schedule the headline size runs (groups of four panels, look-ahead, replicated factor) with 4 and 8 REAL
     processes: more ranks than panels per group, ranks that own no block of a group, a short last group"""
     mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path), group), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
+
+
+@pytest.mark.parametrize("world,n,group,finish", [(2, 1100, None, 0), (3, 1300, None, 3), (4, 1900, 4, 5), (3, 1500, 2, 64)])
+def test_distributed_cholesky_gloo_replicated_finish(tmp_path, world, n, group, finish):
+    """TGP_DIST_FINISH: off (every panel through the distributed chain), a tail that is not a multiple of the group size, a
+    tail longer than a group of four, and a tail that covers the whole matrix (every rank factors all of it); the default
+    (a quarter of the blocks) is what the other tests in this file run."""
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path), group, None, finish), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
 
 

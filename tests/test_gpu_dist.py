@@ -57,6 +57,21 @@ def test_virtual_ranks_queued_bulk(G, n, group, units, monkeypatch):
     _run_virtual_ranks(G, n)
 
 
+@pytest.mark.parametrize("G,n,group,finish,replicate", [(4, 6000, 2, 7, None), (8, 9000, 4, 12, None), (3, 5000, 3, 0, None),
+                                                        (2, 4000, 4, 64, None), (1, 5000, 4, 8, None), (4, 7000, 4, 9, "0"),
+                                                        (1, 4000, 2, 6, "0"), (1, 4000, 2, 6, "1")])
+def test_virtual_ranks_replicated_finish(G, n, group, finish, replicate, monkeypatch):
+    """TGP_DIST_FINISH: the last `finish` blocks leave the distributed chain -- one all-gather of the trailing matrix, every rank
+    factors it with the single-GPU schedule (tgp_dd_tail_assemble + tgp_d_potrf + tgp_dd_tail_scatter): tails that are not
+    multiples of the group size, none at all, the whole matrix, a world of one, and the route without the replicated factor
+    (the tail is factored in a buffer and only scattered back into the shares)."""
+    monkeypatch.setenv("TGP_DIST_GROUP", str(group))
+    monkeypatch.setenv("TGP_DIST_FINISH", str(finish))
+    if replicate is not None:
+        monkeypatch.setenv("TGP_DIST_REPLICATE", replicate)
+    _run_virtual_ranks(G, n)
+
+
 @pytest.mark.parametrize("G,n,group,units", [(2, 5000, 4, "0"), (8, 6000, 4, "0"), (3, 4000, 2, "2")])
 def test_virtual_ranks_split_update_with_events(G, n, group, units, monkeypatch):
     """The two-launch form of a group's update (head columns, event, rest) that the driver falls back to where stream
@@ -375,7 +390,7 @@ def test_bench_line_schema_single_gpu():
         assert key in c1, key
     assert "N=8192" in c1["config"] and 0 < c1["cholesky_frac_mfma_peak"] < 1 and 0 < c1["trsv_frac_hbm"] < 1
     for key in ("kbuild_elements_per_sec", "kbuild_frac_of_vk_ceiling", "two_pcf_fit_ms", "kk_log_pairs_per_sec",
-                "kk_log_over_lds_atomic_ceiling", "bootstrap_444_resamples_21x21_ms", "solve_plus_predict_32768_ms"):
+                "bootstrap_444_resamples_21x21_ms", "solve_plus_predict_32768_ms"):
         assert key in c2, key
     assert "N=32768" in c2["config"] and c2["two_pcf_fit_ms"] > 0
     assert any(k.startswith("extrapolated_n") for k in cb)

@@ -89,6 +89,8 @@ SIGNATURES = {
     "tgp_dd_update_group_fused": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int]),
     "tgp_dd_wait_head": (C.c_int, [_vp, _vp]),
     "tgp_handoff_mode": (C.c_int, [_vp]),
+    "tgp_dd_tail_assemble": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp]),
+    "tgp_dd_tail_scatter": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "tgp_dd_queue_reset": (C.c_int, [_vp]),
     "tgp_dd_set_exclusive": (C.c_int, [_vp, C.c_int]),
     "tgp_dd_keep_panel": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp, C.c_int]),

@@ -253,6 +253,8 @@ struct DistSegs {
 //  * whole super-tiles dealt in turn leave the XCDs up to one super-tile = one full round of an XCD's 64 slots apart:
 //    only the first 8 floor(total / 8) super-tiles are dealt whole, every one of the remaining (< 8) is cut into its 8
 //    tile rows, one per XCD (`whole`);
+//  * the launch ends when its slowest workgroup does, on average half a tile time (125 us at depth 1024) after the slots
+//    start to idle: the last round's tiles (`half_from`) are run as two 64 x 128 half tiles each, which halves that;
 //  * the tile columns of the NEXT group of panels (`head_cols`, which the panel chain waits for) and the rest used to
 //    be two launches, each with its own ramp and tail: in the fused form the first `nhead` workgroup indices are the
 //    dense grid of the head columns, the super-tile map of the rest follows, and the workgroup that completes the
@@ -263,6 +265,7 @@ struct DistMap {
     int qfb;                  // local index (= round) of the first block >= kpanel + NSEG this rank owns (host: dist_first_round)
     unsigned ginv;            // floor(2^32 / G) + 1: x / G == (x * ginv) >> 32 for 0 <= x < 65536 (block indices are < 1024); 0 for G == 1
     int whole;                // 64 floor(total / 8): slots per XCD class that belong to whole super-tiles
+    int half_from;            // tile slots of a class from this one on are run as two 64-row half tiles each (the last round)
     int nhead, head_cols;     // fused form: workgroup indices below nhead (a multiple of 8) are the dense grid of the head columns
     unsigned *done, *flag;    // head tiles finished so far (monotonic over launches) / where to publish
     unsigned target, seq;     // value of *done that completes this launch's head / what to publish then
@@ -283,7 +286,7 @@ __device__ __forceinline__ int first_round32(int s, int r, int G, unsigned ginv)
 template <int NSEG>
 __device__ __forceinline__ void syrk_distn_tile(int64_t b, double *Aloc, const int64_t *__restrict__ loff, int kpanel, int G, int g,
                                                 const DistSegs<NSEG> &S, int col_lo, int ncol, int nrows, const DistMap &M) {
-    int lt, ct;
+    int lt, ct, half = -1;
     bool valid = true;
     const bool head = M.ngroups == 0 || b < M.nhead;
     if (head) {
@@ -293,7 +296,12 @@ __device__ __forceinline__ void syrk_distn_tile(int64_t b, double *Aloc, const i
         valid = lt < nrows;
     } else {
         const int bb = (int)(b - M.nhead);
-        const int x = bb & 7, n = bb >> 3;
+        const int x = bb & 7;
+        int n = bb >> 3;
+        if (n >= M.half_from) {               // two consecutive slots share a tile: rows 0..63 and 64..127
+            half = (n - M.half_from) & 1;
+            n = M.half_from + ((n - M.half_from) >> 1);
+        }
         int st, within;
         if (n < M.whole) {
             st = (n >> 6) * 8 + x;
@@ -332,7 +340,13 @@ __device__ __forceinline__ void syrk_distn_tile(int64_t b, double *Aloc, const i
             sp.b[s] = S.P[s] + (((int64_t)rj * S.cmax[s] + js) * TGP_PW + hj) * TGP_PW;
         }
         double *c = Aloc + loff[bj] + ((int64_t)(qi - first_round32(bj, g, G, M.ginv)) * TGP_PW + hi) * TGP_PW + hj;
-        gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, c);
+        if (half < 0) {
+            gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, c);
+        } else {
+#pragma unroll
+            for (int s = 0; s < NSEG; ++s) sp.a[s] += (int64_t)half * 64 * TGP_PW;
+            gemm_tile_dtv_segs<4, TGP_PW, NSEG, 1>(sp, c + (int64_t)half * 64 * TGP_PW);
+        }
         if (head && M.ngroups != 0) __builtin_amdgcn_s_setprio(0);
     }
     if (M.ngroups != 0 && b < M.nhead) {
@@ -787,6 +801,7 @@ int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64
     hipStream_t st = ctx->stream;
     DistMap M;
     M.nhead = M.head_cols = M.whole = 0;
+    M.half_from = 1 << 30;
     M.done = M.flag = nullptr;
     M.target = M.seq = 0;
     if (head_cols > 0) {
@@ -833,7 +848,11 @@ int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64
         }
         M.start[M.ngroups] = total;
         M.whole = 64 * (total / 8);
-        grid = (unsigned)(M.nhead + 8 * (M.whole + 8 * (total % 8)));
+        const int slots = M.whole + 8 * (total % 8);          // tile slots per XCD class
+        static const int half_tiles = [] { const char *e = getenv("TGP_DIST_HALF_TILES"); return e ? atoi(e) : 32; }();
+        const int nhalf = slots < half_tiles ? slots : half_tiles;      // 32 per class = 256 tiles -> 512 half tiles = one round
+        M.half_from = slots - nhalf;
+        grid = (unsigned)(M.nhead + 8 * (slots + nhalf));
         if (grid == 0) return 0;
         if (head_cols > 0) {
             // every head workgroup counts itself in; the counter runs on from launch to launch (modulo 2^32: all of the

@@ -168,6 +168,65 @@ int tgp_dd_keep_panel(tgp_ctx *ctx, double *d_Afull, int64_t Np, int kpanel, int
     return 0;
 }
 
+// ---- replicated finish -----------------------------------------------------------------------------------------------
+// The last `m` rows of the factorisation (m / 256 <= a few dozen blocks) are chain-bound on every rank: per panel a diagonal
+// block, a broadcast, local solves and an all-gather, for a bulk update of a handful of tiles.  Instead the ranks exchange
+// their shares of the (fully updated) trailing matrix in ONE all-gather, every rank assembles the packed matrix of order m
+// and factors it with the single-GPU schedule (launch_potrf), redundantly: same volume over the links, one collective
+// instead of 2 m / 256, and 6 ms of arithmetic at m = 8192 where the distributed chain needs ~10.
+// `gathered`: [G][stride] doubles, rank r's region = its share from panel k0 on exactly as stored (panels in order, own blocks
+// >= p in order).  `dst`: where panel k0 of the packed matrix starts (the trailing part of a packed matrix from panel k0 on is
+// itself a packed matrix of order m: the replicated factor's tail, or a buffer of tgp_panel_elems(m)).
+}  // extern "C"
+namespace {
+__device__ __forceinline__ int64_t tail_region_off(int p, int k0, int64_t nB, int r, int G) {      // of panel p inside rank r's region
+    int64_t blocks = 0;
+    for (int q = k0; q < p; ++q) blocks += dist_panel_blocks(q, nB, r, G);
+    return blocks * TGP_PW * TGP_PW;
+}
+// blockIdx: x = b - k0, y = p - k0, z = 2048-double slice of the block.  TO_SHARE: the opposite direction, own blocks only.
+template <bool TO_SHARE>
+__global__ __launch_bounds__(256) void tail_blocks_kernel(double *gathered_or_share, int64_t stride, const int64_t *__restrict__ loff,
+                                                          int k0, int64_t nB, int G, int g, double *tail) {
+    const int b = k0 + blockIdx.x, p = k0 + blockIdx.y;
+    if (p > b) return;
+    const int r = dist_owner(b, G);
+    const int64_t idx = b / G - dist_first_round(p, r, G);
+    const int64_t m = (nB - k0) * TGP_PW;
+    double2 *packed = reinterpret_cast<double2 *>(tail + panel_off(p - k0, m) + (int64_t)(b - p) * TGP_PW * TGP_PW) + blockIdx.z * 1024;
+    if constexpr (TO_SHARE) {
+        if (r != g) return;
+        double2 *mine = reinterpret_cast<double2 *>(gathered_or_share + loff[p] + idx * TGP_PW * TGP_PW) + blockIdx.z * 1024;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mine[threadIdx.x + 256 * u] = packed[threadIdx.x + 256 * u];
+    } else {
+        const double2 *src = reinterpret_cast<const double2 *>(gathered_or_share + (int64_t)r * stride + tail_region_off(p, k0, nB, r, G) +
+                                                               idx * TGP_PW * TGP_PW) + blockIdx.z * 1024;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) packed[threadIdx.x + 256 * u] = src[threadIdx.x + 256 * u];
+    }
+}
+}  // namespace
+extern "C" {
+
+int tgp_dd_tail_assemble(tgp_ctx *ctx, const double *d_gathered, int64_t stride, int64_t Np, int k0, int G, double *d_tail) {
+    const int64_t nB = Np / TGP_PW;
+    TGP_ARG(d_gathered && d_tail && G >= 1 && k0 >= 0 && k0 < nB && stride > 0);
+    const unsigned nt = (unsigned)(nB - k0);
+    tail_blocks_kernel<false><<<dim3(nt, nt, 32), 256, 0, ctx->stream>>>(const_cast<double *>(d_gathered), stride, nullptr, k0, nB, G, 0, d_tail);
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+// the factored tail back into this rank's share (its sweeps and its log-determinant read the share)
+int tgp_dd_tail_scatter(tgp_ctx *ctx, const double *d_tail, int64_t Np, int k0, int G, int g, double *d_Aloc, const int64_t *d_loff) {
+    const int64_t nB = Np / TGP_PW;
+    TGP_ARG(d_tail && d_Aloc && d_loff && G >= 1 && g >= 0 && g < G && k0 >= 0 && k0 < nB);
+    const unsigned nt = (unsigned)(nB - k0);
+    tail_blocks_kernel<true><<<dim3(nt, nt, 32), 256, 0, ctx->stream>>>(d_Aloc, 0, d_loff, k0, nB, G, g, const_cast<double *>(d_tail));
+    TGP_HIP(hipGetLastError());
+    return 0;
+}
+
 // forward sweep, block kb (owner): y_k (256) <- L_kk^-1 y_k
 int tgp_dd_fwd_diag(tgp_ctx *ctx, const double *d_Aloc, const int64_t *h_loff, int kb, const double *d_W, double *d_yk) {
     const double *W0 = d_W + (int64_t)(2 * kb) * TGP_TB * TGP_TB;

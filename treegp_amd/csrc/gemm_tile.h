@@ -414,13 +414,12 @@ struct SegPtrs {
 #ifndef TGP_KB32
 #define TGP_KB32 0
 #endif
-#if TGP_KB32
 // A/B build (-DTGP_KB32=1, round 4): B staged through LDS in 32-deep chunks -- one workgroup barrier per 32 k instead of per
 // 16 -- with everything else as below: A still comes 16 k at a time straight into registers, and the staging registers do not
 // grow because a chunk's B is fetched and stored in two halves (one per 16-k sub-step; the half stored after sub-step 0 lands
 // in the buffer nobody reads until the next barrier).  LDS 2 x 128 x 34 x 8 B = 69.6 KB per workgroup, two per CU still fit.
 template <int NW, int KDEPTH, int NSEG>
-__device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, double *c_ptr) {
+__device__ __forceinline__ void gemm_tile_dtv_segs_kb32(const SegPtrs<NSEG> &sp, double *c_ptr) {
     static_assert(NSEG >= 1, "compile-time segment list");
     constexpr int LD = TGP_PW;
     constexpr int LSB = 34;
@@ -533,9 +532,10 @@ __device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, doub
 #pragma unroll
             for (int r = 0; r < 4; ++r) buf_st1_stream(-acc[m][n][r], rc, vc, ((m * 16 + 4 * r) * LD + n * 16) * 8);
 }
-#else
-template <int NW, int KDEPTH, int NSEG>
-__device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, double *c_ptr) {
+
+// MT = 16-row m-tiles per wave: 2 -> 128 x 128 per workgroup, 1 -> 64 x 128 (half the time per tile: the last round of a short launch)
+template <int NW, int KDEPTH, int NSEG, int MT = 2>
+__device__ __forceinline__ void gemm_tile_dtv_segs_kb16(const SegPtrs<NSEG> &sp, double *c_ptr) {
     static_assert(NSEG >= 1, "compile-time segment list");
     constexpr int LD = TGP_PW;
     constexpr int LSB = 18;
@@ -551,21 +551,21 @@ __device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, doub
     __amdgpu_buffer_rsrc_t ra[NSEG], rb[NSEG];
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
-        ra[s] = tile_rsrc(sp.a[s], 32 * NW * LD * 8);
+        ra[s] = tile_rsrc(sp.a[s], 16 * MT * NW * LD * 8);
         rb[s] = tile_rsrc(sp.b[s], 128 * LD * 8);
     }
-    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(c_ptr, 32 * NW * LD * 8);
-    const int va = ((32 * w + l15) * LD + 2 * l4) * 8;
+    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(c_ptr, 16 * MT * NW * LD * 8);
+    const int va = ((16 * MT * w + l15) * LD + 2 * l4) * 8;
     const int srow = tid >> 3, kp = (tid & 7) * 2;
     const int vb = (srow * LD + kp) * 8;
-    const int vc = ((32 * w + l4) * LD + l15) * 8;
+    const int vc = ((16 * MT * w + l4) * LD + l15) * 8;
     const int fb = l15 * LSB + 2 * l4;
 
-    double2 areg[2][2][2];                                      // [set][m][h]
+    double2 areg[2][MT][2];                                     // [set][m][h]
     double2 rbst[BPT];
-    auto load_a = [&](double2 (&dst)[2][2], __amdgpu_buffer_rsrc_t src, int k0) {
+    auto load_a = [&](double2 (&dst)[MT][2], __amdgpu_buffer_rsrc_t src, int k0) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int h = 0; h < 2; ++h) dst[m][h] = buf_ld2(src, va, (m * 16 * LD + k0 + 8 * h) * 8);
     };
@@ -580,9 +580,9 @@ __device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, doub
     load_a(areg[0], ra[0], 0);
     load_b(rb[0], 0);
 
-    d4 acc[2][8];
+    d4 acc[MT][8];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 8; ++n)
 #pragma unroll
@@ -590,7 +590,7 @@ __device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, doub
     store_b(0);
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 8; ++n) acc[m][n] = -acc[m][n];
 
@@ -598,7 +598,7 @@ __device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, doub
     static_assert(cps % 2 == 0, "chunks are processed in register-set pairs");
     // chunk cc of a segment; `nsrc_*` = where the chunk after it comes from (same segment, or chunk 0 of the next)
     auto step = [&](const int cc, const bool last_seg, __amdgpu_buffer_rsrc_t sa, __amdgpu_buffer_rsrc_t sb,
-                    __amdgpu_buffer_rsrc_t na, __amdgpu_buffer_rsrc_t nb, double2 (&cur)[2][2], double2 (&nxt)[2][2]) {
+                    __amdgpu_buffer_rsrc_t na, __amdgpu_buffer_rsrc_t nb, double2 (&cur)[MT][2], double2 (&nxt)[MT][2]) {
         const int buf = cc & 1;
         const bool wrap = (cc + 1 == cps);                       // wave-uniform
         const bool more = !(wrap && last_seg);
@@ -614,12 +614,12 @@ __device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, doub
 #pragma unroll
             for (int n = 0; n < 8; ++n) bf[n] = *reinterpret_cast<const double2 *>(&Bs[fb + n * 16 * LSB + 8 * h]);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < 8; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m][h].x, bf[n].x, acc[m][n], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < 8; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m][h].y, bf[n].y, acc[m][n], 0, 0, 0);
@@ -640,10 +640,15 @@ __device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, doub
     }
 
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 8; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) buf_st1_stream(-acc[m][n][r], rc, vc, ((m * 16 + 4 * r) * LD + n * 16) * 8);
 }
-#endif      // TGP_KB32
+
+template <int NW, int KDEPTH, int NSEG, int MT = 2>
+__device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, double *c_ptr) {
+    if constexpr (TGP_KB32 != 0 && MT == 2) gemm_tile_dtv_segs_kb32<NW, KDEPTH, NSEG>(sp, c_ptr);
+    else gemm_tile_dtv_segs_kb16<NW, KDEPTH, NSEG, MT>(sp, c_ptr);
+}

@@ -67,6 +67,9 @@ def panel_blocks(p, nB, g, G):
     return max(0, ql - first_round(p, g, G) + 1)
 
 
+FINISH_BLOCKS_MAX = 64          # upper limit of TGP_DIST_FINISH (blocks of 256 rows factored redundantly at the end)
+
+
 def panel_cmax(p, nB, G):
     """most blocks p <= b < nB any rank holds (the per-rank slot count of an all-gathered panel).  With the reflected deal
     a window shorter than G can hold two blocks of one rank (G-1 and G are both rank G-1's), so this is not ceil((nB-p)/G)."""
@@ -331,7 +334,8 @@ class HipLocalOps(object):
         self.loff = np.array([self.lib.tgp_dist_panel_off(p, self.Np, G, g) for p in range(self.nB + 1)], dtype=np.int64)
         self.nloc = panel_blocks(0, self.nB, g, G)
         self.cmax0 = panel_cmax(1, self.nB, G)
-        slack = (self.cmax0 + 1) * BLK * BLK                   # the padded all-gather send view may overrun
+        # the padded send views of the panel exchange and of the replicated finish may overrun the share
+        slack = (max(self.cmax0, FINISH_BLOCKS_MAX) + 1) * BLK * BLK
         self.A = torch.empty(int(self.loff[-1]) + slack, dtype=torch.float64, device=device)
         self.W = torch.empty(self.Np * 128, dtype=torch.float64, device=device)
         self.bcast = torch.empty(BCAST_ELEMS, dtype=torch.float64, device=device)
@@ -502,6 +506,40 @@ class HipLocalOps(object):
 
     def main_wait_keeps(self):
         self.main_stream.wait_stream(self.keep_stream)
+
+    # -- replicated finish ------------------------------------------------------------------------
+    def tail_elems(self, k0, r):
+        """doubles of rank r's share from panel k0 on"""
+        return int(self.lib.tgp_dist_local_elems(self.Np, self.G, r)) - int(self.lib.tgp_dist_panel_off(k0, self.Np, self.G, r))
+
+    def tail_send_view(self, k0, stride):
+        o = int(self.loff[k0])
+        return self.A[o:o + stride]
+
+    def tail_finish(self, k0, gathered, stride):
+        """main stream: assemble the packed trailing matrix of order Np - 256 k0 from everybody's shares (`gathered`, [G][stride]),
+        factor it with the single-GPU schedule, copy this rank's blocks of the result back into its share.  Returns the
+        1-based index of the first non-positive pivot (global), or 0.  Synchronises the stream."""
+        m = self.Np - BLK * k0
+        own_factor = self.G == 1 and self.Afull is not None and not self.keep_copies      # world of one: the share IS the factor
+        if own_factor:
+            tail = self._p(self.A, self.loff[k0])
+        else:
+            if self.Afull is not None:
+                tail = self._p(self.Afull, int(self.lib.tgp_panel_off(k0, self.Np)))
+            else:
+                need = int(self.lib.tgp_panel_elems(m))
+                if getattr(self, "_tail_buf", None) is None or self._tail_buf.numel() < need:
+                    self._tail_buf = self.empty(need)
+                tail = self._p(self._tail_buf)
+            self._chk(self.lib.tgp_dd_tail_assemble(self.ctx, self._p(gathered), int(stride), self.Np, k0, self.G, tail),
+                      "tgp_dd_tail_assemble")
+        rc = self.lib.tgp_d_potrf(self.ctx, tail, m, self._p(self.W, 2 * k0 * 128 * 128))
+        self._chk(rc, "tgp_d_potrf (finish)")
+        if not own_factor:
+            self._chk(self.lib.tgp_dd_tail_scatter(self.ctx, tail, self.Np, k0, self.G, self.g, self._p(self.A), self._p(self.d_loff)),
+                      "tgp_dd_tail_scatter")
+        return (BLK * k0 + int(rc)) if rc > 0 else 0
 
     def potrs_full(self, rhs):             # main stream: rhs (Np) <- L^-T L^-1 rhs with the replicated factor
         self._chk(self.lib.tgp_d_potrs(self.ctx, self._p(self.Afull), self._p(self.W), self.Np, self._p(rhs)), "tgp_d_potrs")
@@ -701,11 +739,26 @@ class DistributedCholesky(object):
                     return r
             return 0
 
+        # Replicated finish (TGP_DIST_FINISH = blocks of 256 rows, 0 = off): the last rows are chain-bound on every
+        # rank -- per panel a diagonal block, a broadcast, local solves and an all-gather for a bulk update of a handful of
+        # tiles -- so from the group boundary k_fin on the ranks exchange their shares of the trailing matrix in ONE
+        # all-gather and every rank factors it with the single-GPU schedule (HipLocalOps.tail_finish): the same volume over
+        # the links, one collective instead of two per panel, ~6 ms of arithmetic at 8192 rows where the chain needs ~10.
+        # Default: 32 blocks (8192 rows), never more than a quarter of the matrix (1.6 % of the flops done redundantly).
+        fin = min(int(os.environ.get("TGP_DIST_FINISH", min(32, nB // 4))), FINISH_BLOCKS_MAX)
+        k_fin = None
+        if fin >= GS and hasattr(ops, "tail_finish") and nB > 1:
+            k_fin = GS * (-(-max(nB - fin, 0) // GS))
+            if k_fin >= nB:
+                k_fin = None
         ops.side_wait_main()                                     # K build (main) precedes panel 0
-        with ops.on_side():
-            cur_w = side_group(0, self.gathered[:GS])
+        cur_w = None
+        if k_fin != 0:
+            with ops.on_side():
+                cur_w = side_group(0, self.gathered[:GS])
         k, flip = 0, 0
-        while k + GS < nB:
+        while k + GS < nB and (k_fin is None or k < k_fin):
+            last_regular = k_fin is not None and k + GS >= k_fin         # the group whose update completes the finish's matrix
             cur = self.gathered[flip * GS:(flip + 1) * GS]
             nxt = self.gathered[(1 - flip) * GS:(2 - flip) * GS]
             if self.timer is not None:
@@ -720,6 +773,12 @@ class DistributedCholesky(object):
             cm = [c for _, c in cur_w]
             cur = [w.tensor for w, _ in cur_w]                   # where each gathered panel of the group is (see _Done / _Work)
             units = bulk_queue_units(k)
+            if last_regular:
+                timed(lambda: ops.update_group(k, cur, cm, 0, -1))           # nothing runs beside it: one plain launch
+                self.update_flops += GS * self._local_update_flops(k + GS - 1)
+                self.update_launches += 1
+                k += GS
+                break
             if fused:
                 # Ua (the next group's columns) and Ub (the bulk) in ONE launch, Ua's tiles first; the launch itself
                 # releases the side stream when they are done: one ramp and one tail per group instead of two
@@ -745,9 +804,22 @@ class DistributedCholesky(object):
             ops.chain_exclusive(False)
         if keep:
             ops.main_wait_keeps()                                # the replicated factor is complete before the solves
+        tail_info = 0
+        if k_fin is not None:
+            assert k == k_fin
+            stride = max(ops.tail_elems(k_fin, r) for r in range(G))
+            if getattr(self, "_tail_gather", None) is None or self._tail_gather.numel() < G * stride:
+                self._tail_gather = ops.empty(G * stride)
+            if not hasattr(comm, "bytes_in"):
+                self.bytes_received += 8 * (G - 1) * stride
+            h = comm.all_gather_start(self._tail_gather[:G * stride], ops.tail_send_view(k_fin, stride))
+            h.wait()
+            tail_info = ops.tail_finish(k_fin, h.tensor, stride)
         # any rank's failure is everybody's failure; report the smallest failing index
         big = 1e18
         mine = ops.info()                                        # synchronises the stream
+        if tail_info > 0 and not mine > 0:
+            mine = tail_info
         self.update_ms = sum(a.elapsed_time(b) for a, b in events) if events else 0.0
         self.chain_ms = sum(a.elapsed_time(b) for a, b in chain_events) if chain_events else 0.0
         self.wait_ms = sum(a.elapsed_time(b) for a, b in wait_events) if wait_events else 0.0
