@@ -232,6 +232,18 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
 // k assignment: lane (r, kq) handles k = 8h + 2kq + {0, 1} in MFMA steps 2h, 2h+1, so both the direct A
 // loads and the B fragment reads are 16-byte accesses (B rows padded to 18 doubles: conflict-free b128).
 // NSEG = 0: run-time number of operand pairs, pair s at a_ptr + s * seg_stride_a / b_ptr + s * seg_stride_b.
+#ifndef TGP_KB32
+#define TGP_KB32 0
+#endif
+// B staging buffers of the DTV tiles: ONE array per kernel whatever mix of tile variants it instantiates (a __shared__
+// array inside a template is one per instantiation: two of them would push a trailing-update workgroup from 37 to 74 KB and
+// potrf128's 96 KB would no longer fit on a compute unit beside it)
+constexpr int DTV_LSB = TGP_KB32 ? 34 : 18;
+__device__ __forceinline__ double *dtv_lds_storage() {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 128 * DTV_LSB];
+    return lds;
+}
+
 template <int NW, int KDEPTH, int NSEG, int MT = 2>
 __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double *b_ptr, double *c_ptr,
                                               const double *a1_ptr, const double *b1_ptr, int nseg_rt = 1,
@@ -240,7 +252,7 @@ __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double 
     constexpr int LSB = 18;
     constexpr int BPT = 16 / NW;                    // B staging pieces (16 B) per thread and chunk
     constexpr int BROWS = 8 * NW;                   // rows covered by one staging pass
-    __shared__ __attribute__((aligned(16))) double ldsB[2][128 * LSB];
+    double (*ldsB)[128 * LSB] = reinterpret_cast<double (*)[128 * LSB]>(dtv_lds_storage());
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -411,9 +423,6 @@ struct SegPtrs {
     const double *b[NSEG];
 };
 
-#ifndef TGP_KB32
-#define TGP_KB32 0
-#endif
 // A/B build (-DTGP_KB32=1, round 4): B staged through LDS in 32-deep chunks -- one workgroup barrier per 32 k instead of per
 // 16 -- with everything else as below: A still comes 16 k at a time straight into registers, and the staging registers do not
 // grow because a chunk's B is fetched and stored in two halves (one per 16-k sub-step; the half stored after sub-step 0 lands
@@ -425,7 +434,7 @@ __device__ __forceinline__ void gemm_tile_dtv_segs_kb32(const SegPtrs<NSEG> &sp,
     constexpr int LSB = 34;
     constexpr int BPT = 16 / NW;
     constexpr int BROWS = 8 * NW;
-    __shared__ __attribute__((aligned(16))) double ldsB[2][128 * LSB];
+    double (*ldsB)[128 * LSB] = reinterpret_cast<double (*)[128 * LSB]>(dtv_lds_storage());
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -541,7 +550,7 @@ __device__ __forceinline__ void gemm_tile_dtv_segs_kb16(const SegPtrs<NSEG> &sp,
     constexpr int LSB = 18;
     constexpr int BPT = 16 / NW;
     constexpr int BROWS = 8 * NW;
-    __shared__ __attribute__((aligned(16))) double ldsB[2][128 * LSB];
+    double (*ldsB)[128 * LSB] = reinterpret_cast<double (*)[128 * LSB]>(dtv_lds_storage());
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
