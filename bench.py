@@ -506,7 +506,12 @@ def main():
                 # HBM-side bytes per launch of this kernel for this exact workload, from separate rocprofv3 --pmc
                 # passes on the shipped sources (FETCH_SIZE x2 for the 16-B/lane operand loads, WRITE_SIZE exact;
                 # tools/pmc_bench.sh); algorithmic bytes per launch = C read + written once (16 B per updated element)
-                traffic, src = measured_traffic(n, "syrk_hbm_bytes_per_launch")
+                # (per STEP in the PMC file -- the profiled run splits the launches the timed run fuses -- over this run's launches)
+                traffic, src = measured_traffic(n, "syrk_hbm_bytes_per_step")
+                if traffic is not None:
+                    traffic = traffic / (launches / K)
+                else:
+                    traffic, src = measured_traffic(n, "syrk_hbm_bytes_per_launch")
                 alg_bytes = 16.0 * (acc["syrk_flops"] / (2.0 * 1024.0)) / launches if n >= 22528 else None
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": src,

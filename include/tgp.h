@@ -244,6 +244,7 @@ int tgp_d_unpack_lower(tgp_ctx *ctx, const double *d_A, int64_t Np, int64_t n, d
  * reference lines as tgp_gp_solve (treegp/gp_interp.py:180-182).                              */
 int tgp_set_stream(tgp_ctx *ctx, void *hip_stream);      /* launch on the caller's stream (NULL = default stream) */
 int tgp_reset_stream(tgp_ctx *ctx);                      /* back to the context's own stream */
+int tgp_set_side_stream(tgp_ctx *ctx, void *hip_stream); /* lend the look-ahead stream of the context's own schedules */
 int64_t tgp_dist_panel_rows(int64_t p, int64_t Np, int G, int g);
 int64_t tgp_dist_panel_off(int64_t p, int64_t Np, int G, int g);
 int64_t tgp_dist_local_elems(int64_t Np, int G, int g);

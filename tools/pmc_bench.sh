@@ -12,10 +12,11 @@ rm -rf $R/gpurun_out/pmcb_* $R/gpurun_out/pmccal_*   # the derivation sums every
 mkdir -p $R/gpurun_out
 hipcc --offload-arch=gfx950 -O2 -w -o /tmp/fetch_calib $R/tools/probes/fetch_calib.hip
 cd /tmp && export TMPDIR=/tmp
-# Under counter collection rocprofv3 serialises the dispatches of the intercepted queues, and a stream blocked in
-# hipStreamWaitValue32 (the factorisation's cross-stream hand-offs since round 3) then never gets going: these passes once hung
-# for 7 minutes until the box's watchdog ended them.  The library now falls back to event hand-offs by itself when it sees
-# ROCPROF_COUNTER_COLLECTION (set by rocprofv3 --pmc); the kernels and their traffic are the same.  Belt and braces:
+# Under counter collection rocprofv3 serialises the dispatches of the intercepted queues, and a stream parked in
+# hipStreamWaitValue32 (the factorisation's cross-stream hand-offs) then never gets going: these passes once hung for 7 minutes
+# until the box's watchdog ended them.  The library tries the mechanism once per process (csrc/handoff.hip: consumer parked
+# first, producer second, 2 s host timeout) and hands over by events where the trial fails; TGP_SYNC_EVENTS=1 is the documented
+# profiler setting and skips the trial.  The kernels and their traffic are the same (the fused bulk launches run as two).
 export TGP_SYNC_EVENTS=1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmccal_$C -- /tmp/fetch_calib > $R/gpurun_out/pmccal_$C.log 2>&1

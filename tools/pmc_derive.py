@@ -66,7 +66,10 @@ if "FETCH_SIZE" in sy and "WRITE_SIZE" in sy:
     c_read_reported = write / f8t
     fetch = write + max(fetch_raw - c_read_reported, 0.0) * f16
     der.update(syrk_launches=L, syrk_fetch_bytes_reported=fetch_raw, syrk_fetch_bytes=fetch, syrk_write_bytes=write,
-               syrk_hbm_bytes_per_launch=(fetch + write) / L, syrk_algorithmic_C_bytes_per_launch=2.0 * write / L)
+               syrk_hbm_bytes_per_launch=(fetch + write) / L, syrk_algorithmic_C_bytes_per_launch=2.0 * write / L,
+               # the profiled run is ONE step; under counter collection the library hands over by events, so the update runs as
+               # two launches per group where the timed run fuses them: bench.py divides the step's total by ITS launch count
+               syrk_hbm_bytes_per_step=fetch + write)
     if "TCC_HIT_sum" in sy:
         der["syrk_L2_hit_rate"] = sy["TCC_HIT_sum"]["sum"] / (sy["TCC_HIT_sum"]["sum"] + sy["TCC_MISS_sum"]["sum"])
 kb = out.get("kbuild_lower_kernel", {})

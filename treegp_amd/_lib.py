@@ -76,6 +76,7 @@ SIGNATURES = {
     # multi-GPU tier
     "tgp_set_stream": (C.c_int, [_vp, _vp]),
     "tgp_reset_stream": (C.c_int, [_vp]),
+    "tgp_set_side_stream": (C.c_int, [_vp, _vp]),
     "tgp_dist_panel_rows": (_i64, [_i64, _i64, C.c_int, C.c_int]),
     "tgp_dist_panel_off": (_i64, [_i64, _i64, C.c_int, C.c_int]),
     "tgp_dist_local_elems": (_i64, [_i64, C.c_int, C.c_int]),

@@ -208,31 +208,61 @@ __global__ __launch_bounds__(256, 2) void syrk_dtv_queue_kernel(double *Abase, i
     }
 }
 
+// "The head of a fused launch is done": the first `nhead` workgroup indices of a launch are the tile columns the panel chain
+// waits for; each of them counts itself in when its tile is stored (valid or not: the count is the grid's), and the last one
+// publishes the sequence number on which the chain's stream is parked (hipStreamWaitValue32).  One launch then carries the
+// head AND the rest of the update: no second ramp and tail.
+struct HeadSignal {
+    unsigned *done = nullptr, *flag = nullptr;      // counter (monotonic over launches, modulo 2^32) / where to publish
+    unsigned target = 0, seq = 0;                   // value of *done that completes this launch's head / what to publish then
+    int nhead = 0;                                  // 0: not a fused launch
+};
+__device__ __forceinline__ void head_done(const HeadSignal &h) {
+    // every wave makes its stores visible device-wide (release fence at agent scope: vmcnt(0) + write-back of the XCD's L2)
+    // before the barrier; then one thread counts the workgroup in
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(h.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == h.target) __hip_atomic_store(h.flag, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // Trailing update with a compile-time list of NSEG factored panels (depth 256 * NSEG): P.a[s] points at the row of
 // panel s that corresponds to the first trailing row (P.b is filled in per tile).  Same tile map as above.
+//   hs.nhead == 0, strip == 0 : all tiles;  strip > 0 : only the first `strip` tile columns (dense grid)
+//   hs.nhead  > 0 (fused)     : the first `strip` tile columns as a dense grid in workgroups 0 .. nhead-1 (nhead = 8 ceil(T
+//                               strip / 8)), the triangle to the right of them behind it, one launch
 template <int NSEG>
-__global__ __launch_bounds__(256, 2) void syrk_segs_kernel(double *Abase, int64_t Np, int ob, int T, int strip, SegPtrs<NSEG> P) {
+__global__ __launch_bounds__(256, 2) void syrk_segs_kernel(double *Abase, int64_t Np, int ob, int T, int strip, SegPtrs<NSEG> P,
+                                                           HeadSignal hs) {
     int ti, tj;
-    if (strip == 0) {
-        tilemap(blockIdx.x, T, ti, tj);
-        if (ti < 0) return;
-    } else {
+    bool valid = true;
+    const bool head = strip > 0 && (hs.nhead == 0 || (int)blockIdx.x < hs.nhead);
+    if (head) {
         tj = (int)(blockIdx.x % strip);
         ti = (int)(blockIdx.x / strip);
-        if (ti < tj || ti >= T) return;
+        valid = ti >= tj && ti < T;
+    } else {
+        tilemap(blockIdx.x - hs.nhead, T - (hs.nhead ? strip : 0), ti, tj);
+        valid = ti >= 0;
+        if (hs.nhead) { ti += strip; tj += strip; }
     }
-    if (strip) TGP_CHAIN_PRIO();
-    const int64_t pj = ob + (tj >> 1);
-    const int64_t I = (int64_t)TGP_PW * ob + (int64_t)TGP_TB * ti;
-    double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
-    const int64_t oa = (int64_t)ti * TGP_TB * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
-    SegPtrs<NSEG> sp;
+    if (valid) {
+        if (head) TGP_CHAIN_PRIO();
+        const int64_t pj = ob + (tj >> 1);
+        const int64_t I = (int64_t)TGP_PW * ob + (int64_t)TGP_TB * ti;
+        double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
+        const int64_t oa = (int64_t)ti * TGP_TB * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
+        SegPtrs<NSEG> sp;
 #pragma unroll
-    for (int s = 0; s < NSEG; ++s) {
-        sp.a[s] = P.a[s] + oa;
-        sp.b[s] = P.a[s] + obb;
+        for (int s = 0; s < NSEG; ++s) {
+            sp.a[s] = P.a[s] + oa;
+            sp.b[s] = P.a[s] + obb;
+        }
+        gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, C);
     }
-    gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, C);
+    if (hs.nhead && head) head_done(hs);
 }
 
 // multi-GPU trailing update: rank g updates its own block rows, after a GROUP of NSEG consecutive panels
@@ -267,8 +297,7 @@ struct DistMap {
     int whole;                // 64 floor(total / 8): slots per XCD class that belong to whole super-tiles
     int half_from;            // tile slots of a class from this one on are run as two 64-row half tiles each (the last round)
     int nhead, head_cols;     // fused form: workgroup indices below nhead (a multiple of 8) are the dense grid of the head columns
-    unsigned *done, *flag;    // head tiles finished so far (monotonic over launches) / where to publish
-    unsigned target, seq;     // value of *done that completes this launch's head / what to publish then
+    HeadSignal hs;            // what the head's last workgroup publishes (hs.nhead is not used here)
 };
 __device__ __forceinline__ int div_g(int x, unsigned ginv) { return ginv ? (int)__umulhi((unsigned)x, ginv) : x; }     // ginv == 0: G == 1
 // the reflected owner map of tgp_internal.h (dist_owner / dist_block_of / dist_first_round) in 32 bits: position of rank r in
@@ -349,17 +378,7 @@ __device__ __forceinline__ void syrk_distn_tile(int64_t b, double *Aloc, const i
         }
         if (head && M.ngroups != 0) __builtin_amdgcn_s_setprio(0);
     }
-    if (M.ngroups != 0 && b < M.nhead) {
-        // Head tile of a fused launch (valid or not: the count is the grid's).  Every wave makes its stores visible device-wide
-        // (release fence at agent scope: vmcnt(0) + write-back of the XCD's L2) before the barrier; the last workgroup to
-        // count itself in publishes the sequence number the chain's stream waits for.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned old = __hip_atomic_fetch_add(M.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old + 1u == M.target) __hip_atomic_store(M.flag, M.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    if (M.ngroups != 0 && b < M.nhead) head_done(M.hs);       // head tile of a fused launch, valid or not
 }
 
 template <int NSEG>
@@ -460,6 +479,36 @@ void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_inf
         if (r2 <= small_rows) gemm_col_small_kernel<0, TGP_TB><<<r2 * 8, 256, 0, st>>>(R2, W1, R2);
         else gemm_col_kernel<0, TGP_TB><<<r2, 256, 0, st>>>(R2, W1, R2);
     }
+}
+
+// factor_panel with the rows below the diagonal 256-block taken off the chain between the two diagonal blocks (round 4,
+// TGP_PANEL_OVERLAP=1; chain-bound steps only).  `s` carries potrf(0,0) -> the 128 rows of tile 1 (L10 = A10 W0^T, A11 -= L10
+// L10^T: one workgroup, diag_mid_kernel) -> potrf(1,1) -> X = A W1^T; a second chain stream `s2` takes X = A W0^T and the
+// column-half update of the rows from 256 on, which nothing needs before potrf(1,1) has finished.  Three flag hand-offs per
+// panel: (a) W0 ready, (c) L10 ready, (b) rows below updated; two of them are signal kernels on `s`.
+int factor_panel_overlap(tgp_ctx *ctx, hipStream_t s, hipStream_t s2, double *Pk, int64_t mk, double *W0, int base, bool exclusive) {
+    double *W1 = W0 + TGP_TB * TGP_TB;
+    double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
+    double *Rb = Pk + (int64_t)TGP_PW * TGP_PW;                 // row 256: the rows below the diagonal block
+    const int r2 = (int)((mk - TGP_PW) / TGP_TB);
+    static const int small_rows = [] { const char *e = getenv("TGP_SMALL_ROWS"); return e ? atoi(e) : 40; }();
+    const bool slices = r2 <= small_rows;
+    run_potrf128(s, Pk, TGP_PW, W0, ctx->d_info, base, exclusive);
+    TGP_HIP(tgp_signal(ctx, s, 2, ctx->ev[6]));
+    TGP_HIP(tgp_await(ctx, s2, 2, ctx->ev[6]));
+    if (slices) gemm_col_small_kernel<0, TGP_TB><<<r2 * 8, 256, 0, s2>>>(Rb, W0, Rb);
+    else gemm_col_kernel<0, TGP_TB><<<r2, 256, 0, s2>>>(Rb, W0, Rb);
+    diag_mid_kernel<<<1, 256, 0, s>>>(R1, W0);
+    TGP_HIP(tgp_signal(ctx, s, 3, ctx->ev[7]));
+    TGP_HIP(tgp_await(ctx, s2, 3, ctx->ev[7]));
+    if (slices) gemm_col_small_kernel<1, TGP_PW><<<r2 * 8, 256, 0, s2>>>(Rb, R1, Rb + TGP_TB);
+    else gemm_col_kernel<1, TGP_PW><<<r2, 256, 0, s2>>>(Rb, R1, Rb + TGP_TB);
+    TGP_HIP(tgp_signal(ctx, s2, 4, ctx->ev2[0]));
+    run_potrf128(s, R1 + TGP_TB, TGP_PW, W1, ctx->d_info, base + TGP_TB, exclusive);
+    TGP_HIP(tgp_await(ctx, s, 4, ctx->ev2[0]));
+    if (slices) gemm_col_small_kernel<0, TGP_TB><<<r2 * 8, 256, 0, s>>>(Rb + TGP_TB, W1, Rb + TGP_TB);
+    else gemm_col_kernel<0, TGP_TB><<<r2, 256, 0, s>>>(Rb + TGP_TB, W1, Rb + TGP_TB);
+    return 0;
 }
 
 inline int small_t() {          // steps with at most this many tile rows run on the latency tile (16-row slices)
@@ -573,15 +622,29 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
         TGP_HIP(hipMemsetAsync(ctx->d_queue, 0, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned), st));
     auto run_pairs = [&](int kstart) -> int {
         hipStream_t sd = ctx->side_stream;
-        auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false) {       // F(k), U1(k), F(k+1)
-            const int64_t mk = Np - (int64_t)TGP_PW * k;
+        static const int overlap_env = [] { const char *e = getenv("TGP_PANEL_OVERLAP"); return e ? atoi(e) : 0; }();
+        auto one_panel = [&](hipStream_t s, int k, int64_t mk, bool exclusive) -> int {
+            // the overlapped form needs rows below the diagonal block, a step that keeps compute units clear, and flag hand-offs
+            if (overlap_env && exclusive && mk > 2 * TGP_PW && s == sd && tgp_handoff_by_flags(ctx)) {
+                int rc = tgp_ensure_chain2_stream(ctx);
+                if (rc) return rc;
+                return factor_panel_overlap(ctx, s, ctx->chain2_stream, panel(k), mk, Wk(k), k * TGP_PW, exclusive);
+            }
             factor_panel(s, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, exclusive, n_data);
-            if (k + 1 >= nP) return;
+            return 0;
+        };
+        auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false) -> int {       // F(k), U1(k), F(k+1)
+            const int64_t mk = Np - (int64_t)TGP_PW * k;
+            int rc = one_panel(s, k, mk, exclusive);
+            if (rc || k + 1 >= nP) return rc;
             const int T1 = (int)((mk - TGP_PW) / TGP_TB);
             launch_syrk<1>(s, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
-            factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, exclusive, n_data);
+            return one_panel(s, k + 1, mk - TGP_PW, exclusive);
         };
-        factor_pair(st, kstart);
+        {
+            int rc = factor_pair(st, kstart);
+            if (rc) return rc;
+        }
         for (int k = kstart; k + 2 < nP; k += 2) {
             const int T2 = (int)((Np - (int64_t)TGP_PW * (k + 2)) / TGP_TB);       // tiles from block k+2
             const double *P0 = panel(k) + (int64_t)2 * TGP_PW * TGP_PW;
@@ -598,7 +661,10 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             }
             TGP_HIP(tgp_signal(ctx, st, 0, ctx->ev[4]));
             TGP_HIP(tgp_await(ctx, sd, 0, ctx->ev[4]));
-            factor_pair(sd, k + 2, queued);
+            {
+                int rc = factor_pair(sd, k + 2, queued);
+                if (rc) return rc;
+            }
             TGP_HIP(tgp_signal(ctx, sd, 1, ctx->ev[5]));
             if (T3 > 0) {   // U2b: everything from block k+4 on
                 const double m = (double)T3 * TGP_TB;
@@ -645,13 +711,13 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             const unsigned gs = (unsigned)((int64_t)T * 2);
             if (j == 1) {
                 SegPtrs<1> P{{seg_rows(k0, ob)}, {nullptr}};
-                syrk_segs_kernel<1><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P);
+                syrk_segs_kernel<1><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P, HeadSignal{});
             } else if (j == 2) {
                 SegPtrs<2> P{{seg_rows(k0, ob), seg_rows(k0 + 1, ob)}, {nullptr, nullptr}};
-                syrk_segs_kernel<2><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P);
+                syrk_segs_kernel<2><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P, HeadSignal{});
             } else {
                 SegPtrs<3> P{{seg_rows(k0, ob), seg_rows(k0 + 1, ob), seg_rows(k0 + 2, ob)}, {nullptr, nullptr, nullptr}};
-                syrk_segs_kernel<3><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P);
+                syrk_segs_kernel<3><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P, HeadSignal{});
             }
         };
         auto factor_group = [&](hipStream_t s, int k0) {
@@ -671,8 +737,28 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             SegPtrs<4> P{{seg_rows(k0, ob), seg_rows(k0 + 1, ob), seg_rows(k0 + 2, ob), seg_rows(k0 + 3, ob)},
                          {nullptr, nullptr, nullptr, nullptr}};
             const unsigned gs = strip == 0 ? (unsigned)tilemap_grid(T) : (unsigned)((int64_t)T * strip);
-            syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, ob, T, strip, P);
+            syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, ob, T, strip, P, HeadSignal{});
         };
+        // U4a and U4b in ONE launch: the 8 tile columns of the next group first, the rest behind them; the launch itself
+        // releases the side stream (parked on the head flag) when the head is done.  Saves one ramp and one tail per group
+        // (the slots a separate U4a leaves idle while its last tiles finish, and again at the start of U4b).
+        auto bulk_fused = [&](int k0, int ob, int T) -> hipError_t {
+            SegPtrs<4> P{{seg_rows(k0, ob), seg_rows(k0 + 1, ob), seg_rows(k0 + 2, ob), seg_rows(k0 + 3, ob)},
+                         {nullptr, nullptr, nullptr, nullptr}};
+            HeadSignal hs;
+            hipError_t e = hipSuccess;
+            hs.seq = tgp_next_seq(ctx, TGP_FLAG_HEAD, &e);
+            if (e != hipSuccess) return e;
+            hs.flag = ctx->d_flags + 16 * TGP_FLAG_HEAD;
+            hs.done = ctx->d_flags + 16 * TGP_FLAG_HEAD_COUNT;
+            hs.nhead = T * 8;
+            ctx->head_count += (unsigned)hs.nhead;
+            hs.target = ctx->head_count;
+            syrk_segs_kernel<4><<<(unsigned)(hs.nhead + tilemap_grid(T - 8)), 256, 0, st>>>(d_A, Np, ob, T, 8, P, hs);
+            return hipGetLastError();
+        };
+        static const bool fuse_env = [] { const char *e = getenv("TGP_FUSED_BULK"); return !e || atoi(e) != 0; }();
+        const bool fuse = fuse_env && tgp_handoff_by_flags(ctx);
         // Below `tail_tiles` rows of trailing matrix the deeper grouping no longer pays (its strips and the longer
         // serial chain cost more than the per-tile overhead it saves: crossover at N ~ 24k): the tail runs in pairs.
         static const int tail_tiles = [] { const char *e = getenv("TGP_QUAD_TAIL_TILES"); return e ? atoi(e) : 128; }();
@@ -689,6 +775,19 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
                 counting = true;
                 if (rc) return rc;
                 break;
+            }
+            if (fuse && T4 > 8) {   // U4a + U4b in one launch (both parts exist)
+                const double m = (double)T4 * TGP_TB;
+                hipError_t le = hipSuccess;
+                int rc = timed([&] { le = bulk_fused(k, k + 4, T4); }, 4.0 * TGP_PW * m * (m + 1.0));
+                if (rc) return rc;
+                TGP_HIP(le);
+                TGP_HIP(hipStreamWaitValue32(sd, ctx->d_flags + 16 * TGP_FLAG_HEAD, ctx->flag_seq[TGP_FLAG_HEAD], hipStreamWaitValueGte,
+                                             0xffffffffu));
+                factor_group(sd, k + 4);
+                TGP_HIP(tgp_signal(ctx, sd, 1, ctx->ev[5]));
+                TGP_HIP(tgp_await(ctx, st, 1, ctx->ev[5]));
+                continue;
             }
             {   // U4a: the 8 tile columns of the next group
                 const double rows = (double)T4 * TGP_TB, w = (T4 < 8 ? T4 : 8) * (double)TGP_TB;
@@ -802,18 +901,16 @@ int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64
     DistMap M;
     M.nhead = M.head_cols = M.whole = 0;
     M.half_from = 1 << 30;
-    M.done = M.flag = nullptr;
-    M.target = M.seq = 0;
     if (head_cols > 0) {
         // the waiter is released whatever this rank's share is (even none at all): the signal is part of the call's contract
         hipError_t e = hipSuccess;
-        M.seq = tgp_next_seq(ctx, TGP_FLAG_HEAD, &e);
+        M.hs.seq = tgp_next_seq(ctx, TGP_FLAG_HEAD, &e);
         TGP_HIP(e);
-        M.flag = ctx->d_flags + 16 * TGP_FLAG_HEAD;
-        M.done = ctx->d_flags + 16 * TGP_FLAG_HEAD_COUNT;
+        M.hs.flag = ctx->d_flags + 16 * TGP_FLAG_HEAD;
+        M.hs.done = ctx->d_flags + 16 * TGP_FLAG_HEAD_COUNT;
     }
     if (nloc <= 0 || ncol <= 0) {
-        if (head_cols > 0) TGP_HIP(tgp_signal_value(ctx, st, TGP_FLAG_HEAD, M.seq));
+        if (head_cols > 0) TGP_HIP(tgp_signal_value(ctx, st, TGP_FLAG_HEAD, M.hs.seq));
         return 0;
     }
     // staircase of valid tiles: local tile row lt reaches global tile column gti(lt); super-tiles per group of 8 rows
@@ -858,7 +955,7 @@ int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64
             // every head workgroup counts itself in; the counter runs on from launch to launch (modulo 2^32: all of the
             // previous launch's increments are in before this one starts, same stream)
             ctx->head_count += (unsigned)M.nhead;
-            M.target = ctx->head_count;
+            M.hs.target = ctx->head_count;
         }
     }
     // queued form: one set of counters per launch, zeroed by tgp_dd_queue_reset at the start of a factorisation; beyond
@@ -893,9 +990,9 @@ int tgp_debug_syrk_loop(tgp_ctx *ctx, double *d_A, int64_t Np, int reps, double 
     if (getenv("TGP_DEBUG_SEGS")) {           // the depth-1024 kernel on the same two panels twice
         SegPtrs<4> P{{P0, P1, P0, P1}, {nullptr, nullptr, nullptr, nullptr}};
         const unsigned gs = (unsigned)tilemap_grid(T2);
-        syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, 2, T2, 0, P);
+        syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, 2, T2, 0, P, HeadSignal{});
         TGP_HIP(hipEventRecord(ctx->ev[0], st));
-        for (int r = 0; r < reps; ++r) syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, 2, T2, 0, P);
+        for (int r = 0; r < reps; ++r) syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, 2, T2, 0, P, HeadSignal{});
         TGP_HIP(hipEventRecord(ctx->ev[1], st));
         TGP_HIP(hipStreamSynchronize(st));
         float ms2 = 0.f;

@@ -15,6 +15,23 @@ int tgp_set_stream(tgp_ctx *ctx, void *stream) {
     return 0;
 }
 
+// The look-ahead stream of this context's single-GPU schedules (launch_potrf) is the caller's too: the multi-GPU driver lends
+// its own idle chain stream to the replicated finish instead of letting the context create one more -- the runtime maps
+// streams onto 8 hardware queues, and one stream too many made the driver's bulk and chain streams share a queue
+// (rank slice at 8 ranks: chain 75 -> 93 ms).  The context never destroys a stream it was lent; NULL takes it back.
+int tgp_set_side_stream(tgp_ctx *ctx, void *stream) {
+    if (!ctx) return -1;
+    if (!stream) {                                  // take a lent stream back (the context creates its own on next need)
+        if (ctx->ext_side_stream) ctx->side_stream = nullptr;
+        ctx->ext_side_stream = false;
+        return 0;
+    }
+    if (ctx->side_stream && !ctx->ext_side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    ctx->side_stream = (hipStream_t)stream;
+    ctx->ext_side_stream = true;
+    return 0;
+}
+
 int tgp_reset_stream(tgp_ctx *ctx) {
     if (!ctx) return -1;
     ctx->ext_stream = false;

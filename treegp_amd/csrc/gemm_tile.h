@@ -232,13 +232,10 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
 // k assignment: lane (r, kq) handles k = 8h + 2kq + {0, 1} in MFMA steps 2h, 2h+1, so both the direct A
 // loads and the B fragment reads are 16-byte accesses (B rows padded to 18 doubles: conflict-free b128).
 // NSEG = 0: run-time number of operand pairs, pair s at a_ptr + s * seg_stride_a / b_ptr + s * seg_stride_b.
-#ifndef TGP_KB32
-#define TGP_KB32 0
-#endif
 // B staging buffers of the DTV tiles: ONE array per kernel whatever mix of tile variants it instantiates (a __shared__
 // array inside a template is one per instantiation: two of them would push a trailing-update workgroup from 37 to 74 KB and
 // potrf128's 96 KB would no longer fit on a compute unit beside it)
-constexpr int DTV_LSB = TGP_KB32 ? 34 : 18;
+constexpr int DTV_LSB = 18;
 __device__ __forceinline__ double *dtv_lds_storage() {
     __shared__ __attribute__((aligned(16))) double lds[2 * 128 * DTV_LSB];
     return lds;
@@ -423,128 +420,11 @@ struct SegPtrs {
     const double *b[NSEG];
 };
 
-// A/B build (-DTGP_KB32=1, round 4): B staged through LDS in 32-deep chunks -- one workgroup barrier per 32 k instead of per
-// 16 -- with everything else as below: A still comes 16 k at a time straight into registers, and the staging registers do not
-// grow because a chunk's B is fetched and stored in two halves (one per 16-k sub-step; the half stored after sub-step 0 lands
-// in the buffer nobody reads until the next barrier).  LDS 2 x 128 x 34 x 8 B = 69.6 KB per workgroup, two per CU still fit.
-template <int NW, int KDEPTH, int NSEG>
-__device__ __forceinline__ void gemm_tile_dtv_segs_kb32(const SegPtrs<NSEG> &sp, double *c_ptr) {
-    static_assert(NSEG >= 1, "compile-time segment list");
-    constexpr int LD = TGP_PW;
-    constexpr int LSB = 34;
-    constexpr int BPT = 16 / NW;
-    constexpr int BROWS = 8 * NW;
-    double (*ldsB)[128 * LSB] = reinterpret_cast<double (*)[128 * LSB]>(dtv_lds_storage());
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, l4 = lane >> 4;
-
-    __amdgpu_buffer_rsrc_t ra[NSEG], rb[NSEG];
-#pragma unroll
-    for (int s = 0; s < NSEG; ++s) {
-        ra[s] = tile_rsrc(sp.a[s], 32 * NW * LD * 8);
-        rb[s] = tile_rsrc(sp.b[s], 128 * LD * 8);
-    }
-    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(c_ptr, 32 * NW * LD * 8);
-    const int va = ((32 * w + l15) * LD + 2 * l4) * 8;
-    const int srow = tid >> 3, kp = (tid & 7) * 2;
-    const int vb = (srow * LD + kp) * 8;
-    const int vc = ((32 * w + l4) * LD + l15) * 8;
-    const int fb = l15 * LSB + 2 * l4;
-
-    double2 areg[2][2][2];                                      // [set][m][h]
-    double2 rbst[BPT];
-    auto load_a = [&](double2 (&dst)[2][2], __amdgpu_buffer_rsrc_t src, int k0) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) dst[m][h] = buf_ld2(src, va, (m * 16 * LD + k0 + 8 * h) * 8);
-    };
-    auto load_b = [&](__amdgpu_buffer_rsrc_t src, int k0) {
-#pragma unroll
-        for (int s = 0; s < BPT; ++s) rbst[s] = buf_ld2(src, vb, (s * BROWS * LD + k0) * 8);
-    };
-    auto store_b = [&](int buf, int sub) {
-#pragma unroll
-        for (int s = 0; s < BPT; ++s) *reinterpret_cast<double2 *>(&ldsB[buf][(srow + BROWS * s) * LSB + kp + 16 * sub]) = rbst[s];
-    };
-    load_a(areg[0], ra[0], 0);
-    load_b(rb[0], 0);
-
-    d4 acc[2][8];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 8; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[m][n][r] = buf_ld1_stream(rc, vc, ((m * 16 + 4 * r) * LD + n * 16) * 8);
-    store_b(0, 0);
-    load_b(rb[0], 16);
-    store_b(0, 1);
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 8; ++n) acc[m][n] = -acc[m][n];
-
-    constexpr int cps = KDEPTH / 32;                             // 32-deep chunks per segment
-    // sub-step `sub` (16 k) of chunk cc of a segment; na / nb: where the chunk after this segment's last comes from
-    auto step = [&](const int cc, const int sub, const bool last_seg, __amdgpu_buffer_rsrc_t sa, __amdgpu_buffer_rsrc_t sb,
-                    __amdgpu_buffer_rsrc_t na, __amdgpu_buffer_rsrc_t nb, double2 (&cur)[2][2], double2 (&nxt)[2][2]) {
-        const int buf = cc & 1;
-        const bool wrap = (cc + 1 == cps);                       // wave-uniform: the next chunk is the next segment's first
-        const bool more_b = !(wrap && last_seg);                 // a next chunk exists: fetch its half `sub`
-        const bool more_a = sub == 0 || more_b;                  // a next sub-step exists
-        if (more_a) {
-            const bool awrap = sub == 1 && wrap;
-            load_a(nxt, awrap ? na : sa, awrap ? 0 : cc * 32 + 16 * (sub + 1));
-        }
-        if (more_b) load_b(wrap ? nb : sb, (wrap ? 0 : (cc + 1) * 32) + 16 * sub);
-        const double *Bs = ldsB[buf] + 16 * sub;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            double2 bf[8];
-#pragma unroll
-            for (int n = 0; n < 8; ++n) bf[n] = *reinterpret_cast<const double2 *>(&Bs[fb + n * 16 * LSB + 8 * h]);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 8; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m][h].x, bf[n].x, acc[m][n], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 8; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m][h].y, bf[n].y, acc[m][n], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more_b) store_b(buf ^ 1, sub);
-        if (sub == 1) __syncthreads();
-    };
-#pragma unroll
-    for (int s = 0; s < NSEG; ++s) {
-        const bool last = (s == NSEG - 1);
-        const __amdgpu_buffer_rsrc_t na = ra[last ? s : s + 1], nb = rb[last ? s : s + 1];
-#pragma unroll 1
-        for (int cc = 0; cc < cps; ++cc) {
-            step(cc, 0, last, ra[s], rb[s], na, nb, areg[0], areg[1]);
-            step(cc, 1, last, ra[s], rb[s], na, nb, areg[1], areg[0]);
-        }
-    }
-
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 8; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) buf_st1_stream(-acc[m][n][r], rc, vc, ((m * 16 + 4 * r) * LD + n * 16) * 8);
-}
-
+// (Round 4 A/B: B staged in 32-deep chunks -- half the workgroup barriers, staging split in two halves so that no register is
+// added, LDS 69.6 KB -- ran 66.4 against 69.3 TF in situ at N = 65 536, profiles/r04_kb32_ab.txt: not adopted, git history.)
 // MT = 16-row m-tiles per wave: 2 -> 128 x 128 per workgroup, 1 -> 64 x 128 (half the time per tile: the last round of a short launch)
 template <int NW, int KDEPTH, int NSEG, int MT = 2>
-__device__ __forceinline__ void gemm_tile_dtv_segs_kb16(const SegPtrs<NSEG> &sp, double *c_ptr) {
+__device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, double *c_ptr) {
     static_assert(NSEG >= 1, "compile-time segment list");
     constexpr int LD = TGP_PW;
     constexpr int LSB = 18;
@@ -654,10 +534,4 @@ __device__ __forceinline__ void gemm_tile_dtv_segs_kb16(const SegPtrs<NSEG> &sp,
         for (int n = 0; n < 8; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) buf_st1_stream(-acc[m][n][r], rc, vc, ((m * 16 + 4 * r) * LD + n * 16) * 8);
-}
-
-template <int NW, int KDEPTH, int NSEG, int MT = 2>
-__device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, double *c_ptr) {
-    if constexpr (TGP_KB32 != 0 && MT == 2) gemm_tile_dtv_segs_kb32<NW, KDEPTH, NSEG>(sp, c_ptr);
-    else gemm_tile_dtv_segs_kb16<NW, KDEPTH, NSEG, MT>(sp, c_ptr);
 }

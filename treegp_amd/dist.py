@@ -534,7 +534,13 @@ class HipLocalOps(object):
                 tail = self._p(self._tail_buf)
             self._chk(self.lib.tgp_dd_tail_assemble(self.ctx, self._p(gathered), int(stride), self.Np, k0, self.G, tail),
                       "tgp_dd_tail_assemble")
-        rc = self.lib.tgp_d_potrf(self.ctx, tail, m, self._p(self.W, 2 * k0 * 128 * 128))
+        # the single-GPU schedule's look-ahead runs on the (now idle) chain stream, lent for this call: one more stream of the
+        # context's own made the bulk and chain streams share a hardware queue
+        self.lib.tgp_set_side_stream(self.ctx, C.c_void_p(self.side_stream.cuda_stream))
+        try:
+            rc = self.lib.tgp_d_potrf(self.ctx, tail, m, self._p(self.W, 2 * k0 * 128 * 128))
+        finally:
+            self.lib.tgp_set_side_stream(self.ctx, None)
         self._chk(rc, "tgp_d_potrf (finish)")
         if not own_factor:
             self._chk(self.lib.tgp_dd_tail_scatter(self.ctx, tail, self.Np, k0, self.G, self.g, self._p(self.A), self._p(self.d_loff)),
