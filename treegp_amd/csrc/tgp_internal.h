@@ -125,43 +125,55 @@ __host__ __device__ inline int64_t dist_panel_blocks(int64_t p, int64_t nB, int 
 }
 
 // trailing-update tile enumeration (XCD-aware): see chol.hip.  Blocks b, b+8, ... share an XCD; an XCD works through
-// whole super-tiles of sup x sup tiles (shared operand rows stay in its L2).  Super-tiles are dealt to the XCDs in turn, so
-// the XCDs' shares differ by up to a super-tile or two: with 8 x 8 that is 0.3 % of a launch at T = 496 but 7 % at T = 100
-// and 25 % at T = 40 (measured by enumeration); below TGP_SUP4_BELOW tile rows the super-tiles are 4 x 4 (1 % at T = 100,
-// 3 % at T = 40), below 32 tile rows 2 x 2.
+// whole super-tiles of sup x sup tiles (shared operand rows stay in its L2).  Super-tiles are dealt to the XCDs in turn; whole
+// ones only while all eight get one: the last ns % 8 of them would leave the XCDs a full super-tile apart (0.3 % of a launch at
+// T = 496 but 7 % at T = 56 and 25 % at T = 40 with 8 x 8; the queued bulk update of the chain-bound sizes has one tile queue
+// per XCD class and ends with its slowest), so each of those is cut into eight equal slices, one per XCD (round 4).  Below
+// TGP_SUP4_BELOW tile rows the super-tiles are 4 x 4, below 32 tile rows 2 x 2.
 #ifndef TGP_SUP4_BELOW
 #define TGP_SUP4_BELOW 192
 #endif
 __host__ __device__ inline int tilemap_sup_shift(int64_t T) { return T < 32 ? 1 : (T < TGP_SUP4_BELOW ? 2 : 3); }
-__host__ __device__ inline int64_t tilemap_grid(int64_t T) {
+// slots per XCD class: per (= sup^2) for every whole round of eight super-tiles, q = max(per / 8, 1) for each of the rest
+__host__ __device__ inline int64_t tilemap_slots(int64_t T) {
+    if (T <= 0) return 0;
     const int sh = tilemap_sup_shift(T);
-    int64_t S = (T + (1 << sh) - 1) >> sh;   // super-tiles per side
-    int64_t ns = S * (S + 1) / 2;            // lower-triangular super-tiles
-    return ((ns + 7) / 8) * 8 * ((int64_t)1 << (2 * sh));
+    const int64_t S = (T + (1 << sh) - 1) >> sh;   // super-tiles per side
+    const int64_t ns = S * (S + 1) / 2;            // lower-triangular super-tiles
+    const int64_t per = (int64_t)1 << (2 * sh), q = per >= 8 ? per / 8 : 1;
+    return (ns / 8) * per + (ns % 8) * q;
 }
+__host__ __device__ inline int64_t tilemap_grid(int64_t T) { return 8 * tilemap_slots(T); }
 // block id -> (ti, tj), or ti = -1 when the slot is empty
 __host__ __device__ inline void tilemap(int64_t b, int64_t T, int &ti, int &tj) {
+    ti = -1; tj = -1;
+    if (T <= 0 || b < 0) return;
     const int sh = tilemap_sup_shift(T);
-    int64_t S = (T + (1 << sh) - 1) >> sh;
-    int64_t ns = S * (S + 1) / 2;
-    int xcd = (int)(b & 7);                  // blocks b, b+8, ... share an XCD (speed only)
-    int64_t slot = b >> 3;
-    int64_t st = (slot >> (2 * sh)) * 8 + xcd;      // super-tile handled by this XCD group
-    int within = (int)(slot & ((1 << (2 * sh)) - 1));
-    if (st >= ns) { ti = -1; tj = -1; return; }
+    const int64_t S = (T + (1 << sh) - 1) >> sh;
+    const int64_t ns = S * (S + 1) / 2;
+    const int per = 1 << (2 * sh), q = per >= 8 ? per / 8 : 1;
+    const int xcd = (int)(b & 7);                  // blocks b, b+8, ... share an XCD (speed only)
+    const int64_t slot = b >> 3;
+    const int64_t whole = (ns / 8) * per;
+    int64_t st;
+    int within;
+    if (slot < whole) {
+        st = (slot >> (2 * sh)) * 8 + xcd;         // super-tile handled by this XCD group
+        within = (int)(slot & (per - 1));
+    } else {                                       // the last ns % 8 super-tiles: slice xcd of each
+        const int64_t nn = slot - whole;
+        st = (ns / 8) * 8 + nn / q;
+        within = xcd * q + (int)(nn % q);
+        if (st >= ns || within >= per) return;
+    }
     // st -> (Si, Sj), Sj <= Si, row-major triangular enumeration
     int64_t Si = (int64_t)((sqrt(8.0 * (double)st + 1.0) - 1.0) * 0.5);
     while (Si * (Si + 1) / 2 > st) --Si;
     while ((Si + 1) * (Si + 2) / 2 <= st) ++Si;
-    int64_t Sj = st - Si * (Si + 1) / 2;
-#ifdef TGP_SUP_COLMAJOR          // A/B build (round 3): walk a super-tile column by column instead of row by row
-    int i = (int)((Si << sh) + (within & ((1 << sh) - 1)));
-    int j = (int)((Sj << sh) + (within >> sh));
-#else
-    int i = (int)((Si << sh) + (within >> sh));
-    int j = (int)((Sj << sh) + (within & ((1 << sh) - 1)));
-#endif
-    if (j > i || i >= T) { ti = -1; tj = -1; return; }
+    const int64_t Sj = st - Si * (Si + 1) / 2;
+    const int i = (int)((Si << sh) + (within >> sh));
+    const int j = (int)((Sj << sh) + (within & ((1 << sh) - 1)));
+    if (j > i || i >= T) return;
     ti = i; tj = j;
 }
 

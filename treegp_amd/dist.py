@@ -707,14 +707,16 @@ class DistributedCholesky(object):
 
         # Chain-bound steps (this rank's share of the bulk shorter than the panel chain that runs beside it): the bulk as a
         # persistent grid that keeps compute units clear for the chain, whose diagonal blocks then take a unit of their own.
-        # TGP_DIST_QUEUE: -1 decide per step (default), 0 never, 1..3 always with that many units per shader engine.
+        # TGP_DIST_QUEUE: 0 never (default: without communication on the chain the clear units cost more than they bring,
+        # profiles/r04_rank_slice.txt), -1 decide per step from the measured chain, 1..3 always with that many units per
+        # shader engine -- a knob for the first run on a real node.
         # Rank-local decisions: no collective depends on them.
         # How long a group's chain takes is MEASURED, not assumed: the side stream's span of every group is timed (it
         # contains the broadcasts and panel exchanges of a real node), and a step is chain-bound when the last chain that
         # has finished took longer than this step's bulk would with every slot.  TGP_DIST_CHAIN_US=<us per panel> replaces
         # the measurement by a constant (tests; rounds 2-3 used 600, tuned on one GPU without communication, which
         # cost 3.7 % at 8 ranks because it kept units clear for a chain that did not need them).
-        queue_mode = int(os.environ.get("TGP_DIST_QUEUE", "-1"))
+        queue_mode = int(os.environ.get("TGP_DIST_QUEUE", "0"))
         chain_env = os.environ.get("TGP_DIST_CHAIN_US")
         can_queue = queue_mode != 0 and hasattr(ops, "queue_reset")
         if can_queue:
@@ -750,8 +752,10 @@ class DistributedCholesky(object):
         # tiles -- so from the group boundary k_fin on the ranks exchange their shares of the trailing matrix in ONE
         # all-gather and every rank factors it with the single-GPU schedule (HipLocalOps.tail_finish): the same volume over
         # the links, one collective instead of two per panel, ~6 ms of arithmetic at 8192 rows where the chain needs ~10.
-        # Default: 32 blocks (8192 rows), never more than a quarter of the matrix (1.6 % of the flops done redundantly).
-        fin = min(int(os.environ.get("TGP_DIST_FINISH", min(32, nB // 4))), FINISH_BLOCKS_MAX)
+        # Default: 16 blocks (4096 rows), never more than a quarter of the matrix.  Without communication the finish is neutral
+        # at 16 blocks and costs 2 ms at 32 (profiles/r04_rank_slice.txt); every panel it takes off the chain is a broadcast
+        # and an all-gather less on a real node, so the first hardware run should sweep it.
+        fin = min(int(os.environ.get("TGP_DIST_FINISH", min(16, nB // 4))), FINISH_BLOCKS_MAX)
         k_fin = None
         if fin >= GS and hasattr(ops, "tail_finish") and nB > 1:
             k_fin = GS * (-(-max(nB - fin, 0) // GS))
