@@ -148,9 +148,7 @@ def test_golden_config1_and_aniso2d(tg, golden):
                                  {"TGP_PREDICT_EXP": "0"}, {"TGP_PREDICT_EXP": "32"}, {"TGP_PREDICT_EXP": "64"},
                                  {"TGP_NO_AUGMENT_ALPHA": "1"}, {"TGP_SYNC_EVENTS": "1"}, {"TGP_SYNC_EVENTS": "0"},
                                  {"TGP_SYNC_EVENTS": "1", "TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "8"},
-                                 {"TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "8", "TGP_FUSED_BULK": "0"},
                                  {"TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "8", "TGP_FLAG_SEQ_START": "4294967274"},
-                                 {"TGP_PANEL_OVERLAP": "1"}, {"TGP_PANEL_OVERLAP": "1", "TGP_SMALL_ROWS": "0"},
                                  {"TGP_FLAG_SEQ_START": "4294967274"}])      # the hand-off sequence numbers wrap during this solve
 def test_alternative_kernel_paths_agree(env):
     """The A/B switches kept in the library (schedules, tile thresholds, hand-off mechanism) must stay correct:

@@ -55,15 +55,6 @@ int tgp_ensure_side_stream(tgp_ctx *ctx) {
     return 0;
 }
 
-int tgp_ensure_chain2_stream(tgp_ctx *ctx) {
-    if (ctx->chain2_stream) return 0;
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    TGP_HIP(hipStreamCreateWithPriority(&ctx->chain2_stream, hipStreamNonBlocking, hi));
-    for (auto &e : ctx->ev2) TGP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    return 0;
-}
-
 int tgp_ensure_scratch2(tgp_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->scratch2_bytes) return 0;
     if (ctx->scratch2) TGP_HIP(hipFree(ctx->scratch2));
@@ -188,9 +179,6 @@ void tgp_destroy(tgp_ctx *ctx) {
     for (auto &ev : ctx->prof_events) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->side_stream && !ctx->ext_side_stream) (void)hipStreamDestroy(ctx->side_stream);
-    if (ctx->chain2_stream) (void)hipStreamDestroy(ctx->chain2_stream);
-    for (auto &ev : ctx->ev2)
-        if (ev) (void)hipEventDestroy(ev);
     delete static_cast<tgp_ctx_full *>(ctx);
 }
 

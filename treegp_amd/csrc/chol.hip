@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void syrk_dtv_queue_kernel(double *Abase, i
     }
 }
 
-// "The head of a fused launch is done": the first `nhead` workgroup indices of a launch are the tile columns the panel chain
+// "The head of a fused launch is done" (multi-GPU bulk update): the first `nhead` workgroup indices of a launch are the tile columns the panel chain
 // waits for; each of them counts itself in when its tile is stored (valid or not: the count is the grid's), and the last one
 // publishes the sequence number on which the chain's stream is parked (hipStreamWaitValue32).  One launch then carries the
 // head AND the rest of the update: no second ramp and tail.
@@ -230,39 +230,32 @@ __device__ __forceinline__ void head_done(const HeadSignal &h) {
 
 // Trailing update with a compile-time list of NSEG factored panels (depth 256 * NSEG): P.a[s] points at the row of
 // panel s that corresponds to the first trailing row (P.b is filled in per tile).  Same tile map as above.
-//   hs.nhead == 0, strip == 0 : all tiles;  strip > 0 : only the first `strip` tile columns (dense grid)
-//   hs.nhead  > 0 (fused)     : the first `strip` tile columns as a dense grid in workgroups 0 .. nhead-1 (nhead = 8 ceil(T
-//                               strip / 8)), the triangle to the right of them behind it, one launch
+// (The fused head + rest form of the multi-GPU kernel below was measured here too in round 4 and is NOT used: 1368.7 vs
+// 1361.0 ms at N = 65 536, profiles/r04_fused_bulk_ab.txt -- the rest tiles start in lockstep when the head ends, so the
+// panel chain's first kernel waits a whole tile time for a slot, where after a separate head launch it finds the chip empty.)
 template <int NSEG>
-__global__ __launch_bounds__(256, 2) void syrk_segs_kernel(double *Abase, int64_t Np, int ob, int T, int strip, SegPtrs<NSEG> P,
-                                                           HeadSignal hs) {
+__global__ __launch_bounds__(256, 2) void syrk_segs_kernel(double *Abase, int64_t Np, int ob, int T, int strip, SegPtrs<NSEG> P) {
     int ti, tj;
-    bool valid = true;
-    const bool head = strip > 0 && (hs.nhead == 0 || (int)blockIdx.x < hs.nhead);
-    if (head) {
+    if (strip == 0) {
+        tilemap(blockIdx.x, T, ti, tj);
+        if (ti < 0) return;
+    } else {
         tj = (int)(blockIdx.x % strip);
         ti = (int)(blockIdx.x / strip);
-        valid = ti >= tj && ti < T;
-    } else {
-        tilemap(blockIdx.x - hs.nhead, T - (hs.nhead ? strip : 0), ti, tj);
-        valid = ti >= 0;
-        if (hs.nhead) { ti += strip; tj += strip; }
+        if (ti < tj || ti >= T) return;
     }
-    if (valid) {
-        if (head) TGP_CHAIN_PRIO();
-        const int64_t pj = ob + (tj >> 1);
-        const int64_t I = (int64_t)TGP_PW * ob + (int64_t)TGP_TB * ti;
-        double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
-        const int64_t oa = (int64_t)ti * TGP_TB * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
-        SegPtrs<NSEG> sp;
+    if (strip) TGP_CHAIN_PRIO();
+    const int64_t pj = ob + (tj >> 1);
+    const int64_t I = (int64_t)TGP_PW * ob + (int64_t)TGP_TB * ti;
+    double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
+    const int64_t oa = (int64_t)ti * TGP_TB * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
+    SegPtrs<NSEG> sp;
 #pragma unroll
-        for (int s = 0; s < NSEG; ++s) {
-            sp.a[s] = P.a[s] + oa;
-            sp.b[s] = P.a[s] + obb;
-        }
-        gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, C);
+    for (int s = 0; s < NSEG; ++s) {
+        sp.a[s] = P.a[s] + oa;
+        sp.b[s] = P.a[s] + obb;
     }
-    if (hs.nhead && head) head_done(hs);
+    gemm_tile_dtv_segs<4, TGP_PW, NSEG>(sp, C);
 }
 
 // multi-GPU trailing update: rank g updates its own block rows, after a GROUP of NSEG consecutive panels
@@ -481,36 +474,6 @@ void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_inf
     }
 }
 
-// factor_panel with the rows below the diagonal 256-block taken off the chain between the two diagonal blocks (round 4,
-// TGP_PANEL_OVERLAP=1; chain-bound steps only).  `s` carries potrf(0,0) -> the 128 rows of tile 1 (L10 = A10 W0^T, A11 -= L10
-// L10^T: one workgroup, diag_mid_kernel) -> potrf(1,1) -> X = A W1^T; a second chain stream `s2` takes X = A W0^T and the
-// column-half update of the rows from 256 on, which nothing needs before potrf(1,1) has finished.  Three flag hand-offs per
-// panel: (a) W0 ready, (c) L10 ready, (b) rows below updated; two of them are signal kernels on `s`.
-int factor_panel_overlap(tgp_ctx *ctx, hipStream_t s, hipStream_t s2, double *Pk, int64_t mk, double *W0, int base, bool exclusive) {
-    double *W1 = W0 + TGP_TB * TGP_TB;
-    double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
-    double *Rb = Pk + (int64_t)TGP_PW * TGP_PW;                 // row 256: the rows below the diagonal block
-    const int r2 = (int)((mk - TGP_PW) / TGP_TB);
-    static const int small_rows = [] { const char *e = getenv("TGP_SMALL_ROWS"); return e ? atoi(e) : 40; }();
-    const bool slices = r2 <= small_rows;
-    run_potrf128(s, Pk, TGP_PW, W0, ctx->d_info, base, exclusive);
-    TGP_HIP(tgp_signal(ctx, s, 2, ctx->ev[6]));
-    TGP_HIP(tgp_await(ctx, s2, 2, ctx->ev[6]));
-    if (slices) gemm_col_small_kernel<0, TGP_TB><<<r2 * 8, 256, 0, s2>>>(Rb, W0, Rb);
-    else gemm_col_kernel<0, TGP_TB><<<r2, 256, 0, s2>>>(Rb, W0, Rb);
-    diag_mid_kernel<<<1, 256, 0, s>>>(R1, W0);
-    TGP_HIP(tgp_signal(ctx, s, 3, ctx->ev[7]));
-    TGP_HIP(tgp_await(ctx, s2, 3, ctx->ev[7]));
-    if (slices) gemm_col_small_kernel<1, TGP_PW><<<r2 * 8, 256, 0, s2>>>(Rb, R1, Rb + TGP_TB);
-    else gemm_col_kernel<1, TGP_PW><<<r2, 256, 0, s2>>>(Rb, R1, Rb + TGP_TB);
-    TGP_HIP(tgp_signal(ctx, s2, 4, ctx->ev2[0]));
-    run_potrf128(s, R1 + TGP_TB, TGP_PW, W1, ctx->d_info, base + TGP_TB, exclusive);
-    TGP_HIP(tgp_await(ctx, s, 4, ctx->ev2[0]));
-    if (slices) gemm_col_small_kernel<0, TGP_TB><<<r2 * 8, 256, 0, s>>>(Rb + TGP_TB, W1, Rb + TGP_TB);
-    else gemm_col_kernel<0, TGP_TB><<<r2, 256, 0, s>>>(Rb + TGP_TB, W1, Rb + TGP_TB);
-    return 0;
-}
-
 inline int small_t() {          // steps with at most this many tile rows run on the latency tile (16-row slices)
     static const int v = [] { const char *e = getenv("TGP_SMALL_T"); return e ? atoi(e) : 8; }();
     return v;
@@ -622,29 +585,15 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
         TGP_HIP(hipMemsetAsync(ctx->d_queue, 0, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned), st));
     auto run_pairs = [&](int kstart) -> int {
         hipStream_t sd = ctx->side_stream;
-        static const int overlap_env = [] { const char *e = getenv("TGP_PANEL_OVERLAP"); return e ? atoi(e) : 0; }();
-        auto one_panel = [&](hipStream_t s, int k, int64_t mk, bool exclusive) -> int {
-            // the overlapped form needs rows below the diagonal block, a step that keeps compute units clear, and flag hand-offs
-            if (overlap_env && exclusive && mk > 2 * TGP_PW && s == sd && tgp_handoff_by_flags(ctx)) {
-                int rc = tgp_ensure_chain2_stream(ctx);
-                if (rc) return rc;
-                return factor_panel_overlap(ctx, s, ctx->chain2_stream, panel(k), mk, Wk(k), k * TGP_PW, exclusive);
-            }
-            factor_panel(s, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, exclusive, n_data);
-            return 0;
-        };
-        auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false) -> int {       // F(k), U1(k), F(k+1)
+        auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false) {       // F(k), U1(k), F(k+1)
             const int64_t mk = Np - (int64_t)TGP_PW * k;
-            int rc = one_panel(s, k, mk, exclusive);
-            if (rc || k + 1 >= nP) return rc;
+            factor_panel(s, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, exclusive, n_data);
+            if (k + 1 >= nP) return;
             const int T1 = (int)((mk - TGP_PW) / TGP_TB);
             launch_syrk<1>(s, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
-            return one_panel(s, k + 1, mk - TGP_PW, exclusive);
+            factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, exclusive, n_data);
         };
-        {
-            int rc = factor_pair(st, kstart);
-            if (rc) return rc;
-        }
+        factor_pair(st, kstart);
         for (int k = kstart; k + 2 < nP; k += 2) {
             const int T2 = (int)((Np - (int64_t)TGP_PW * (k + 2)) / TGP_TB);       // tiles from block k+2
             const double *P0 = panel(k) + (int64_t)2 * TGP_PW * TGP_PW;
@@ -661,10 +610,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             }
             TGP_HIP(tgp_signal(ctx, st, 0, ctx->ev[4]));
             TGP_HIP(tgp_await(ctx, sd, 0, ctx->ev[4]));
-            {
-                int rc = factor_pair(sd, k + 2, queued);
-                if (rc) return rc;
-            }
+            factor_pair(sd, k + 2, queued);
             TGP_HIP(tgp_signal(ctx, sd, 1, ctx->ev[5]));
             if (T3 > 0) {   // U2b: everything from block k+4 on
                 const double m = (double)T3 * TGP_TB;
@@ -711,13 +657,13 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             const unsigned gs = (unsigned)((int64_t)T * 2);
             if (j == 1) {
                 SegPtrs<1> P{{seg_rows(k0, ob)}, {nullptr}};
-                syrk_segs_kernel<1><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P, HeadSignal{});
+                syrk_segs_kernel<1><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P);
             } else if (j == 2) {
                 SegPtrs<2> P{{seg_rows(k0, ob), seg_rows(k0 + 1, ob)}, {nullptr, nullptr}};
-                syrk_segs_kernel<2><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P, HeadSignal{});
+                syrk_segs_kernel<2><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P);
             } else {
                 SegPtrs<3> P{{seg_rows(k0, ob), seg_rows(k0 + 1, ob), seg_rows(k0 + 2, ob)}, {nullptr, nullptr, nullptr}};
-                syrk_segs_kernel<3><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P, HeadSignal{});
+                syrk_segs_kernel<3><<<gs, 256, 0, s>>>(d_A, Np, ob, T, 2, P);
             }
         };
         auto factor_group = [&](hipStream_t s, int k0) {
@@ -737,28 +683,8 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             SegPtrs<4> P{{seg_rows(k0, ob), seg_rows(k0 + 1, ob), seg_rows(k0 + 2, ob), seg_rows(k0 + 3, ob)},
                          {nullptr, nullptr, nullptr, nullptr}};
             const unsigned gs = strip == 0 ? (unsigned)tilemap_grid(T) : (unsigned)((int64_t)T * strip);
-            syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, ob, T, strip, P, HeadSignal{});
+            syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, ob, T, strip, P);
         };
-        // U4a and U4b in ONE launch: the 8 tile columns of the next group first, the rest behind them; the launch itself
-        // releases the side stream (parked on the head flag) when the head is done.  Saves one ramp and one tail per group
-        // (the slots a separate U4a leaves idle while its last tiles finish, and again at the start of U4b).
-        auto bulk_fused = [&](int k0, int ob, int T) -> hipError_t {
-            SegPtrs<4> P{{seg_rows(k0, ob), seg_rows(k0 + 1, ob), seg_rows(k0 + 2, ob), seg_rows(k0 + 3, ob)},
-                         {nullptr, nullptr, nullptr, nullptr}};
-            HeadSignal hs;
-            hipError_t e = hipSuccess;
-            hs.seq = tgp_next_seq(ctx, TGP_FLAG_HEAD, &e);
-            if (e != hipSuccess) return e;
-            hs.flag = ctx->d_flags + 16 * TGP_FLAG_HEAD;
-            hs.done = ctx->d_flags + 16 * TGP_FLAG_HEAD_COUNT;
-            hs.nhead = T * 8;
-            ctx->head_count += (unsigned)hs.nhead;
-            hs.target = ctx->head_count;
-            syrk_segs_kernel<4><<<(unsigned)(hs.nhead + tilemap_grid(T - 8)), 256, 0, st>>>(d_A, Np, ob, T, 8, P, hs);
-            return hipGetLastError();
-        };
-        static const bool fuse_env = [] { const char *e = getenv("TGP_FUSED_BULK"); return !e || atoi(e) != 0; }();
-        const bool fuse = fuse_env && tgp_handoff_by_flags(ctx);
         // Below `tail_tiles` rows of trailing matrix the deeper grouping no longer pays (its strips and the longer
         // serial chain cost more than the per-tile overhead it saves: crossover at N ~ 24k): the tail runs in pairs.
         static const int tail_tiles = [] { const char *e = getenv("TGP_QUAD_TAIL_TILES"); return e ? atoi(e) : 128; }();
@@ -775,19 +701,6 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
                 counting = true;
                 if (rc) return rc;
                 break;
-            }
-            if (fuse && T4 > 8) {   // U4a + U4b in one launch (both parts exist)
-                const double m = (double)T4 * TGP_TB;
-                hipError_t le = hipSuccess;
-                int rc = timed([&] { le = bulk_fused(k, k + 4, T4); }, 4.0 * TGP_PW * m * (m + 1.0));
-                if (rc) return rc;
-                TGP_HIP(le);
-                TGP_HIP(hipStreamWaitValue32(sd, ctx->d_flags + 16 * TGP_FLAG_HEAD, ctx->flag_seq[TGP_FLAG_HEAD], hipStreamWaitValueGte,
-                                             0xffffffffu));
-                factor_group(sd, k + 4);
-                TGP_HIP(tgp_signal(ctx, sd, 1, ctx->ev[5]));
-                TGP_HIP(tgp_await(ctx, st, 1, ctx->ev[5]));
-                continue;
             }
             {   // U4a: the 8 tile columns of the next group
                 const double rows = (double)T4 * TGP_TB, w = (T4 < 8 ? T4 : 8) * (double)TGP_TB;
@@ -990,9 +903,9 @@ int tgp_debug_syrk_loop(tgp_ctx *ctx, double *d_A, int64_t Np, int reps, double 
     if (getenv("TGP_DEBUG_SEGS")) {           // the depth-1024 kernel on the same two panels twice
         SegPtrs<4> P{{P0, P1, P0, P1}, {nullptr, nullptr, nullptr, nullptr}};
         const unsigned gs = (unsigned)tilemap_grid(T2);
-        syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, 2, T2, 0, P, HeadSignal{});
+        syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, 2, T2, 0, P);
         TGP_HIP(hipEventRecord(ctx->ev[0], st));
-        for (int r = 0; r < reps; ++r) syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, 2, T2, 0, P, HeadSignal{});
+        for (int r = 0; r < reps; ++r) syrk_segs_kernel<4><<<gs, 256, 0, st>>>(d_A, Np, 2, T2, 0, P);
         TGP_HIP(hipEventRecord(ctx->ev[1], st));
         TGP_HIP(hipStreamSynchronize(st));
         float ms2 = 0.f;

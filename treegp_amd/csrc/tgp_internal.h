@@ -27,8 +27,6 @@ struct tgp_ctx {
     hipStream_t stream = nullptr;      // the stream every kernel is launched on
     hipStream_t own_stream = nullptr;  // created by tgp_init
     hipStream_t side_stream = nullptr; // high-priority stream for the Cholesky look-ahead
-    hipStream_t chain2_stream = nullptr; // second chain stream (factor_panel_overlap: the rows below the diagonal block)
-    hipEvent_t ev2[2] = {nullptr};     // its hand-off events (event mode), created with it
     unsigned *d_flags = nullptr;       // cross-stream hand-off flags (handoff.hip: hand-offs by stream wait-value), 16 x 64 B
     unsigned flag_seq[16] = {0};       // last value signalled on each (monotonic over the context's life)
     unsigned head_count = 0;           // value of the head-tile counter (flag word TGP_FLAG_HEAD_COUNT) after the last fused launch
@@ -179,7 +177,6 @@ __host__ __device__ inline void tilemap(int64_t b, int64_t T, int &ti, int &tj) 
 
 // implemented across the .hip files
 int tgp_ensure_side_stream(tgp_ctx *ctx);
-int tgp_ensure_chain2_stream(tgp_ctx *ctx);
 int tgp_ensure_scratch(tgp_ctx *ctx, size_t bytes);
 int tgp_ensure_scratch2(tgp_ctx *ctx, size_t bytes);
 int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,
