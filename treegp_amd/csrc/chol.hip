@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void syrk_dtv_queue_kernel(double *Abase, i
             const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));      // HW_ID[15:8]: CU_ID[3:0], SH_ID, SE_ID[2:0]
             const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;  // XCC_ID[3:0]
             const unsigned key = hw + 1;
-            unsigned *claims = queue + 8 + 3 * (4 * xcc + ((hw >> 5) & 3));
+            unsigned *claims = queue + 8 + TGP_QUEUE_MAXRES * (4 * xcc + ((hw >> 5) & 3));
             unsigned leave = 0;
             for (int r = 0; r < nres && !leave; ++r) {
                 const unsigned prev = atomicCAS(&claims[r], 0u, key);
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void syrk_dtv_queue_kernel(double *Abase, i
             // Progress does not depend on where the dispatcher puts workgroups: at most 8 nres + 8 of the 65 of a tile
             // class may leave.  (With other contexts' kernels on the chip the only free room can be the units those kernels
             // keep clear; without the cap every workgroup of this one could land there and leave, and no tile be done.)
-            if (leave && atomicAdd(&queue[104 + xcd], 1u) >= 8u * (unsigned)nres + 8u) leave = 0u;
+            if (leave && atomicAdd(&queue[TGP_QUEUE_LEAVE + xcd], 1u) >= 8u * (unsigned)nres + 8u) leave = 0u;
             s_slot = leave;
         }
         __syncthreads();
@@ -396,14 +396,14 @@ __global__ __launch_bounds__(256, 2) void syrk_distn_queue_kernel(double *Aloc, 
         const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));      // HW_ID[15:8]: CU_ID[3:0], SH_ID, SE_ID[2:0]
         const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;  // XCC_ID[3:0]
         const unsigned key = hw + 1;
-        unsigned *claims = queue + 8 + 3 * (4 * xcc + ((hw >> 5) & 3));
+        unsigned *claims = queue + 8 + TGP_QUEUE_MAXRES * (4 * xcc + ((hw >> 5) & 3));
         unsigned leave = 0;
         for (int r = 0; r < nres && !leave; ++r) {
             const unsigned prev = atomicCAS(&claims[r], 0u, key);
             leave = (prev == 0u || prev == key) ? 1u : 0u;
         }
         // at most 8 nres + 8 workgroups of a class may leave: progress never depends on where the dispatcher puts workgroups
-        if (leave && atomicAdd(&queue[104 + xcd], 1u) >= 8u * (unsigned)nres + 8u) leave = 0u;
+        if (leave && atomicAdd(&queue[TGP_QUEUE_LEAVE + xcd], 1u) >= 8u * (unsigned)nres + 8u) leave = 0u;
         s_slot = leave;
     }
     __syncthreads();
@@ -505,7 +505,7 @@ void launch_syrk2_queued(tgp_ctx *ctx, hipStream_t st, double *d_A, int64_t Np, 
     static const int queue_res = [] { const char *e = getenv("TGP_QUEUE_RES"); return e ? atoi(e) : 0; }();
     int nres = 1;
     if (queue_res > 0) {
-        nres = queue_res > 3 ? 3 : queue_res;
+        nres = queue_res > TGP_QUEUE_MAXRES ? TGP_QUEUE_MAXRES : queue_res;
     } else {
         const int64_t tiles = (int64_t)T * (T + 1) / 2;
         for (int r = 3; r > 1; --r) {
@@ -874,7 +874,7 @@ int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64
     // queued form: one set of counters per launch, zeroed by tgp_dd_queue_reset at the start of a factorisation; beyond
     // TGP_NQUEUE launches (N > 131 072 in groups of four) the sets are reused in turn, each zeroed on this stream in front of
     // its launch -- the launch that used it TGP_NQUEUE launches ago is long finished (same stream)
-    int nres = queue_nres > 3 ? 3 : queue_nres;
+    int nres = queue_nres > TGP_QUEUE_MAXRES ? TGP_QUEUE_MAXRES : queue_nres;
     unsigned *queue = nullptr;
     if (nres > 0 && M.ngroups != 0) {
         queue = ctx->d_queue + TGP_QUEUE_WORDS * (ctx->dist_nqueue % TGP_NQUEUE);

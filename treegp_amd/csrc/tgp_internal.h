@@ -17,7 +17,9 @@
 #define TGP_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
 #endif
 
-#define TGP_QUEUE_WORDS 112    // per launch: 8 XCD-class tile counters + 8 x 4 x 3 clear-CU words + 8 leave counters
+#define TGP_QUEUE_MAXRES 6    // most compute units per shader engine and XCD (of 8) a queued bulk update can keep clear
+#define TGP_QUEUE_LEAVE (8 + 32 * TGP_QUEUE_MAXRES)      // word offset of the 8 leave counters
+#define TGP_QUEUE_WORDS (TGP_QUEUE_LEAVE + 8)   // per launch: 8 XCD-class tile counters + 8 x 4 x MAXRES clear-CU words + 8 leave counters
 #define TGP_NQUEUE 128        // persistent bulk-update launches per factorisation (one set of 8 counters each)
 #define TGP_TB 128            // tile / diagonal-block size
 #define TGP_PW 256            // panel width = trailing-update depth
