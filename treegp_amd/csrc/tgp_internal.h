@@ -197,8 +197,6 @@ hipError_t tgp_signal(tgp_ctx *ctx, hipStream_t from, int id, hipEvent_t ev);
 hipError_t tgp_await(tgp_ctx *ctx, hipStream_t to, int id, hipEvent_t ev);
 bool potrs_big_step(int64_t Np, int *S);
 int acquire_slabs(tgp_ctx *ctx, int64_t Np, int S, double **slab_cache, int *slab_S, double **out, bool *need_build);
-int launch_potrs_big_fwd_step(tgp_ctx *ctx, hipStream_t st, const double *d_A, int64_t Np, int S, const double *slabs, int K,
-                              double *d_b, double *d_z);
 int launch_potrs_big_bwd(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z);
 int launch_kbuild_lower_dist(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,
                              const double *d_yerr, double *d_Aloc, const int64_t *d_loff, int G, int g);
