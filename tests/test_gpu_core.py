@@ -149,7 +149,6 @@ def test_golden_config1_and_aniso2d(tg, golden):
                                  {"TGP_NO_AUGMENT_ALPHA": "1"}, {"TGP_SYNC_EVENTS": "1"}, {"TGP_SYNC_EVENTS": "0"},
                                  {"TGP_SYNC_EVENTS": "1", "TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "8"},
                                  {"TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "8", "TGP_FLAG_SEQ_START": "4294967274"},
-                                 {"TGP_POTRS_UNFUSED": "1"},
                                  {"TGP_FLAG_SEQ_START": "4294967274"}])      # the hand-off sequence numbers wrap during this solve
 def test_alternative_kernel_paths_agree(env):
     """The A/B switches kept in the library (schedules, tile thresholds, hand-off mechanism) must stay correct:

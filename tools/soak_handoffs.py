@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Soak of the factorisation's cross-stream hand-offs (flags + stream wait-value, round 3): many solves per size over every
-schedule regime, each compared BIT FOR BIT with the first solve of its size -- a lost or early hand-off shows up as a different
-bit (or a hang: run under `timeout -k 10 ...`).  Then the same from two host threads with a context each.
+"""Soak of everything that hands over without a kernel boundary or an event: the factorisation's cross-stream hand-offs (flags +
+stream wait-value, round 3) and the multi-GPU driver's fused bulk launches that release the panel chain from inside the
+kernel (round 4).  Many solves
+per size over every schedule regime, each compared BIT FOR BIT with the first solve of its size -- a lost or early hand-off
+shows up as a different bit (or a hang: run under `timeout -k 10 ...`).  Then the same from two host threads with a context
+each, then the multi-GPU driver with a world of one and with four virtual ranks.
 usage: soak_handoffs.py [seconds per size, default 12]"""
 import sys
 import threading
@@ -51,4 +54,59 @@ for t in ths:
     t.start()
 for t in ths:
     t.join()
+
+
+def soak_dist(n, G, seconds):
+    """the multi-GPU driver (fused launches, replicated finish) with G virtual ranks on this GPU: alpha bit for bit over repetitions"""
+    import os
+    import torch
+    sys.path.insert(0, __file__.rsplit("/tools/", 1)[0] + "/tests")
+    from _dist_helpers import ThreadComm
+    from treegp_amd.dist import DistributedGP, SelfComm
+    X, y, ye, Xs = star_field(n, 64, seed=n)
+    y = y - y.mean()
+    dev = torch.device("cuda", 0)
+    shared = ThreadComm.Shared(G)
+    out, errs = [None] * G, []
+
+    def rank(r):
+        try:
+            gp = DistributedGP(_lib.new_ctx(0), spec, X, y, ye, Xs, comm=(ThreadComm(shared, r) if G > 1 else SelfComm()), device=dev)
+            ref, t0, count = None, time.time(), 0
+            while True:
+                alpha, _ = gp.step()
+                torch.cuda.synchronize()
+                got = alpha.cpu().numpy().tobytes()
+                if ref is None:
+                    ref = got
+                elif got != ref:
+                    raise RuntimeError("rank %d of %d, N=%d: step %d differs from the first" % (r, G, n, count))
+                count += 1
+                # every rank takes the same number of steps: the decision to stop is rank 0's, published through the barrier
+                if r == 0:
+                    shared.stop = time.time() - t0 >= seconds and count >= 3
+                if G > 1:
+                    shared.barrier.wait()
+                if getattr(shared, "stop", False):
+                    break
+            out[r] = count
+        except BaseException as ex:      # noqa: BLE001
+            errs.append(ex)
+            try:
+                shared.barrier.abort()
+            except Exception:
+                pass
+
+    ths = [threading.Thread(target=rank, args=(r,)) for r in range(G)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise SystemExit("dist soak failed: %r" % (errs[0],))
+    print("multi-GPU driver, %d virtual rank(s), N=%6d: %4d identical steps" % (G, n, out[0]), flush=True)
+
+
+for n, G in ((8192, 1), (24576, 1), (40000, 1), (12000, 4), (30000, 4)):
+    soak_dist(n, G, budget / 2)
 print("soak ok")

@@ -165,48 +165,11 @@ __global__ __launch_bounds__(256) void vtrans_kernel(const double *__restrict__ 
 // wave per row, whatever lies on the other side of the diagonal inside those panels is zero.  All loads of a row are
 // issued together (panels outside the row's range are redirected to its diagonal panel and weighted with 0): the
 // kernel is one memory latency long, and there is one of it on the critical path of every step.
-// Next step's diagonal product riding in THIS step's bulk launch (round 4).  A step of a sweep used to be two dependent
-// launches -- the S x S product with the inverse slab, then the streaming update -- and at 2 N / S steps per solve the launch
-// boundaries were a fifth of the sweeps' time at N = 65 536 and nearly all of it at N = 8192.  Now the bulk kernel of step K
-// carries, as extra workgroups at the END of its grid, the diagonal product of step K+1: they start by fetching their rows of
-// the slab, wait until the workgroups that update super-block K+1's part of the right-hand side -- the FIRST ones of the grid,
-// so dispatched before them -- have counted themselves in, and finish one memory latency later.  The wait is a bounded spin
-// (a wave that gives up writes NaN, which no caller mistakes for a result).
-struct NextDiag {
-    const double *M = nullptr;      // V (forward) / Vt (backward) slab; nullptr: nothing rides along
-    int64_t r0 = 0;                 // first row of the next super-block
-    int rows = 0;
-    unsigned *count = nullptr;      // producers that have published their part (zeroed before the sweep)
-    unsigned nprod = 0;
-};
-__device__ __forceinline__ bool wait_for_producers(const NextDiag &nd) {
-    bool ok = true;
-    if ((threadIdx.x & 63) == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(nd.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nd.nprod) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1 << 24)) {       // seconds: the producers are gone
-                ok = false;
-                break;
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return __shfl(ok ? 1 : 0, 0, 64) != 0;
-}
-__device__ __forceinline__ void publish(const NextDiag &nd) {      // one wave's stores are out: count it in
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(nd.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// out[r0 + i] = sum_lc M(r0 + i, lc) in[r0 + lc]:  M = V (lower: panels 0 .. i/256) or Vt (upper: panels i/256 .. last); one
-// wave per row, whatever lies on the other side of the diagonal inside those panels is zero.  All loads of a row are
-// issued together (panels outside the row's range are redirected to its diagonal panel and weighted with 0): the
-// product is one memory latency long.  `nd`: the slab rows are fetched first, the vector only after the producers are in.
 template <bool UPPER, int NP, int NR>
-__device__ __forceinline__ void diag_gemv_row(const double *__restrict__ M, int64_t Np, int64_t r0, int rows, int i, const double *in,
-                                              double *out, int64_t vs, const NextDiag *nd) {
+__global__ __launch_bounds__(256) void diag_gemv_big_kernel(const double *__restrict__ M, int64_t Np, int64_t r0, int rows,
+                                                            const double *__restrict__ in, double *__restrict__ out, int64_t vs) {
     const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= rows) return;
     const int pd = i >> 8, plast = (rows - 1) >> 8;
     double2 m[NP][2];
@@ -221,7 +184,6 @@ __device__ __forceinline__ void diag_gemv_row(const double *__restrict__ M, int6
         m[q][0] = *reinterpret_cast<const double2 *>(mp);
         m[q][1] = *reinterpret_cast<const double2 *>(mp + 128);
     }
-    const bool ok = nd ? wait_for_producers(*nd) : true;
 #pragma unroll
     for (int v = 0; v < NR; ++v) {
         double2 x[NP][2];
@@ -236,30 +198,17 @@ __device__ __forceinline__ void diag_gemv_row(const double *__restrict__ M, int6
         for (int q = 0; q < NP; ++q)
             s += wgt[q] * ((m[q][0].x * x[q][0].x + m[q][0].y * x[q][0].y) + (m[q][1].x * x[q][1].x + m[q][1].y * x[q][1].y));
         s = wsum(s);
-        if (lane == 0) out[v * vs + r0 + i] = ok ? s : __builtin_nan("");
+        if (lane == 0) out[v * vs + r0 + i] = s;
     }
-}
-
-template <bool UPPER, int NP, int NR>
-__global__ __launch_bounds__(256) void diag_gemv_big_kernel(const double *__restrict__ M, int64_t Np, int64_t r0, int rows,
-                                                            const double *in, double *out, int64_t vs) {
-    diag_gemv_row<UPPER, NP, NR>(M, Np, r0, rows, blockIdx.x * 4 + (threadIdx.x >> 6), in, out, vs, nullptr);
 }
 
 // forward bulk: b[r] -= L[r, columns of super-block K] . z_K   for nrows rows from row0.  One wave per row, RPW rows per
 // wave with every load (the rows, z, the old b) in flight before the first use: a workgroup lives for one memory latency
-// `nbulk` workgroups do that; the ones behind them (nd.M set) are the next step's diagonal product z_{K+1} = V_{K+1} b_{K+1},
-// whose rows of b are this launch's first nd.rows rows: the waves that update them publish, the product's waves wait.
 template <int NP, int NR>
 __global__ __launch_bounds__(256) void bulk_fwd_kernel(const double *__restrict__ A, int64_t Np, int p0, int npan, int64_t row0,
-                                                       int64_t nrows, const double *__restrict__ z, double *b, int64_t vs,
-                                                       unsigned nbulk, NextDiag nd, double *znext) {
+                                                       int64_t nrows, const double *__restrict__ z, double *b, int64_t vs) {
     constexpr int RPW = (16 / NP) / (NR > 1 ? 2 : 1) > 0 ? (16 / NP) / (NR > 1 ? 2 : 1) : 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (blockIdx.x >= nbulk) {
-        diag_gemv_row<false, NP, NR>(nd.M, Np, nd.r0, nd.rows, (int)(blockIdx.x - nbulk) * 4 + wave, b, znext, vs, &nd);
-        return;
-    }
     const int64_t first = (int64_t)blockIdx.x * (4 * RPW) + wave * RPW;
     if (first >= nrows) return;
     double2 zr[NR][NP][2], av[RPW][NP][2];
@@ -300,7 +249,6 @@ __global__ __launch_bounds__(256) void bulk_fwd_kernel(const double *__restrict_
             if (lane == v * RPW + t) mysum = acc;
         }
     if (lane < NR * RPW && mine < nrows) b[myv * vs + row0 + mine] = bold - mysum;
-    if (nd.M && first < nd.rows) publish(nd);
 }
 
 // backward bulk: z[c] -= sum_i L[r0 + i, c] a[r0 + i]  (i < rows) for the CW columns c0 = CW blockIdx.x .. : no reduction across
@@ -308,26 +256,17 @@ __global__ __launch_bounds__(256) void bulk_fwd_kernel(const double *__restrict_
 // through ONE compute unit (~50 GB/s), so its width sets the latency of the launch: CW = 128 (1 KiB per row and wave load, 1 MiB
 // per workgroup at S = 1024) when there are enough columns to fill the chip anyway, CW = 32 (four rows of 256 B per wave load,
 // 256 KiB per workgroup) for the short steps, where the launch is otherwise 20 us long whatever its size.
-// Workgroups take the column blocks from the RIGHT: the columns of super-block K-1, which the next step's diagonal product
-// a_{K-1} = Vt_{K-1} z_{K-1} needs, are finished (and published) by the first workgroups of the grid; that product rides in
-// the workgroups behind the `nbulk` column blocks (nd.M set), eight rows each.
 template <int CW, int NR>
 __global__ __launch_bounds__(512) void bulk_bwd_kernel(const double *__restrict__ A, int64_t Np, int64_t r0, int rows,
-                                                       const double *a, double *z, int64_t vs, unsigned nbulk,
-                                                       NextDiag nd, double *anext) {
+                                                       const double *__restrict__ a, double *z, int64_t vs) {
     constexpr int LPR = CW / 2;                     // lanes per row (a double2 each)
     constexpr int RPI = 64 / LPR;                   // rows per wave load instruction
     extern __shared__ double dyn_lds[];
     double *as = dyn_lds;                           // [NR][rows]
     double2 *part = reinterpret_cast<double2 *>(dyn_lds);                   // [NR][8][LPR], reuses the space once `as` is done with
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (blockIdx.x >= nbulk) {
-        if (nd.rows > 256) diag_gemv_row<true, 4, NR>(nd.M, Np, nd.r0, nd.rows, (int)(blockIdx.x - nbulk) * 8 + wave, z, anext, vs, &nd);
-        else diag_gemv_row<true, 2, NR>(nd.M, Np, nd.r0, nd.rows, (int)(blockIdx.x - nbulk) * 8 + wave, z, anext, vs, &nd);
-        return;
-    }
     const int sub = lane / LPR, cl = lane % LPR;
-    const int64_t c0 = (int64_t)(nbulk - 1 - blockIdx.x) * CW, p = c0 >> 8;
+    const int64_t c0 = (int64_t)blockIdx.x * CW, p = c0 >> 8;
     // wave-uniform base + 32-bit lane offsets: one address register per load in flight instead of two
     const char *ubase = reinterpret_cast<const char *>(A + panel_off(p, Np) + (r0 - p * TGP_PW) * TGP_PW + (c0 & 255));
     const int loff = 16 * cl;
@@ -410,7 +349,6 @@ __global__ __launch_bounds__(512) void bulk_bwd_kernel(const double *__restrict_
             *reinterpret_cast<double2 *>(z + v * vs + c0 + 2 * tid) = zold[v];
         }
     }
-    if (nd.M && wave == 0 && c0 >= nd.r0) publish(nd);      // (the storing lanes are all in wave 0: LPR <= 64)
 }
 }  // namespace
 
@@ -480,18 +418,28 @@ void launch_diag_gemv(hipStream_t st, int NPmax, const double *M, int64_t Np, in
 
 template <int NP, int NR>
 void launch_bulk_fwd(hipStream_t st, const double *d_A, int64_t Np, int p0, int npan, int64_t row0, int64_t below, const double *z,
-                     double *b, int64_t vs, NextDiag nd, double *znext) {
+                     double *b, int64_t vs) {
     constexpr int RPW = (16 / NP) / (NR > 1 ? 2 : 1) > 0 ? (16 / NP) / (NR > 1 ? 2 : 1) : 1;
-    const unsigned nbulk = (unsigned)((below + 4 * RPW - 1) / (4 * RPW));
-    if (nd.M) nd.nprod = (unsigned)((nd.rows + RPW - 1) / RPW);       // the waves whose rows belong to the next super-block
-    const unsigned ndiag = nd.M ? (unsigned)((nd.rows + 3) / 4) : 0u;
-    bulk_fwd_kernel<NP, NR><<<nbulk + ndiag, 256, 0, st>>>(d_A, Np, p0, npan, row0, below, z, b, vs, nbulk, nd, znext);
+    bulk_fwd_kernel<NP, NR><<<(unsigned)((below + 4 * RPW - 1) / (4 * RPW)), 256, 0, st>>>(d_A, Np, p0, npan, row0, below, z, b, vs);
+}
+
+// one step of the forward sweep: z_K = V_K b_K, then b[below] -= L[below, K] z_K
+template <int NR>
+void fwd_step(hipStream_t st, const double *d_A, int64_t Np, int S, const double *V, int K, double *d_b, double *d_z, int64_t vs) {
+    const int NPmax = S / 256;
+    const int64_t r0 = (int64_t)K * S;
+    const int rows = (int)((Np - r0) < S ? (Np - r0) : S);
+    launch_diag_gemv<false, NR>(st, NPmax, V, Np, r0, rows, d_b, d_z, vs);
+    const int64_t below = Np - (r0 + rows);
+    if (below > 0) {
+        const int p0 = (int)(r0 / 256), npan = rows / 256;
+        if (NPmax <= 2) launch_bulk_fwd<2, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs);
+        else launch_bulk_fwd<4, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs);
+    }
 }
 
 // NR right-hand sides (vectors at stride vs in d_b and d_z) through both sweeps.  `backward_only`: d_z already holds L^-1 b
-// (it came out of the factorisation as the augmented row, api.hip).  `counters`: 2 nS zeroed words (one per step and
-// direction) for the diagonal products that ride in the previous step's bulk launch; nullptr: every step is two launches, as
-// before round 4 (TGP_POTRS_UNFUSED=1, and the pipelined slab build).
+// (it came out of the factorisation as the augmented row, api.hip).
 template <int NR>
 int potrs_big_nr(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z, int64_t vs,
                  bool forward_only, const SlabPipeline *pipe = nullptr, bool backward_only = false) {
@@ -499,34 +447,10 @@ int potrs_big_nr(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const doubl
     const double *V = slabs, *Vt = slabs + Np * S;
     const int nS = (int)((Np + S - 1) / S);
     const int NPmax = S / 256;
-    static const bool unfused = getenv("TGP_POTRS_UNFUSED") != nullptr;
-    unsigned *counters = nullptr;
-    if (!unfused && !pipe && 2 * nS <= TGP_NQUEUE * TGP_QUEUE_WORDS) {
-        counters = ctx->d_queue;                  // free between factorisations: the sweeps run behind them on the same stream
-        TGP_HIP(hipMemsetAsync(counters, 0, (size_t)2 * nS * sizeof(unsigned), st));
-    }
-    auto rows_of = [&](int K) { return (int)((Np - (int64_t)K * S) < S ? (Np - (int64_t)K * S) : S); };
-    if (!backward_only) {
-        if (counters) launch_diag_gemv<false, NR>(st, NPmax, V, Np, 0, rows_of(0), d_b, d_z, vs);
-        for (int K = 0; K < nS; ++K) {
-            // slabs built beside this sweep (launch_potrs): super-block K's chunk has to be there
-            if (pipe && K > 0 && K % pipe->chunk == 0) TGP_HIP(hipStreamWaitEvent(st, pipe->ready[K / pipe->chunk], 0));
-            const int64_t r0 = (int64_t)K * S;
-            const int rows = rows_of(K);
-            if (!counters) launch_diag_gemv<false, NR>(st, NPmax, V, Np, r0, rows, d_b, d_z, vs);
-            const int64_t below = Np - (r0 + rows);
-            if (below <= 0) break;
-            NextDiag nd;
-            if (counters) {
-                nd.M = V;
-                nd.r0 = r0 + rows;
-                nd.rows = rows_of(K + 1);
-                nd.count = counters + K;
-            }
-            const int p0 = (int)(r0 / 256), npan = rows / 256;
-            if (NPmax <= 2) launch_bulk_fwd<2, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs, nd, d_z);
-            else launch_bulk_fwd<4, NR>(st, d_A, Np, p0, npan, r0 + rows, below, d_z + r0, d_b, vs, nd, d_z);
-        }
+    for (int K = 0; K < nS && !backward_only; ++K) {
+        // slabs built beside this sweep (launch_potrs): super-block K's chunk has to be there
+        if (pipe && K > 0 && K % pipe->chunk == 0) TGP_HIP(hipStreamWaitEvent(st, pipe->ready[K / pipe->chunk], 0));
+        fwd_step<NR>(st, d_A, Np, S, V, K, d_b, d_z, vs);
     }
     if (forward_only) {
         for (int v = 0; v < NR; ++v)
@@ -534,30 +458,17 @@ int potrs_big_nr(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const doubl
         TGP_HIP(hipGetLastError());
         return 0;
     }
-    if (counters) launch_diag_gemv<true, NR>(st, NPmax, Vt, Np, (int64_t)(nS - 1) * S, rows_of(nS - 1), d_z, d_b, vs);
     for (int K = nS - 1; K >= 0; --K) {
         const int64_t r0 = (int64_t)K * S;
-        const int rows = rows_of(K);
-        if (!counters) launch_diag_gemv<true, NR>(st, NPmax, Vt, Np, r0, rows, d_z, d_b, vs);
+        const int rows = (int)((Np - r0) < S ? (Np - r0) : S);
+        launch_diag_gemv<true, NR>(st, NPmax, Vt, Np, r0, rows, d_z, d_b, vs);
         if (K > 0) {
-            NextDiag nd;
-            if (counters) {
-                nd.M = Vt;
-                nd.r0 = r0 - S;
-                nd.rows = S;
-                nd.count = counters + nS + K;
-            }
-            const unsigned ndiag = nd.M ? (unsigned)(S / 8) : 0u;
             if (r0 / 128 >= 512) {
                 const size_t lds = (size_t)NR * (rows * 8 > 8 * 64 * 16 ? rows * 8 : 8 * 64 * 16);
-                const unsigned nbulk = (unsigned)(r0 / 128);
-                nd.nprod = (unsigned)(S / 128);
-                bulk_bwd_kernel<128, NR><<<nbulk + ndiag, 512, lds, st>>>(d_A, Np, r0, rows, d_b, d_z, vs, nbulk, nd, d_b);
+                bulk_bwd_kernel<128, NR><<<(unsigned)(r0 / 128), 512, lds, st>>>(d_A, Np, r0, rows, d_b, d_z, vs);
             } else {
                 const size_t lds = (size_t)NR * (rows * 8 > 8 * 16 * 16 ? rows * 8 : 8 * 16 * 16);
-                const unsigned nbulk = (unsigned)(r0 / 32);
-                nd.nprod = (unsigned)(S / 32);
-                bulk_bwd_kernel<32, NR><<<nbulk + ndiag, 512, lds, st>>>(d_A, Np, r0, rows, d_b, d_z, vs, nbulk, nd, d_b);
+                bulk_bwd_kernel<32, NR><<<(unsigned)(r0 / 32), 512, lds, st>>>(d_A, Np, r0, rows, d_b, d_z, vs);
             }
         }
     }
