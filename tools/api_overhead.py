@@ -11,6 +11,8 @@ from treegp_amd import _lib  # noqa: E402
 from treegp_amd.synthetic import star_field, headline_kernel_string  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+if len(sys.argv) > 2 and sys.argv[2] == "profiling":      # bench.py's mode: per-launch events in the factorisation
+    _lib.load_library().tgp_set_profiling(_lib.get_ctx(), 1)
 X, y, ye, Xs = star_field(n, 4 * n)
 for rep in range(3):
     gp = treegp_amd.GPInterpolation(kernel=headline_kernel_string(), optimizer="none", normalize=True, white_noise=0.0)
