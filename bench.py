@@ -282,7 +282,16 @@ def api_route(X, y, y_err, Xs, kernel_string, passes=5):
         t0 = time.perf_counter()
         gp1.initialize(X, y, y_err)
         t1 = time.perf_counter()
-        gp1.predict(Xs)
+        if it == passes and os.environ.get("TGP_BENCH_PROFILE_API") == "1":      # development: where the host time of a pass goes
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            gp1.predict(Xs)
+            pr.disable()
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(12)
+        else:
+            gp1.predict(Xs)
         t2 = time.perf_counter()
         tm = _lib.timings(_lib.get_ctx())
         if it:

@@ -72,6 +72,14 @@ def test_virtual_ranks_replicated_finish(G, n, group, finish, replicate, monkeyp
     _run_virtual_ranks(G, n)
 
 
+def test_world_of_one_forced_to_the_fused_launch(monkeypatch):
+    """a world of one takes the two-launch form by default (whole-chip launches: DESIGN A.0); TGP_DIST_FUSED=1 forces the fused one"""
+    monkeypatch.setenv("TGP_DIST_GROUP", "4")
+    monkeypatch.setenv("TGP_DIST_FUSED", "1")
+    monkeypatch.setenv("TGP_DIST_FINISH", "0")
+    _run_virtual_ranks(1, 6000)
+
+
 @pytest.mark.parametrize("G,n,group,units", [(2, 5000, 4, "0"), (8, 6000, 4, "0"), (3, 4000, 2, "2")])
 def test_virtual_ranks_split_update_with_events(G, n, group, units, monkeypatch):
     """The two-launch form of a group's update (head columns, event, rest) that the driver falls back to where stream
@@ -242,7 +250,7 @@ def test_fused_update_equals_the_two_launches(G, g, n, ns):
     spec, X, y, y_err, Xs = _problem(n, 10)
     dev = torch.device("cuda", 0)
     o = HipLocalOps(_lib.new_ctx(0), spec, len(y), G, g, dev, replicate=False)
-    if not o.fused_ok():
+    if _lib.load_library().tgp_handoff_mode(o.ctx) != 1:
         pytest.skip("hand-offs by events on this box")
     dX, de = o.to_device(as_xy(X)), o.to_device(y_err)
     o.kbuild(dX, de)

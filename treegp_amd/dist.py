@@ -464,8 +464,11 @@ class HipLocalOps(object):
     def fused_ok(self):
         """the whole update of a group as one launch that signals the panel chain from inside (tgp_dd_update_group_fused):
         only where this process hands over between streams by flags + stream wait-value (a first-use trial decides,
-        csrc/handoff.hip); TGP_DIST_FUSED=0: two launches and an event, as before round 4"""
-        if os.environ.get("TGP_DIST_FUSED", "1") == "0":
+        csrc/handoff.hip) and with more than one rank; TGP_DIST_FUSED=0: two launches and an event, as before round 4"""
+        env = os.environ.get("TGP_DIST_FUSED")
+        if env == "0" or (env is None and self.G == 1):
+            # a world of one runs whole-chip launches of dozens of rounds: there the fused form loses 0.6 % (the rest tiles
+            # start in lockstep when the head ends and the chain waits a tile time for a slot; DESIGN A.0); TGP_DIST_FUSED=1 forces it
             return False
         return int(self.lib.tgp_handoff_mode(self.ctx)) == 1
 
