@@ -278,6 +278,10 @@ def api_route(X, y, y_err, Xs, kernel_string, passes=5):
     from treegp_amd import _lib
     gp1 = treegp_amd.GPInterpolation(kernel=kernel_string, optimizer="none", normalize=True, white_noise=0.0, backend="single")
     rows = []
+    # as a user runs it: without the per-launch events of the roofline accounting (in that mode the factorisation ends with a
+    # host loop over ~200 event pairs, 10 - 30 ms at the headline size that no device phase shows; TGP_HOST_PHASES=1 prints it)
+    lib, ctx0 = _lib.load_library(), _lib.get_ctx()
+    lib.tgp_set_profiling(ctx0, 0)
     for it in range(passes + 1):
         t0 = time.perf_counter()
         gp1.initialize(X, y, y_err)
@@ -296,6 +300,7 @@ def api_route(X, y, y_err, Xs, kernel_string, passes=5):
         tm = _lib.timings(_lib.get_ctx())
         if it:
             rows.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t2 - t0) * 1e3, tm[0] + tm[1] + tm[2] + tm[3]))
+    lib.tgp_set_profiling(ctx0, 1)
     rows = np.array(rows)
     return {"initialize": float(np.median(rows[:, 0])), "predict": float(np.median(rows[:, 1])), "total": float(np.median(rows[:, 2])),
             "total_min": float(rows[:, 2].min()), "total_max": float(rows[:, 2].max()), "passes": passes,

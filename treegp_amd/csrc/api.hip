@@ -1,6 +1,8 @@
 // C-ABI glue of libtgp.so (include/tgp.h): context, staging of host buffers, phase timings.
 #include "tgp_internal.h"
 
+#include <chrono>
+
 namespace {
 struct Arena {               // bump allocator over the ctx staging buffer (sized up front)
     char *base;
@@ -323,8 +325,11 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
     };
     // The solves are queued behind the factorisation without waiting for its verdict (one host round trip less per
     // likelihood evaluation); if a pivot failed they run on a meaningless factor and their result is discarded below.
+    static const bool dbg = getenv("TGP_HOST_PHASES") != nullptr;
+    const auto h0 = std::chrono::steady_clock::now();
     int info = launch_potrf(ctx, d_A, Np, d_W, /*defer_info=*/true, /*n_data=*/n);
     if (info < 0) return fail(info);
+    const auto h1 = std::chrono::steady_clock::now();
     TGP_HIP(hipEventRecord(ctx->ev[2], st));
     double sweeps = 0.0;
     if (info == 0 && augmented) {
@@ -375,7 +380,13 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
         TGP_HIP(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     TGP_HIP(hipEventRecord(ctx->ev[3], st));
+    const auto h2 = std::chrono::steady_clock::now();
     TGP_HIP(hipStreamSynchronize(st));
+    if (dbg) {
+        const auto h3 = std::chrono::steady_clock::now();
+        auto d = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[factor_and_solve] launch_potrf returned after %.2f ms, solves queued after %.2f ms, final sync %.2f ms\n", d(h0, h1), d(h1, h2), d(h2, h3));
+    }
     if (info == 0) info = *ctx->h_info;               // the factorisation's verdict (first failing pivot, 1-based)
     float ms = 0.f;
     TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
@@ -529,15 +540,26 @@ int tgp_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n, 
     Arena ar{(char *)ext_of(ctx)->io.buf};
     double *d_X = ar.take<double>(2 * n), *d_y = ar.take<double>(n), *d_e = ar.take<double>(n),
            *d_a = ar.take<double>(n);
+    const bool dbg = getenv("TGP_HOST_PHASES") != nullptr;      // development: where the host-boundary call spends its wall time
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
     TGP_HIP(hipMemcpyAsync(d_X, X, 2 * n * 8, hipMemcpyHostToDevice, st));
     TGP_HIP(hipMemcpyAsync(d_y, y, n * 8, hipMemcpyHostToDevice, st));
     if (yerr) TGP_HIP(hipMemcpyAsync(d_e, yerr, n * 8, hipMemcpyHostToDevice, st));
+    const auto t1 = now();
     rc = tgp_d_gp_solve(ctx, k, d_X, n, d_y, yerr ? d_e : nullptr, alpha ? d_a : nullptr, logdet, ydota, keep);
     if (rc) return rc;
+    const auto t2 = now();
     if (alpha) {
         TGP_HIP(hipMemcpyAsync(alpha, d_a, n * 8, hipMemcpyDeviceToHost, st));
         TGP_HIP(hipStreamSynchronize(st));
     }
+    if (dbg)
+        fprintf(stderr, "[tgp_gp_solve n=%ld] H2D %.2f ms, tgp_d_gp_solve %.2f ms (device phases %.2f), D2H %.2f ms\n", (long)n, ms(t0, t1),
+                ms(t1, t2), ctx->timings[0] + ctx->timings[1] + ctx->timings[2], ms(t2, now()));
     return 0;
 }
 
