@@ -73,6 +73,11 @@ def _worker(rank, world, port, n, out_dir, group=None, gather=None, finish=None)
         Kbad[300, 300] = -1.0
         ch2 = DistributedCholesky(NumpyLocalOps(Kbad, n, world, rank), comm)
         assert ch2.factorize() > 0
+        # ... also when the failing pivot lies in the replicated finish (the last rows, factored by every rank)
+        Kbad = K.copy()
+        Kbad[n - 2, n - 2] = -1.0
+        ch3 = DistributedCholesky(NumpyLocalOps(Kbad, n, world, rank), comm)
+        assert ch3.factorize() > 0
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()

@@ -260,6 +260,14 @@ def test_threshold_route_fields_and_errors_virtual_ranks(tmp_path):
         bad.initialize(Xd, y, np.zeros(n))
         with pytest.raises(np.linalg.LinAlgError):
             bad.predict(Xs[:10])
+        # the same with the coincident pair among the LAST points: the failing pivot lies in the replicated finish, which every
+        # rank factors redundantly -- still one LinAlgError on every rank
+        bad2 = treegp_amd.GPInterpolation(kernel=kw["kernel"], optimizer="none", backend="dist")
+        Xe = X.copy()
+        Xe[n - 1] = Xe[n - 2]
+        bad2.initialize(Xe, y, np.zeros(n))
+        with pytest.raises(np.linalg.LinAlgError):
+            bad2.predict(Xs[:10])
         return yp, fields, ys
 
     scale = np.abs(ref).max()
