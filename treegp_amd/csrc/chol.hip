@@ -218,13 +218,18 @@ struct HeadSignal {
     int nhead = 0;                                  // 0: not a fused launch
 };
 __device__ __forceinline__ void head_done(const HeadSignal &h) {
-    // every wave makes its stores visible device-wide (release fence at agent scope: vmcnt(0) + write-back of the XCD's L2)
-    // before the barrier; then one thread counts the workgroup in
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // The workgroup's stores become visible device-wide: every wave waits until its own stores have been acknowledged by the
+    // L2 (vmcnt(0)), the barrier collects the waves, and ONE wave then writes the XCD's L2 back (release fence at agent scope);
+    // then one thread counts the workgroup in.  (Every wave fencing before the barrier -- four write-backs per workgroup --
+    // cost 1.5 ms of a rank's 190 at 8 ranks and N = 65 536: profiles/r04_head_fence_ab.txt.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(h.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == h.target) __hip_atomic_store(h.flag, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(h.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1u == h.target) __hip_atomic_store(h.flag, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
