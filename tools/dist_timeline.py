@@ -41,6 +41,13 @@ def main():
     last = max(int(r["End_Timestamp"]) for r in bulk)
     print("after the last bulk launch: %.2f ms" % ((max(int(r["End_Timestamp"]) for r in rows) - last) / 1e6))
     print("before the first bulk launch: %.2f ms" % ((int(bulk[0]["Start_Timestamp"]) - t0) / 1e6))
+    if len(sys.argv) > 3:                                   # every kernel from this many ms before the last bulk launch's end
+        lo = last - int(float(sys.argv[3]) * 1e6)
+        print("kernels from %.2f ms before the end of the last bulk launch on (start ms rel. to it, dur us, workgroups, queue, name):" % float(sys.argv[3]))
+        for r in rows:
+            if int(r["End_Timestamp"]) >= lo:
+                print("  %8.3f  %8.1f  %6d  q%-3s %s" % ((int(r["Start_Timestamp"]) - last) / 1e6, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                                                   int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), r.get("Queue_Id", "?"), name(r).split("(")[0][-70:]))
 
 
 if __name__ == "__main__":

@@ -66,6 +66,21 @@ __global__ __launch_bounds__(256, 2) void panel_tall_kernel(double *rows0, const
     gemm_tile_128<0, TGP_TB, TGP_TB>(rows + TGP_TB, W1, rows + TGP_TB);
 }
 
+// The same three steps on the latency tile, one workgroup per 16-row slice (8 x the workgroups, each ~1/5 of the time): for a
+// rank's panel solves of a multi-GPU factorisation, which hold 2 - 64 row tiles and sit on the panel chain's critical path
+// (59 us per panel in the 128-row form whatever the number of tiles, kernel trace of a rank's share at 8 ranks).
+__global__ __launch_bounds__(256) void panel_tall_small_kernel(double *rows0, const double *W0, const double *L10, const double *W1) {
+    double *rows = rows0 + (int64_t)blockIdx.x * 16 * TGP_PW;
+    TGP_CHAIN_PRIO();
+    nt_small_tile<0, TGP_TB, 1>(rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's X0 is in the L2 before the others read it
+    __syncthreads();
+    nt_small_tile<1, TGP_TB, 1>(rows, TGP_PW, L10, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    nt_small_tile<0, TGP_TB, 1>(rows + TGP_TB, TGP_PW, W1, TGP_TB, rows + TGP_TB, TGP_PW, nullptr, nullptr);
+}
+
 // rows 128..255 of a 256 x 256 diagonal block between its two potrf128 calls, one workgroup, one launch:
 // L10 = A10 W0^T, then A11 -= L10 L10^T
 __global__ __launch_bounds__(256, 2) void diag_mid_kernel(double *R1, const double *W0) {
@@ -295,6 +310,7 @@ struct DistMap {
     int whole;                // 64 floor(total / 8): slots per XCD class that belong to whole super-tiles
     int half_from;            // tile slots of a class from this one on are run as two 64-row half tiles each (the last round)
     int nhead, head_cols;     // fused form: workgroup indices below nhead (a multiple of 8) are the dense grid of the head columns
+    int head_half;            // the dense grid (a strip, or the head of a fused launch) runs as 64-row half tiles, two workgroups per tile
     HeadSignal hs;            // what the head's last workgroup publishes (hs.nhead is not used here)
 };
 __device__ __forceinline__ int div_g(int x, unsigned ginv) { return ginv ? (int)__umulhi((unsigned)x, ginv) : x; }     // ginv == 0: G == 1
@@ -318,8 +334,13 @@ __device__ __forceinline__ void syrk_distn_tile(int64_t b, double *Aloc, const i
     const bool head = M.ngroups == 0 || b < M.nhead;
     if (head) {
         const int hc = M.ngroups == 0 ? ncol : M.head_cols;
-        lt = (int)(b / hc);
-        ct = (int)(b - (int64_t)lt * hc);
+        int64_t bb = b;
+        if (M.head_half) {                    // what the panel chain waits for, when it is less than a round of tiles: half the time per tile
+            half = (int)(bb & 1);
+            bb >>= 1;
+        }
+        lt = (int)(bb / hc);
+        ct = (int)(bb - (int64_t)lt * hc);
         valid = lt < nrows;
     } else {
         const int bb = (int)(b - M.nhead);
@@ -783,7 +804,14 @@ int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int
 // rows (ntiles x 128, ld 256) <- rows L_kk^-T with L_kk given by its 256x256 block and W0, W1
 int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, const double *W0, const double *W1) {
     if (ntiles <= 0) return 0;
-    panel_tall_kernel<<<ntiles, 256, 0, ctx->stream>>>(rows, W0, Lkk + (int64_t)TGP_TB * TGP_PW, W1);
+    // up to 24 row tiles -- about where a rank's bulk update falls under the chain's time at 2 - 8 ranks: beside a long bulk
+    // launch eight times the workgroups wait longer for slots than they save (sweep 0 / 16 / 24 / 32 / 48 / 64:
+    // profiles/r04_chain_latency_ab.txt)
+    constexpr int small_max = 24;
+    if (ntiles <= small_max)
+        panel_tall_small_kernel<<<ntiles * 8, 256, 0, ctx->stream>>>(rows, W0, Lkk + (int64_t)TGP_TB * TGP_PW, W1);
+    else
+        panel_tall_kernel<<<ntiles, 256, 0, ctx->stream>>>(rows, W0, Lkk + (int64_t)TGP_TB * TGP_PW, W1);
     TGP_HIP(hipGetLastError());
     return 0;
 }
@@ -817,8 +845,11 @@ int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64
     const int64_t ncol = (int64_t)col_hi - col_lo;
     hipStream_t st = ctx->stream;
     DistMap M;
-    M.nhead = M.head_cols = M.whole = 0;
+    M.nhead = M.head_cols = M.whole = M.head_half = 0;
     M.half_from = 1 << 30;
+    // what the panel chain waits for -- its own strips, the head of a fused launch -- runs as 64-row half tiles while the
+    // halves still fit one round of slots (256 tiles): half the time per tile on the chain's critical path
+    constexpr int half_max = 256;
     if (head_cols > 0) {
         // the waiter is released whatever this rank's share is (even none at all): the signal is part of the call's contract
         hipError_t e = hipSuccess;
@@ -845,11 +876,13 @@ int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64
     if (head_cols == 0 && ncol <= 8 && queue_nres == 0) {
         M.ngroups = 0;
         M.start[0] = 0;
-        grid = (unsigned)((int64_t)nrows * ncol);
+        M.head_half = (int64_t)nrows * ncol <= half_max ? 1 : 0;
+        grid = (unsigned)((int64_t)nrows * ncol) << M.head_half;
     } else {
         if (head_cols > ncol) head_cols = (int)ncol;
         M.head_cols = head_cols;
-        M.nhead = (nrows * head_cols + 7) / 8 * 8;
+        M.head_half = (head_cols > 0 && (int64_t)nrows * head_cols <= half_max) ? 1 : 0;
+        M.nhead = ((nrows * head_cols << M.head_half) + 7) / 8 * 8;
         M.ngroups = (nrows + 7) / 8;
         TGP_ARG(M.ngroups <= 257);
         int total = 0;
