@@ -12,9 +12,12 @@ g=7
 run TGP_DIST_FUSED=0
 run TGP_DIST_HALF_TILES=0
 run TGP_DIST_FINISH=0
+run TGP_DIST_FINISH=8
 run TGP_DIST_FINISH=32
 run TGP_DIST_QUEUE=-1
 run TGP_DIST_GROUP=2
 X=launches; run DEFAULTS=1; X=""
 N=131072; G=8; g=7; run DEFAULTS=1
+N=32768; G=8; g=7; run DEFAULTS=1
+N=16384; G=4; g=3; run DEFAULTS=1
 cat $R | grep "N=\|^#"

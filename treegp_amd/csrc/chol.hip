@@ -56,9 +56,21 @@ __global__ __launch_bounds__(256) void gemm_col_small_kernel(const double *A, co
 // half, W0 / W1 the inverted 128-blocks).  A row tile depends on nothing but itself and the diagonal block.  Used by the
 // multi-GPU panel chain (tgp_dd_trsm), where every launch beside the bulk update waits for workgroup slots: one wait
 // instead of three.  (On one GPU the same fusion did not pay: same number of launches on the chain, see DESIGN.)
-__global__ __launch_bounds__(256, 2) void panel_tall_kernel(double *rows0, const double *W0, const double *L10, const double *W1) {
+// (keep != nullptr: the grid also copies the two inverted blocks, 2 x 128 x 128 doubles at W0, to `keep` -- a rank that received
+// them in the broadcast keeps them for the solves; as a copy of its own it was one more 5 us kernel on the panel chain)
+__device__ __forceinline__ void keep_w_share(double *__restrict__ keep, const double *__restrict__ W0) {
+    if (!keep) return;
+    constexpr int n2 = TGP_TB * TGP_TB;                        // double2 elements
+    const int per = (n2 + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int lo = (int)blockIdx.x * per, hi = lo + per < n2 ? lo + per : n2;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += 256)
+        reinterpret_cast<double2 *>(keep)[i] = reinterpret_cast<const double2 *>(W0)[i];
+}
+__global__ __launch_bounds__(256, 2) void panel_tall_kernel(double *rows0, const double *W0, const double *L10, const double *W1,
+                                                            double *keep) {
     double *rows = rows0 + (int64_t)blockIdx.x * 128 * TGP_PW;
     TGP_CHAIN_PRIO();
+    keep_w_share(keep, W0);
     gemm_tile_128<0, TGP_TB, TGP_TB>(rows, W0, rows);
     __syncthreads();
     gemm_tile_128<1, TGP_PW, TGP_TB>(rows, L10, rows + TGP_TB);
@@ -69,9 +81,11 @@ __global__ __launch_bounds__(256, 2) void panel_tall_kernel(double *rows0, const
 // The same three steps on the latency tile, one workgroup per 16-row slice (8 x the workgroups, each ~1/5 of the time): for a
 // rank's panel solves of a multi-GPU factorisation, which hold 2 - 64 row tiles and sit on the panel chain's critical path
 // (59 us per panel in the 128-row form whatever the number of tiles, kernel trace of a rank's share at 8 ranks).
-__global__ __launch_bounds__(256) void panel_tall_small_kernel(double *rows0, const double *W0, const double *L10, const double *W1) {
+__global__ __launch_bounds__(256) void panel_tall_small_kernel(double *rows0, const double *W0, const double *L10, const double *W1,
+                                                               double *keep) {
     double *rows = rows0 + (int64_t)blockIdx.x * 16 * TGP_PW;
     TGP_CHAIN_PRIO();
+    keep_w_share(keep, W0);
     nt_small_tile<0, TGP_TB, 1>(rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's X0 is in the L2 before the others read it
     __syncthreads();
@@ -790,28 +804,39 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
 }
 
 // 256x256 diagonal block (ld 256): L in place, inverses of its two 128-blocks to W0 / W1
-int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base) {
+// `latency`: the step between the two 128-blocks as two launches of eight 16-row slices (2 x ~8 us + a launch gap) instead of one
+// workgroup's 42 us -- for the chain-bound phase; beside a long bulk launch every launch waits for slots and one is better
+int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base, bool latency) {
     hipStream_t st = ctx->stream;
     double *R1 = blk + (int64_t)TGP_TB * TGP_PW;
     const bool excl = ctx->chain_exclusive != 0;      // a queued bulk update keeps compute units clear for this chain
     run_potrf128(st, blk, TGP_PW, W0, ctx->d_info, base, excl);
-    diag_mid_kernel<<<1, 256, 0, st>>>(R1, W0);
+    if (latency) {
+        gemm_col_small_kernel<0, TGP_TB><<<8, 256, 0, st>>>(R1, W0, R1);
+        gemm_col_small_kernel<1, TGP_PW><<<8, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
+    } else {
+        diag_mid_kernel<<<1, 256, 0, st>>>(R1, W0);
+    }
     run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, ctx->d_info, base + TGP_TB, excl);
     TGP_HIP(hipGetLastError());
     return 0;
 }
 
 // rows (ntiles x 128, ld 256) <- rows L_kk^-T with L_kk given by its 256x256 block and W0, W1
-int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, const double *W0, const double *W1) {
-    if (ntiles <= 0) return 0;
+// keepW != nullptr: [W0 | W1] (contiguous at W0) is also copied there
+int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, const double *W0, const double *W1, double *keepW) {
+    if (ntiles <= 0) {
+        if (keepW) TGP_HIP(hipMemcpyAsync(keepW, W0, (size_t)2 * TGP_TB * TGP_TB * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
     // up to 24 row tiles -- about where a rank's bulk update falls under the chain's time at 2 - 8 ranks: beside a long bulk
     // launch eight times the workgroups wait longer for slots than they save (sweep 0 / 16 / 24 / 32 / 48 / 64:
     // profiles/r04_chain_latency_ab.txt)
     constexpr int small_max = 24;
     if (ntiles <= small_max)
-        panel_tall_small_kernel<<<ntiles * 8, 256, 0, ctx->stream>>>(rows, W0, Lkk + (int64_t)TGP_TB * TGP_PW, W1);
+        panel_tall_small_kernel<<<ntiles * 8, 256, 0, ctx->stream>>>(rows, W0, Lkk + (int64_t)TGP_TB * TGP_PW, W1, keepW);
     else
-        panel_tall_kernel<<<ntiles, 256, 0, ctx->stream>>>(rows, W0, Lkk + (int64_t)TGP_TB * TGP_PW, W1);
+        panel_tall_kernel<<<ntiles, 256, 0, ctx->stream>>>(rows, W0, Lkk + (int64_t)TGP_TB * TGP_PW, W1, keepW);
     TGP_HIP(hipGetLastError());
     return 0;
 }

@@ -65,7 +65,9 @@ int tgp_dd_factor_diag(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int6
     hipStream_t st = ctx->stream;
     double *blk = d_Aloc + h_loff[kpanel];
     double *W0 = d_W + (int64_t)(2 * kpanel) * TGP_TB * TGP_TB;
-    int rc = launch_factor_diag256(ctx, blk, W0, W0 + TGP_TB * TGP_TB, kpanel * TGP_PW);
+    // (latency form where the rank's rows below hold at most 24 row tiles: the chain-bound phase, as for its panel solve)
+    const bool latency = dist_panel_blocks(kpanel + 1, Np / TGP_PW, g, G) <= 12;
+    int rc = launch_factor_diag256(ctx, blk, W0, W0 + TGP_TB * TGP_TB, kpanel * TGP_PW, latency);
     if (rc) return rc;
     TGP_HIP(hipMemcpyAsync(d_bcast, blk, (size_t)TGP_PW * TGP_PW * 8, hipMemcpyDeviceToDevice, st));
     TGP_HIP(hipMemcpyAsync(d_bcast + TGP_PW * TGP_PW, W0, (size_t)2 * TGP_TB * TGP_TB * 8, hipMemcpyDeviceToDevice, st));
@@ -76,16 +78,14 @@ int tgp_dd_factor_diag(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int6
 int tgp_dd_trsm(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int64_t Np, int kpanel, int G, int g,
                 double *d_W, const double *d_bcast) {
     TGP_ARG(d_Aloc && h_loff && d_W && d_bcast);
-    hipStream_t st = ctx->stream;
     double *W0 = d_W + (int64_t)(2 * kpanel) * TGP_TB * TGP_TB;
-    if (dist_owner(kpanel, G) != g)
-        TGP_HIP(hipMemcpyAsync(W0, d_bcast + TGP_PW * TGP_PW, (size_t)2 * TGP_TB * TGP_TB * 8, hipMemcpyDeviceToDevice, st));
+    double *keepW = dist_owner(kpanel, G) != g ? W0 : nullptr;      // a receiver keeps the inverted blocks: copied by the solve's grid
     const int64_t nB = Np / TGP_PW;
     const int64_t below = dist_panel_blocks(kpanel + 1, nB, g, G);
     const int64_t skip = (dist_owner(kpanel, G) == g) ? TGP_PW : 0;          // the owner's diagonal block comes first
     double *rows = d_Aloc + h_loff[kpanel] + skip * TGP_PW;
     return launch_trsm_rows(ctx, rows, (int)(2 * below), d_bcast, d_bcast + TGP_PW * TGP_PW,
-                            d_bcast + TGP_PW * TGP_PW + TGP_TB * TGP_TB);
+                            d_bcast + TGP_PW * TGP_PW + TGP_TB * TGP_TB, keepW);
 }
 
 // tgp_dd_update / tgp_dd_update2: the one- and two-panel forms of tgp_dd_update_group

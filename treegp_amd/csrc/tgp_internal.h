@@ -200,8 +200,8 @@ int acquire_slabs(tgp_ctx *ctx, int64_t Np, int S, double **slab_cache, int *sla
 int launch_potrs_big_bwd(tgp_ctx *ctx, const double *d_A, int64_t Np, int S, const double *slabs, double *d_b, double *d_z);
 int launch_kbuild_lower_dist(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,
                              const double *d_yerr, double *d_Aloc, const int64_t *d_loff, int G, int g);
-int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base);
-int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, const double *W0, const double *W1);
+int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base, bool latency = false);
+int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, const double *W0, const double *W1, double *keepW = nullptr);
 int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
                       const double *const *d_P, const int *cmax, int col_lo, int col_hi, int queue_nres = 0, int head_cols = 0);
 int launch_diag256_fwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y);

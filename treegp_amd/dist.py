@@ -629,9 +629,9 @@ class DistributedCholesky(object):
     def factorize(self):
         """Right-looking factorisation, panels taken in GROUPS of `self.group`, look-ahead on two streams.
 
-        Side stream (high priority), for the group k .. k+GS-1: for every panel j of it, first the depth-256 j
-        update of its two tile columns with the j gathered panels before it (one launch), then its diagonal block
-        on its owner, broadcast, local solves, all-gather.  Main stream: Ua, the 2 GS tile columns of the NEXT
+        Side stream (high priority), for the group k .. k+GS-1: for every panel j of it, its diagonal block
+        on its owner, broadcast, local solves, all-gather, then the depth-256 update of the tile columns of the
+        group's later panels with it (one launch).  Main stream: Ua, the 2 GS tile columns of the NEXT
         group with all GS gathered panels (depth 256 GS), after which the side stream may start on that group,
         and then Ub, the bulk of the trailing matrix in one pass of the same depth, concurrent with it.
         Per-tile fixed costs of the update (C read + write, pipeline fill) fall from 13 % at depth 256 to 6.8 %
@@ -689,8 +689,11 @@ class DistributedCholesky(object):
                 if j > 0:
                     w, c = out[j - 1]
                     w.wait()                                     # side stream: panel k+j-1 is on every rank
-                    # panel k+j's two tile columns against the j panels before it, one launch of depth 256 j
-                    ops.update_group(k, [ow.tensor for ow, _ in out], [oc for _, oc in out], 0, 2, side=True)
+                    # panel k+j-1 against the tile columns of ALL later panels of the group, depth 256: every strip on the
+                    # chain is one tile time of depth 256 (rounds 2-4 updated panel k+j's two columns against the j panels
+                    # before it, depth 256 j: 24 / 41 / 59 us instead of 3 x 24 in the chain-bound phase,
+                    # profiles/r04_strips_ab.txt)
+                    ops.update_group(k + j - 1, [w.tensor], [c], 0, 2 * (GS - j), side=True)
                 out.append(factor_and_gather(k + j, bufs[j]))
                 if keep and out[-1][0] is not None:
                     ops.keep_rows(k + j, out[-1][0].tensor, out[-1][1], out[-1][0])   # copied on the keep stream, off this chain
