@@ -253,7 +253,8 @@ int tgp_dd_kbuild(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t 
 /* owner of panel kpanel: factor the diagonal block, pack [L_kk(256x256) | W0 | W1] = 98304 doubles */
 int tgp_dd_factor_diag(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int64_t Np, int kpanel, int G, int g,
                        double *d_W, double *d_bcast);
-/* every rank, after the broadcast of d_bcast: solve the local rows of panel kpanel */
+/* every rank, after the broadcast of d_bcast: solve the local rows of panel kpanel (16-row slices while the rank holds at
+ * most 24 row tiles, 128-row tiles above); a receiver's d_W gets the panel's inverted blocks from d_bcast by the same grid */
 int tgp_dd_trsm(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, int64_t Np, int kpanel, int G, int g,
                 double *d_W, const double *d_bcast);
 /* every rank, after the all-gather of the panel ([rank][cmax][256][256]): update the local block rows,
