@@ -123,6 +123,20 @@ def measured_traffic(n, kernel_key):
     return der.get(kernel_key), "%s (csrc digest %s)" % (name, der["csrc_digest"])
 
 
+def measured_pipe():
+    """MFMA-pipe occupancy and effective clock of the dominant kernel from the newest profiles/r*_pmc_sq.json (tools/pmc_sq.sh:
+    SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE passes on the shipped sources); None when collected on other sources."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.json")))
+    if not files:
+        return None
+    rec = json.load(open(files[-1]))
+    if rec.get("csrc_digest") != _csrc_digest():
+        return None
+    return {"mfma_busy_frac": rec.get("mfma_busy_frac"), "effective_clock_ghz_profiled": rec.get("effective_clock_ghz"),
+            "wave_cycles_split": rec.get("wave_cycles_split"), "source": os.path.relpath(files[-1], ROOT)}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a child
     torch.distributed.run (fresh processes; this parent has not touched the GPU and never will), pass their single
@@ -539,6 +553,10 @@ def main():
                                "kernel": ("syrk_segs_kernel<4>" if n >= 22528 else "syrk_dtv_kernel<4, 2>") if not use_dist else "syrk_distn_kernel (rank 0)",
                                "launches": int(acc["syrk_launches"]),
                                "avg_launch_ms": acc["syrk_ms"] / launches}
+            if not use_dist and n >= 22528:
+                # `frac` is against the 2.4 GHz peak; the chip runs this kernel at ~2.3 GHz (DVFS) with the MFMA pipe
+                # busy `mfma_busy_frac` of the cycles -- frac ~ busy x clock / 2.4 (PMC passes, profiles/r*_pmc_sq.json)
+                out["roofline"]["pipe"] = measured_pipe()
         if "chol_ms" in acc:
             out["cholesky_tflops_fp64"] = (n ** 3 / 3.0) * K / (acc["chol_ms"] * 1e-3) / 1e12
             out["gp_solves_per_sec"] = K / ((acc["kbuild_ms"] + acc["chol_ms"] + acc["trsv_ms"]) * 1e-3)

@@ -374,6 +374,7 @@ def test_bench_line_schema_single_gpu():
     rf = out["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert 0.3 < rf["frac"] < 1.0 and "traffic" in rf and "traffic_source" in rf
+    assert "pipe" in rf and (rf["pipe"] is None or 0.5 < rf["pipe"]["mfma_busy_frac"] <= 1.0)      # PMC-derived, None on other sources
     for sub in ("roofline_kbuild", "roofline_trsv"):
         assert out[sub]["bound"] == "hbm" and out[sub]["unit"] == "GB/s" and 0 < out[sub]["frac"] < 1
     cb = out["cpu_baseline"]

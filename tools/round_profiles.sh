@@ -25,3 +25,6 @@ echo "rocprof done"
 cd $R && bash tools/pmc_bench.sh > $O/${TAG}_pmc.log 2>&1
 cp $O/pmc_bench_n65536.json $O/${TAG}_pmc_bench_n65536.json
 echo "pmc done"
+bash tools/pmc_sq.sh > $O/${TAG}_pmc_sq.txt 2>&1
+cp $O/pmc_sq.json $O/${TAG}_pmc_sq.json
+echo "pmc sq done"

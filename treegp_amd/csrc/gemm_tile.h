@@ -230,7 +230,11 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
 // staging stores alone cost 7 % (63.0 -> 67.7 TF with them removed); here they are 1/2 (NW = 4) or 1/4
 // (NW = 8, 256 x 128 per workgroup) of that per flop.
 // k assignment: lane (r, kq) handles k = 8h + 2kq + {0, 1} in MFMA steps 2h, 2h+1, so both the direct A
-// loads and the B fragment reads are 16-byte accesses (B rows padded to 18 doubles: conflict-free b128).
+// loads and the B fragment reads are 16-byte accesses.  B rows are padded to 18 doubles: that leaves every ds_read_b128
+// 2-way conflicted under gfx950's lane groups ({0-3, 12-15, 20-27}, ...: SQ_LDS_BANK_CONFLICT = 0.40 of SQ_LDS_IDX_ACTIVE,
+// profiles/r04_pmc_sq.txt); a stride of 20 is conflict-free and was measured -- no difference (1293-1296 ms of trailing update
+// per N = 65 536 solve either way, profiles/r04_lds_stride_ab.txt): the LDS array is 14 % busy and the MFMA pipe 92.6 %, the
+// waves wait for the pipe, not for B.  18 stays: 4 KB less LDS per workgroup.
 // NSEG = 0: run-time number of operand pairs, pair s at a_ptr + s * seg_stride_a / b_ptr + s * seg_stride_b.
 // B staging buffers of the DTV tiles: ONE array per kernel whatever mix of tile variants it instantiates (a __shared__
 // array inside a template is one per instantiation: two of them would push a trailing-update workgroup from 37 to 74 KB and
@@ -246,7 +250,7 @@ __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double 
                                               const double *a1_ptr, const double *b1_ptr, int nseg_rt = 1,
                                               int64_t seg_stride_a = 0, int64_t seg_stride_b = 0) {
     constexpr int LD = TGP_PW;
-    constexpr int LSB = 18;
+    constexpr int LSB = DTV_LSB;
     constexpr int BPT = 16 / NW;                    // B staging pieces (16 B) per thread and chunk
     constexpr int BROWS = 8 * NW;                   // rows covered by one staging pass
     double (*ldsB)[128 * LSB] = reinterpret_cast<double (*)[128 * LSB]>(dtv_lds_storage());
@@ -427,7 +431,7 @@ template <int NW, int KDEPTH, int NSEG, int MT = 2>
 __device__ __forceinline__ void gemm_tile_dtv_segs(const SegPtrs<NSEG> &sp, double *c_ptr) {
     static_assert(NSEG >= 1, "compile-time segment list");
     constexpr int LD = TGP_PW;
-    constexpr int LSB = 18;
+    constexpr int LSB = DTV_LSB;
     constexpr int BPT = 16 / NW;
     constexpr int BROWS = 8 * NW;
     double (*ldsB)[128 * LSB] = reinterpret_cast<double (*)[128 * LSB]>(dtv_lds_storage());
