@@ -38,6 +38,7 @@ SIGNATURES = {
     "tgp_kernel_matrix": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _i64, _vp]),
     "tgp_gp_solve": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp, _vp, _dp, _dp, C.POINTER(_vp)]),
     "tgp_factor_free": (None, [_vp, _vp]),
+    "tgp_factor_release": (None, [_vp, _vp]),
     "tgp_factor_borrow": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(_vp)]),
     "tgp_gp_predict": (C.c_int, [_vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _vp, _i64, _vp]),
     "tgp_gp_predict_cov": (C.c_int, [_vp, _vp, C.POINTER(TgpKernel), _vp, _i64, _vp, _i64, _vp]),

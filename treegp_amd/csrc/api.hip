@@ -25,6 +25,7 @@ Staging g_dummy;
 // per-ctx staging lives in a side table keyed by ctx (keeps tgp_ctx POD-ish)
 struct tgp_ctx_ext {
     Staging io;
+    Staging hio;                 // pinned host mirror of the front of `io` (same offsets), see h2d / d2h_sync
     double *A_cache = nullptr;   // packed lower panels, reused across solves of the same size
     double *W_cache = nullptr;
     int64_t cache_Np = 0;
@@ -89,6 +90,45 @@ static int ensure_factor_cache(tgp_ctx *ctx, int64_t Np) {
     TGP_HIP(hipMalloc((void **)&e->W_cache, (size_t)Np * TGP_TB * sizeof(double)));
     e->cache_Np = Np;
     return 0;
+}
+
+// Host-boundary copies of the hot calls (tgp_gp_solve, tgp_gp_predict) go through a pinned mirror of the device staging arena.
+// A pageable source or destination makes the runtime pin the caller's pages on the fly and unpin them later, asynchronously:
+// at the headline size that work (4 MB of query points in, 2 MB of predictions out) was still going on when the NEXT call
+// arrived -- 10 - 28 ms during which the device counts as busy (hipDeviceSynchronize on entry took that long) and which showed
+// up as "host tax" of every API pass but the first (bench.py api_route; found with TGP_HOST_PHASES=1).  The mirror is capped
+// at 256 MB; larger transfers (dense kernel matrices) take the direct path.
+static int ensure_hio(tgp_ctx *ctx, size_t bytes) {
+    constexpr size_t cap = (size_t)256 << 20;
+    Staging &s = ext_of(ctx)->hio;
+    if (bytes > cap) bytes = cap;
+    if (bytes <= s.bytes) return 0;
+    if (s.buf) TGP_HIP(hipHostFree(s.buf));
+    s.buf = nullptr;
+    s.bytes = 0;
+    TGP_HIP(hipHostMalloc(&s.buf, bytes, hipHostMallocDefault));
+    s.bytes = bytes;
+    return 0;
+}
+static void *hio_mirror(tgp_ctx *ctx, const void *d_ptr, size_t bytes) {
+    tgp_ctx_ext *e = ext_of(ctx);
+    const size_t off = (size_t)((const char *)d_ptr - (const char *)e->io.buf);
+    return (e->hio.buf && (const char *)d_ptr >= (const char *)e->io.buf && off + bytes <= e->hio.bytes) ? (char *)e->hio.buf + off : nullptr;
+}
+static hipError_t h2d(tgp_ctx *ctx, void *d_dst, const void *src, size_t bytes) {
+    if (void *m = hio_mirror(ctx, d_dst, bytes)) {
+        memcpy(m, src, bytes);
+        src = m;
+    }
+    return hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+}
+// device -> caller's array, then the stream is synchronised (the mirror is free again for the next call)
+static hipError_t d2h_sync(tgp_ctx *ctx, void *dst, const void *d_src, size_t bytes) {
+    void *m = hio_mirror(ctx, d_src, bytes);
+    hipError_t e = hipMemcpyAsync(m ? m : dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && m) memcpy(dst, m, bytes);
+    return e;
 }
 
 int tgp_ensure_io(tgp_ctx *ctx, size_t bytes) { return ensure_io(ctx, bytes); }
@@ -162,6 +202,7 @@ void tgp_destroy(tgp_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     tgp_ctx_ext *e = ext_of(ctx);
     if (e->io.buf) (void)hipFree(e->io.buf);
+    if (e->hio.buf) (void)hipHostFree(e->hio.buf);
     if (e->A_cache) (void)hipFree(e->A_cache);
     if (e->W_cache) (void)hipFree(e->W_cache);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -537,6 +578,8 @@ int tgp_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n, 
     hipStream_t st = ctx->stream;
     int rc = ensure_io(ctx, rup(2 * n * 8) + 3 * rup(n * 8));
     if (rc) return rc;
+    rc = ensure_hio(ctx, rup(2 * n * 8) + 3 * rup(n * 8));
+    if (rc) return rc;
     Arena ar{(char *)ext_of(ctx)->io.buf};
     double *d_X = ar.take<double>(2 * n), *d_y = ar.take<double>(n), *d_e = ar.take<double>(n),
            *d_a = ar.take<double>(n);
@@ -546,20 +589,31 @@ int tgp_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n, 
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
     const auto t0 = now();
-    TGP_HIP(hipMemcpyAsync(d_X, X, 2 * n * 8, hipMemcpyHostToDevice, st));
-    TGP_HIP(hipMemcpyAsync(d_y, y, n * 8, hipMemcpyHostToDevice, st));
-    if (yerr) TGP_HIP(hipMemcpyAsync(d_e, yerr, n * 8, hipMemcpyHostToDevice, st));
+    hipEvent_t evA = nullptr;
+    if (dbg) {
+        const auto p0 = now();
+        TGP_HIP(hipStreamSynchronize(st));
+        const auto p1 = now();
+        TGP_HIP(hipDeviceSynchronize());
+        fprintf(stderr, "[tgp_gp_solve] on entry: stream had %.2f ms of work left, the device %.2f ms more\n", ms(p0, p1), ms(p1, now()));
+        TGP_HIP(hipEventCreate(&evA));
+        TGP_HIP(hipEventRecord(evA, st));
+    }
+    TGP_HIP(h2d(ctx, d_X, X, 2 * n * 8));
+    TGP_HIP(h2d(ctx, d_y, y, n * 8));
+    if (yerr) TGP_HIP(h2d(ctx, d_e, yerr, n * 8));
     const auto t1 = now();
     rc = tgp_d_gp_solve(ctx, k, d_X, n, d_y, yerr ? d_e : nullptr, alpha ? d_a : nullptr, logdet, ydota, keep);
     if (rc) return rc;
     const auto t2 = now();
-    if (alpha) {
-        TGP_HIP(hipMemcpyAsync(alpha, d_a, n * 8, hipMemcpyDeviceToHost, st));
-        TGP_HIP(hipStreamSynchronize(st));
+    if (alpha) TGP_HIP(d2h_sync(ctx, alpha, d_a, n * 8));
+    if (dbg) {
+        float lead = 0.f;      // on the device: from the stream reaching this call to the K build's start (the copies in between)
+        (void)hipEventElapsedTime(&lead, evA, ctx->ev[0]);
+        (void)hipEventDestroy(evA);
+        fprintf(stderr, "[tgp_gp_solve n=%ld] H2D %.2f ms on the host / %.2f ms on the stream, tgp_d_gp_solve %.2f ms (device phases %.2f), D2H %.2f ms\n",
+                (long)n, ms(t0, t1), lead, ms(t1, t2), ctx->timings[0] + ctx->timings[1] + ctx->timings[2], ms(t2, now()));
     }
-    if (dbg)
-        fprintf(stderr, "[tgp_gp_solve n=%ld] H2D %.2f ms, tgp_d_gp_solve %.2f ms (device phases %.2f), D2H %.2f ms\n", (long)n, ms(t0, t1),
-                ms(t1, t2), ctx->timings[0] + ctx->timings[1] + ctx->timings[2], ms(t2, now()));
     return 0;
 }
 
@@ -574,6 +628,18 @@ void tgp_factor_free(tgp_ctx *ctx, tgp_factor *f) {
     if (f->d_slabs) (void)hipFree(f->d_slabs);
     if (f->d_slabs2) (void)hipFree(f->d_slabs2);
     delete f;
+}
+
+// The handle is given up but its device memory stays with the context as the factor cache of the next solve of this size
+// (what tgp_d_gp_solve allocates otherwise): a GPInterpolation that is dropped and followed by another of the same size --
+// a refit, the next exposure -- then costs no hipFree + hipMalloc of the packed matrix (17 GB at N = 65 536: ~20 ms of the
+// following solve went to it, bench.py api_route before round 4's end).  Memory held this way is freed by tgp_destroy, by a
+// solve of another size, or by tgp_factor_free on a handle.  A borrowed handle is simply released.
+void tgp_factor_release(tgp_ctx *ctx, tgp_factor *f) {
+    if (!f) return;
+    if (!ctx) { tgp_factor_free(ctx, f); return; }
+    (void)hipSetDevice(ctx->device);
+    tgp_factor_release_to_cache(ctx, f);
 }
 
 // A handle on a factor that lives in the CALLER's device memory (packed panels d_A + inverted diagonal blocks d_W, as
@@ -613,18 +679,20 @@ int tgp_gp_predict(tgp_ctx *ctx, const tgp_kernel *k, const double *X, int64_t n
     TGP_ARG(k && X && alpha && Xs && ys && n > 0 && m > 0);
     TGP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    int rc = ensure_io(ctx, rup(2 * n * 8) + rup(n * 8) + rup(2 * m * 8) + rup(m * 8));
+    const size_t io_bytes = rup(2 * n * 8) + rup(n * 8) + rup(2 * m * 8) + rup(m * 8);
+    int rc = ensure_io(ctx, io_bytes);
+    if (rc) return rc;
+    rc = ensure_hio(ctx, io_bytes);
     if (rc) return rc;
     Arena ar{(char *)ext_of(ctx)->io.buf};
     double *d_X = ar.take<double>(2 * n), *d_a = ar.take<double>(n), *d_Xs = ar.take<double>(2 * m),
            *d_ys = ar.take<double>(m);
-    TGP_HIP(hipMemcpyAsync(d_X, X, 2 * n * 8, hipMemcpyHostToDevice, st));
-    TGP_HIP(hipMemcpyAsync(d_a, alpha, n * 8, hipMemcpyHostToDevice, st));
-    TGP_HIP(hipMemcpyAsync(d_Xs, Xs, 2 * m * 8, hipMemcpyHostToDevice, st));
+    TGP_HIP(h2d(ctx, d_X, X, 2 * n * 8));
+    TGP_HIP(h2d(ctx, d_a, alpha, n * 8));
+    TGP_HIP(h2d(ctx, d_Xs, Xs, 2 * m * 8));
     rc = tgp_d_gp_predict(ctx, k, d_X, n, d_a, d_Xs, m, d_ys);
     if (rc) return rc;
-    TGP_HIP(hipMemcpyAsync(ys, d_ys, m * 8, hipMemcpyDeviceToHost, st));
-    TGP_HIP(hipStreamSynchronize(st));
+    TGP_HIP(d2h_sync(ctx, ys, d_ys, m * 8));
     return 0;
 }
 

@@ -34,9 +34,16 @@ class Factor(object):
         self._ctx, self._h, self.n = ctx, handle, n
         self._keepalive = keepalive          # a borrowed handle (tgp_factor_borrow): the tensors that own its memory
 
-    def free(self):
+    def free(self, keep_memory=True):
+        """keep_memory: the packed matrix stays with the context as the cache of its next solve of this size (tgp_factor_release)
+        -- dropping one GPInterpolation and fitting the next then costs no 17 GB hipFree + hipMalloc at N = 65 536;
+        False returns it to the device at once (tgp_factor_free; TGP_FACTOR_FREE=1 makes that the default)"""
         if self._h:
-            _lib.load_library().tgp_factor_free(self._ctx, self._h)     # (synchronises the context's stream first)
+            lib = _lib.load_library()
+            if keep_memory and os.environ.get("TGP_FACTOR_FREE") != "1":
+                lib.tgp_factor_release(self._ctx, self._h)
+            else:
+                lib.tgp_factor_free(self._ctx, self._h)                 # (synchronises the context's stream first)
             self._h = None
         self._keepalive = None
 
