@@ -26,6 +26,7 @@ Staging g_dummy;
 struct tgp_ctx_ext {
     Staging io;
     Staging hio;                 // pinned host mirror of the front of `io` (same offsets), see h2d / d2h_sync
+    Staging hpin;                // pinned host scratch (tgp_ensure_pinned)
     double *A_cache = nullptr;   // packed lower panels, reused across solves of the same size
     double *W_cache = nullptr;
     int64_t cache_Np = 0;
@@ -108,6 +109,18 @@ static int ensure_hio(tgp_ctx *ctx, size_t bytes) {
     s.bytes = 0;
     TGP_HIP(hipHostMalloc(&s.buf, bytes, hipHostMallocDefault));
     s.bytes = bytes;
+    return 0;
+}
+int tgp_ensure_pinned(tgp_ctx *ctx, size_t bytes, void **out) {
+    Staging &s = ext_of(ctx)->hpin;
+    if (bytes > s.bytes) {
+        if (s.buf) TGP_HIP(hipHostFree(s.buf));
+        s.buf = nullptr;
+        s.bytes = 0;
+        TGP_HIP(hipHostMalloc(&s.buf, bytes, hipHostMallocDefault));
+        s.bytes = bytes;
+    }
+    *out = s.buf;
     return 0;
 }
 static void *hio_mirror(tgp_ctx *ctx, const void *d_ptr, size_t bytes) {
@@ -203,6 +216,7 @@ void tgp_destroy(tgp_ctx *ctx) {
     tgp_ctx_ext *e = ext_of(ctx);
     if (e->io.buf) (void)hipFree(e->io.buf);
     if (e->hio.buf) (void)hipHostFree(e->hio.buf);
+    if (e->hpin.buf) (void)hipHostFree(e->hpin.buf);
     if (e->A_cache) (void)hipFree(e->A_cache);
     if (e->W_cache) (void)hipFree(e->W_cache);
     if (ctx->scratch) (void)hipFree(ctx->scratch);

@@ -181,6 +181,9 @@ __host__ __device__ inline void tilemap(int64_t b, int64_t T, int &ti, int &tj) 
 int tgp_ensure_side_stream(tgp_ctx *ctx);
 int tgp_ensure_scratch(tgp_ctx *ctx, size_t bytes);
 int tgp_ensure_scratch2(tgp_ctx *ctx, size_t bytes);
+// grow-only PINNED host scratch of the context (api.hip): host-built tables that are uploaded whole are built in it, so that the
+// runtime neither pins the pages of a std::vector for the transfer nor unpins them behind the call
+int tgp_ensure_pinned(tgp_ctx *ctx, size_t bytes, void **out);
 int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, int64_t Np,
                         const double *d_yerr, double *d_A);
 int launch_kernel_dense(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,
