@@ -1012,6 +1012,7 @@ class DistEngine(object):
         self.ctx = self._owned_ctx.handle
         self.streams = RankStreams(device)
         self._solver = None                   # (n, HipLocalOps, DistributedCholesky) of the last problem size
+        self._pin = {}                        # name -> pinned host staging tensor (_h2d / _d2h)
         self._replicate = {}                  # Np -> the collective replicate decision taken for that size (sticky: the same on
                                               # every rank and unaffected by factors handed out since)
         self.acc = {}                         # profile=True: phase times (ms, this rank) summed over calls; reset by the caller
@@ -1045,6 +1046,28 @@ class DistEngine(object):
     def _add(self, name, v):
         self.acc[name] = self.acc.get(name, 0.0) + v
 
+    # Host arrays cross the boundary through persistent PINNED staging tensors: a transfer from / to pageable memory makes the
+    # runtime pin the caller's pages on the fly and unpin them asynchronously, behind the call -- 10 - 28 ms that the NEXT call
+    # then waits for (csrc/api.hip: h2d, the single-GPU side of the same finding)
+    def _pinned(self, key, numel):
+        t = self._pin.get(key)
+        if t is None or t.numel() < numel:
+            t = self.torch.empty(max(int(numel), 1), dtype=self.torch.float64).pin_memory()
+            self._pin[key] = t
+        return t[:numel]
+
+    def _h2d(self, key, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        p = self._pinned(key, a.size)
+        p.copy_(self.torch.from_numpy(a.reshape(-1)))
+        return p.to(self.device, non_blocking=True).view(a.shape)
+
+    def _d2h(self, key, t):
+        p = self._pinned(key, t.numel())
+        p.copy_(t.reshape(-1), non_blocking=True)
+        self.torch.cuda.current_stream(self.device).synchronize()
+        return p.numpy().copy()
+
     # -- seams S2 / S3 (include/tgp.h) on G GPUs --------------------------------------------------------------------
     def gp_solve(self, spec, X, y, y_err=None, keep=False, want_alpha=True):
         """(alpha, logdet, y.alpha, factor|None) like ``ops.gp_solve``, every rank returning the same values.  ``keep``
@@ -1056,11 +1079,11 @@ class DistEngine(object):
         n = X2.shape[0]
         y = f64(y)
         o, chol = self._solver_for(spec, n)
-        dX = o.to_device(X2)
-        de = o.to_device(np.zeros(n) if y_err is None else f64(y_err))
+        dX = self._h2d("X", X2)
+        de = self._h2d("yerr", np.zeros(n) if y_err is None else f64(y_err))
         ypad = np.zeros(o.Np)
         ypad[:n] = y
-        dy = o.to_device(ypad)
+        dy = self._h2d("y", ypad)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.profile else None
         if ev: ev[0].record()
         o.kbuild(dX, de)
@@ -1072,7 +1095,7 @@ class DistEngine(object):
         alpha = chol.solve(dy)
         logdet = chol.logdet()
         if ev: ev[3].record()
-        a = alpha.cpu().numpy()[:n].copy()                   # synchronises
+        a = self._d2h("alpha", alpha)[:n].copy()             # synchronises
         logdet = float(logdet[0])
         if ev:
             for name, i, j in (("kbuild_ms", 0, 1), ("chol_ms", 1, 2), ("trsv_ms", 2, 3)):
@@ -1111,9 +1134,9 @@ class DistEngine(object):
         lo, hi = min(g * per, m), min((g + 1) * per, m)
         mine = torch.zeros(max(per, 1), dtype=torch.float64, device=self.device)
         if hi > lo:
-            dX = torch.from_numpy(X2).to(self.device)
-            da = torch.from_numpy(f64(alpha)).to(self.device)
-            dXs = torch.from_numpy(np.ascontiguousarray(Xs2[lo:hi])).to(self.device)
+            dX = self._h2d("X", X2)
+            da = self._h2d("alpha_in", f64(alpha))
+            dXs = self._h2d("Xs", Xs2[lo:hi])
             kc = spec.to_c()
             rc = self.lib.tgp_d_gp_predict(self.ctx, C.byref(kc), C.c_void_p(dX.data_ptr()), n, C.c_void_p(da.data_ptr()),
                                            C.c_void_p(dXs.data_ptr()), hi - lo, C.c_void_p(mine.data_ptr()))
@@ -1122,10 +1145,10 @@ class DistEngine(object):
                 self._add("predict_ms", self._lib.timings(self.ctx)[3])
                 self._add("predict_points", hi - lo)
         if G == 1:
-            return mine[:m].cpu().numpy()
+            return self._d2h("ys", mine[:m])
         buf = torch.empty(per * G, dtype=torch.float64, device=self.device)
         self.comm.all_gather(buf, mine)
-        return buf[:m].cpu().numpy()
+        return self._d2h("ys", buf[:m])
 
 
 def enable(comm=None, device=None, min_n=None, profile=False, thread_local=False):
