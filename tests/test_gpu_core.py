@@ -241,3 +241,21 @@ def test_alpha_from_the_augmented_row_matches_both_sweeps(tg, n):
         a_ref, ld_ref = O.gp_solve(O.kernel_matrix("gauss", X, amp=1.4, a=90.0, b=12.0, c=70.0), y, e)
         np.testing.assert_allclose(alpha, a_ref, rtol=0, atol=1e-10 * np.abs(a_ref).max())
         np.testing.assert_allclose(logdet, ld_ref, rtol=1e-11)
+
+
+def test_predict_larger_than_the_pinned_mirror(tg):
+    """tgp_gp_predict copies through a pinned mirror of its staging arena (csrc/api.hip: h2d / d2h_sync), capped at 256 MB;
+    a query set whose arena is larger takes the direct path for what lies beyond the mirror -- same values either way."""
+    _lib, ops, ctx = tg
+    rng = np.random.default_rng(5)
+    n, m = 300, 15_000_000                     # arena: 2 n + n + 2 m + m doubles = 360 MB
+    X, y, yerr = _field(rng, n)
+    invL = _inv()
+    spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.1, a=invL[0, 0], b=invL[0, 1], c=invL[1, 1])
+    alpha, _, _, _ = ops.gp_solve(spec, X, y, yerr)
+    Xs = rng.uniform(0, 1, (m, 2))
+    yp = ops.gp_predict(spec, X, alpha, Xs)
+    assert yp.shape == (m,) and np.isfinite(yp).all()
+    for lo in (0, m // 2 - 500, m - 1000):     # pieces small enough to go through the mirror entirely
+        ref = ops.gp_predict(spec, X, alpha, Xs[lo:lo + 1000])
+        np.testing.assert_array_equal(yp[lo:lo + 1000], ref)
