@@ -258,4 +258,4 @@ def test_predict_larger_than_the_pinned_mirror(tg):
     assert yp.shape == (m,) and np.isfinite(yp).all()
     for lo in (0, m // 2 - 500, m - 1000):     # pieces small enough to go through the mirror entirely
         ref = ops.gp_predict(spec, X, alpha, Xs[lo:lo + 1000])
-        np.testing.assert_array_equal(yp[lo:lo + 1000], ref)
+        np.testing.assert_allclose(yp[lo:lo + 1000], ref, rtol=0, atol=1e-12 * np.abs(ref).max())   # (the split of the sum over the training points follows m)
