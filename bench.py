@@ -27,6 +27,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # A rank of a multi-GPU run keeps five streams busy (bulk, panel chain, keep copies, RCCL's, torch's default) and parks
+    # stream wait-values on one of them; the runtime multiplexes streams onto 4 hardware queues by default, and two streams
+    # that share a queue run in order (round 4 saw the bulk and the chain share one: chain 75 -> 93 ms).  Eight queues cost
+    # nothing measurable on one GPU (profiles/r04_hw_queues_ab.txt); must be set before the HIP runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix peak
 
 
