@@ -758,9 +758,10 @@ class DistributedCholesky(object):
         # tiles -- so from the group boundary k_fin on the ranks exchange their shares of the trailing matrix in ONE
         # all-gather and every rank factors it with the single-GPU schedule (HipLocalOps.tail_finish): the same volume over
         # the links, one collective instead of two per panel, ~6 ms of arithmetic at 8192 rows where the chain needs ~10.
-        # Default: 16 blocks (4096 rows), never more than a quarter of the matrix.  Without communication the finish is neutral
-        # at 16 blocks and costs 2 ms at 32 (profiles/r04_rank_slice.txt); every panel it takes off the chain is a broadcast
-        # and an all-gather less on a real node, so the first hardware run should sweep it.
+        # Default: 16 blocks (4096 rows), never more than a quarter of the matrix.  Without communication, and with the chain's
+        # latency kernels of the round's end, the finish COSTS 1.6 ms at 16 blocks and 3.9 ms at 32 (rank 7 of 8 at
+        # N = 65 536: 184.1 ms without, 185.1 / 185.7 / 188.0 with 8 / 16 / 32; profiles/r04_rank_slice.txt); every panel it
+        # takes off the chain is a broadcast and an all-gather less on a real node, so the first hardware run should sweep it.
         fin = min(int(os.environ.get("TGP_DIST_FINISH", min(16, nB // 4))), FINISH_BLOCKS_MAX)
         k_fin = None
         if fin >= GS and hasattr(ops, "tail_finish") and nB > 1:
