@@ -259,3 +259,33 @@ def test_predict_larger_than_the_pinned_mirror(tg):
     for lo in (0, m // 2 - 500, m - 1000):     # pieces small enough to go through the mirror entirely
         ref = ops.gp_predict(spec, X, alpha, Xs[lo:lo + 1000])
         np.testing.assert_allclose(yp[lo:lo + 1000], ref, rtol=0, atol=1e-12 * np.abs(ref).max())   # (the split of the sum over the training points follows m)
+
+
+def test_released_factor_memory_is_reused():
+    """A kept factor that is dropped hands its packed matrix back to the context (tgp_factor_release): the next solve of
+    the same size allocates nothing; Factor.free(keep_memory=False) returns the memory to the device."""
+    from treegp_amd import _lib, ops
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    ctx = _lib.new_ctx(0)
+    try:
+        rng = np.random.default_rng(11)
+        n = 6000                                   # packed factor ~ 150 MB: far above the allocator's granularity
+        X, y, yerr = _field(rng, n)
+        invL = _inv()
+        spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=invL[0, 0], b=invL[0, 1], c=invL[1, 1])
+        a1, _, _, fac = ops.gp_solve(spec, X, y, yerr, keep=True, ctx=ctx)
+        with_one = free_bytes()
+        fac.free()                                 # -> the context's cache
+        a2, _, _, fac2 = ops.gp_solve(spec, X, y, yerr, keep=True, ctx=ctx)
+        assert abs(free_bytes() - with_one) < (8 << 20)          # the second factor lives where the first did
+        np.testing.assert_array_equal(a1, a2)
+        fac2.free(keep_memory=False)               # -> the device
+        assert free_bytes() > with_one + (100 << 20)
+    finally:
+        _lib.load_library().tgp_destroy(ctx)
