@@ -193,6 +193,7 @@ int tgp_init(const int *devices, int ndev, tgp_ctx **out) {
     if (hipMalloc((void **)&ctx->d_info, 256) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_queue, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned)) != hipSuccess) { delete ctx; return -2; }
     if (hipMemset(ctx->d_info, 0, 256) != hipSuccess) { delete ctx; return -2; }
+    if (hipMalloc((void **)&ctx->d_psync, TGP_PSYNC_PANELS * 16 * sizeof(unsigned)) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_flags, 16 * 64) != hipSuccess || hipMemset(ctx->d_flags, 0, 16 * 64) != hipSuccess) { delete ctx; return -2; }
     if (const char *e = getenv("TGP_FLAG_SEQ_START")) {      // test hook: start the hand-off sequence numbers near their wrap-around
         const unsigned v0 = (unsigned)strtoul(e, nullptr, 10);
@@ -225,6 +226,7 @@ void tgp_destroy(tgp_ctx *ctx) {
     if (ctx->vslab_tt) (void)hipFree(ctx->vslab_tt);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx->d_psync) (void)hipFree(ctx->d_psync);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->h_info) (void)hipHostFree(ctx->h_info);
     if (ctx->d_scal) (void)hipFree(ctx->d_scal);
@@ -443,6 +445,7 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
         fprintf(stderr, "[factor_and_solve] launch_potrf returned after %.2f ms, solves queued after %.2f ms, final sync %.2f ms\n", d(h0, h1), d(h1, h2), d(h2, h3));
     }
     if (info == 0) info = *ctx->h_info;               // the factorisation's verdict (first failing pivot, 1-based)
+    if (info < 0) return fail(tgp_potrf_info_rc(ctx, info));
     float ms = 0.f;
     TGP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->timings[0] = ms;

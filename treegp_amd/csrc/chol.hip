@@ -104,6 +104,100 @@ __global__ __launch_bounds__(256, 2) void diag_mid_kernel(double *R1, const doub
     gemm_tile_128<1, TGP_PW, TGP_TB>(R1, R1, R1 + TGP_TB);
 }
 
+// ---- the step between the two diagonal blocks of a panel as ONE launch with in-kernel hand-offs -------------------------------
+// Between potrf128(0,0) and potrf128(1,1) the chain used to run two launches over ALL rows below (X0 = A0 W0^T, then
+// A1 -= X0 L10^T), 24 + 25 us at N = 8192, although the second diagonal block needs only its own 128 rows of them.  Here the
+// workgroups of one launch are, in dispatch order (every wait is on workgroups with LOWER indices, which the dispatcher has
+// started before: progress never depends on how many workgroups are resident):
+//   0 ..  7   A1: sixteen-row slices of rows 128..255:  L10 = A10 W0^T                     -> count sync[0]
+//   8 .. 15   A2: the same slices, after sync[0] == 8:  A11 -= L10 L10^T                   -> count sync[1]
+//   16        after sync[1] == 8: potrf128 of block (1,1): L11 in place, W1 = L11^-1
+//   17 ..     the rows below the 256 x 256 block (128-row tiles, or 16-row slices where SMALLROWS): X0 = A0 W0^T, then -- after
+//             sync[0] == 8 -- A1 -= X0 L10^T, both under the diagonal block's 33 us
+// The third product of the rows (X1 = A1 W1^T) stays a launch of its own behind this one: folded in, its workgroups would
+// hold their compute units spinning for W1.  Hand-off: the producer's waves wait for their stores (vmcnt(0)), barrier, one
+// release fence at agent scope (writes the XCD's L2 back), one relaxed atomic increment; the consumer's thread 0 polls with
+// relaxed agent-scope loads, then one acquire fence (invalidates the XCD's L2 and the CU's L1), barrier.
+// EVERY SPIN IS BOUNDED: after PANEL_SPIN_TICKS of the 100 MHz clock (2 s) the waiter raises sync[2], which ends every other
+// wait of the launch at once, and reports info = -7; launch_potrf turns that into rc < 0.
+constexpr unsigned long long PANEL_SPIN_TICKS = 200000000ull;
+constexpr int PANEL_SYNC_WORDS = 16;           // 64 B per panel: [0] A1 slices done, [1] A2 slices done, [2] abort
+__device__ __forceinline__ void panel_publish(unsigned *counter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ bool panel_wait(unsigned *sync, int which, unsigned target, int *info) {
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned it = 0;
+        while (__hip_atomic_load(sync + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++it & 63u) == 0u) {
+                const bool late = __builtin_amdgcn_s_memrealtime() - t0 > PANEL_SPIN_TICKS;
+                if (late || __hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (late) __hip_atomic_store(info, -7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_ok = ok;
+    }
+    __syncthreads();
+    const bool ok = s_ok != 0;
+    __syncthreads();                             // s_ok is read by everyone before a second wait overwrites it
+    return ok;
+}
+template <bool SMALLROWS>
+__global__ __launch_bounds__(256) void panel_mid_kernel(double *Pk, const double *W0, double *W1, int *info, int base, unsigned *sync) {
+    // one LDS image for every role: potrf128's 96 KB; the 128-row GEMM tile stages its operands in the first 70 KB of it
+    __shared__ __attribute__((aligned(16))) double T[potrf_v2::POTRF_LDS_DOUBLES];
+    static_assert(potrf_v2::POTRF_LDS_DOUBLES >= 2 * 2 * 128 * TileDefault::LS, "the GEMM tile's staging fits in potrf128's image");
+    TGP_CHAIN_PRIO();
+    const int b = blockIdx.x;
+    double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
+    if (b < 8) {
+        double *rows = R1 + (int64_t)b * 16 * TGP_PW;
+        nt_small_tile<0, TGP_TB, 1>(rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
+        panel_publish(sync + 0);
+        return;
+    }
+    if (b < 16) {
+        if (!panel_wait(sync, 0, 8u, info)) return;
+        double *rows = R1 + (int64_t)(b - 8) * 16 * TGP_PW;
+        nt_small_tile<1, TGP_TB, 1>(rows, TGP_PW, R1, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
+        panel_publish(sync + 1);
+        return;
+    }
+    if (b == 16) {
+        if (!panel_wait(sync, 1, 8u, info)) return;
+        potrf_v2::potrf128_body<true>(T, R1 + TGP_TB, TGP_PW, W1, info, base + TGP_TB);
+        return;
+    }
+    if constexpr (SMALLROWS) {
+        double *rows = Pk + (int64_t)TGP_PW * TGP_PW + (int64_t)(b - 17) * 16 * TGP_PW;
+        nt_small_tile<0, TGP_TB, 1>(rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's X0 is in the L2 before the others read it
+        __syncthreads();
+        if (!panel_wait(sync, 0, 8u, info)) return;
+        nt_small_tile<1, TGP_TB, 1>(rows, TGP_PW, R1, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
+    } else {
+        double *rows = Pk + (int64_t)TGP_PW * TGP_PW + (int64_t)(b - 17) * 128 * TGP_PW;
+        gemm_tile_128_at<0, TGP_TB, TGP_TB>(T, rows, W0, rows);
+        __syncthreads();
+        if (!panel_wait(sync, 0, 8u, info)) return;
+        gemm_tile_128_at<1, TGP_PW, TGP_TB>(T, rows, R1, rows + TGP_TB);
+    }
+}
+
 template <int NSEG>
 __global__ __launch_bounds__(256) void syrk_small_kernel(double *Abase, int64_t Np, int ob, int T, const double *P0,
                                                          const double *P1) {
@@ -485,8 +579,10 @@ __global__ void set_identity128_kernel(double *__restrict__ W) {
 
 // `n_data` (>= 0): order of the matrix before padding.  When the second 128-block of a panel lies entirely in the padding
 // (possible for the last panel only) it is the identity and its own factor: no potrf128, no update of it, W1 = I.
+// `mid_sync` != nullptr: the step between the two diagonal blocks runs as panel_mid_kernel (one launch, in-kernel hand-offs, the
+// second diagonal block inside it); `cu_budget` = compute units its workgroups can expect to find free (each takes a whole one)
 void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_info, int base, bool exclusive = false,
-                  int64_t n_data = -1) {
+                  int64_t n_data = -1, unsigned *mid_sync = nullptr, int cu_budget = 256) {
     double *W1 = W0 + TGP_TB * TGP_TB;
     double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
     const int r1 = (int)((mk - TGP_TB) / TGP_TB);
@@ -498,15 +594,26 @@ void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_inf
         set_identity128_kernel<<<64, 256, 0, st>>>(W1);
         return;
     }
-    if (r1 <= small_rows) {
-        gemm_col_small_kernel<0, TGP_TB><<<r1 * 8, 256, 0, st>>>(R1, W0, R1);
-        gemm_col_small_kernel<1, TGP_PW><<<r1 * 8, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
-    } else {
-        gemm_col_kernel<0, TGP_TB><<<r1, 256, 0, st>>>(R1, W0, R1);
-        gemm_col_kernel<1, TGP_PW><<<r1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
-    }
-    run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, d_info, base + TGP_TB, exclusive);
     const int r2 = (int)((mk - TGP_PW) / TGP_TB);
+    if (mid_sync) {
+        constexpr unsigned pad = 128 * 1024 - potrf_v2::POTRF_LDS_DOUBLES * 8;      // exclusive: a compute unit per workgroup
+        static const bool pad_ok = [] {
+            return hipFuncSetAttribute((const void *)panel_mid_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad) == hipSuccess &&
+                   hipFuncSetAttribute((const void *)panel_mid_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad) == hipSuccess;
+        }();
+        const unsigned dyn = (exclusive && pad_ok) ? pad : 0u;
+        if (17 + 8 * r2 <= cu_budget) panel_mid_kernel<true><<<17 + 8 * r2, 256, dyn, st>>>(Pk, W0, W1, d_info, base, mid_sync);
+        else panel_mid_kernel<false><<<17 + r2, 256, dyn, st>>>(Pk, W0, W1, d_info, base, mid_sync);
+    } else {
+        if (r1 <= small_rows) {
+            gemm_col_small_kernel<0, TGP_TB><<<r1 * 8, 256, 0, st>>>(R1, W0, R1);
+            gemm_col_small_kernel<1, TGP_PW><<<r1 * 8, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
+        } else {
+            gemm_col_kernel<0, TGP_TB><<<r1, 256, 0, st>>>(R1, W0, R1);
+            gemm_col_kernel<1, TGP_PW><<<r1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
+        }
+        run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, d_info, base + TGP_TB, exclusive);
+    }
     if (r2 > 0) {
         double *R2 = Pk + (int64_t)TGP_PW * TGP_PW + TGP_TB;    // row 256, column 128
         if (r2 <= small_rows) gemm_col_small_kernel<0, TGP_TB><<<r2 * 8, 256, 0, st>>>(R2, W1, R2);
@@ -540,19 +647,19 @@ void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int str
 // How many of them (1 .. 3 per shader engine = 32 .. 96 CUs): as many as leave the bulk -- tiles x ~130 us over the
 // remaining slots -- shorter than the chain (~400 us per pair of panels): with 64 CUs the panel GEMMs run one workgroup
 // per CU (22 instead of 40 us) and the strips in one round.
+int queued_nres(int T) {
+    static const int queue_res = [] { const char *e = getenv("TGP_QUEUE_RES"); return e ? atoi(e) : 0; }();
+    if (queue_res > 0) return queue_res > TGP_QUEUE_MAXRES ? TGP_QUEUE_MAXRES : queue_res;
+    const int64_t tiles = (int64_t)T * (T + 1) / 2;
+    for (int r = 3; r > 1; --r) {
+        const int64_t slots = 512 - 64 * r;
+        if ((tiles + slots - 1) / slots * 130 <= 400) return r;
+    }
+    return 1;
+}
 void launch_syrk2_queued(tgp_ctx *ctx, hipStream_t st, double *d_A, int64_t Np, int ob, int T, const double *P0, const double *P1,
                          int nqueue) {
-    static const int queue_res = [] { const char *e = getenv("TGP_QUEUE_RES"); return e ? atoi(e) : 0; }();
-    int nres = 1;
-    if (queue_res > 0) {
-        nres = queue_res > TGP_QUEUE_MAXRES ? TGP_QUEUE_MAXRES : queue_res;
-    } else {
-        const int64_t tiles = (int64_t)T * (T + 1) / 2;
-        for (int r = 3; r > 1; --r) {
-            const int64_t slots = 512 - 64 * r;
-            if ((tiles + slots - 1) / slots * 130 <= 400) { nres = r; break; }
-        }
-    }
+    const int nres = queued_nres(T);
     syrk_dtv_queue_kernel<2><<<512 + 8, 256, 0, st>>>(d_A, Np, ob, T, (unsigned)(tilemap_grid(T) / 8), nres,
                                                      ctx->d_queue + TGP_QUEUE_WORDS * nqueue, P0, P1);
 }
@@ -621,19 +728,27 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     // (U2b); the next pair is factored on a high-priority side stream while U2b keeps the chip busy.
     static const int queue_t = [] { const char *e = getenv("TGP_QUEUE_T"); return e ? atoi(e) : 64; }();
     int nqueue = 0;
+    // TGP_PANEL_MID=0: the step between a panel's two diagonal blocks as separate launches everywhere (before round 5)
+    static const bool mid_env = [] { const char *e = getenv("TGP_PANEL_MID"); return e ? atoi(e) != 0 : true; }();
+    const bool mid_on = mid_env;
+    if (mid_on) TGP_HIP(hipMemsetAsync(ctx->d_psync, 0, (size_t)(nP < TGP_PSYNC_PANELS ? nP : TGP_PSYNC_PANELS) * PANEL_SYNC_WORDS * sizeof(unsigned), st));
     if (Np / TGP_TB - 8 > small_t())          // some step can take the queued form (T3 = Np/128 - 8 at the first pair)
         TGP_HIP(hipMemsetAsync(ctx->d_queue, 0, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned), st));
+    auto psync = [&](int k) { return (mid_on && k < TGP_PSYNC_PANELS) ? ctx->d_psync + PANEL_SYNC_WORDS * k : nullptr; };
     auto run_pairs = [&](int kstart) -> int {
         hipStream_t sd = ctx->side_stream;
-        auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false) {       // F(k), U1(k), F(k+1)
+        // `cus` > 0: the chain has that many compute units to itself (the whole chip, or the ones a queued bulk update keeps
+        // clear) -- the step between a panel's two diagonal blocks then runs as panel_mid_kernel
+        auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false, int cus = 0) {       // F(k), U1(k), F(k+1)
             const int64_t mk = Np - (int64_t)TGP_PW * k;
-            factor_panel(s, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, exclusive, n_data);
+            auto sync = [&](int kk) { return (cus > 0 && mid_on && kk < TGP_PSYNC_PANELS) ? ctx->d_psync + PANEL_SYNC_WORDS * kk : nullptr; };
+            factor_panel(s, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, exclusive, n_data, sync(k), cus);
             if (k + 1 >= nP) return;
             const int T1 = (int)((mk - TGP_PW) / TGP_TB);
             launch_syrk<1>(s, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
-            factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, exclusive, n_data);
+            factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, exclusive, n_data, sync(k + 1), cus);
         };
-        factor_pair(st, kstart);
+        factor_pair(st, kstart, false, 256);
         for (int k = kstart; k + 2 < nP; k += 2) {
             const int T2 = (int)((Np - (int64_t)TGP_PW * (k + 2)) / TGP_TB);       // tiles from block k+2
             const double *P0 = panel(k) + (int64_t)2 * TGP_PW * TGP_PW;
@@ -650,7 +765,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             }
             TGP_HIP(tgp_signal(ctx, st, 0, ctx->ev[4]));
             TGP_HIP(tgp_await(ctx, sd, 0, ctx->ev[4]));
-            factor_pair(sd, k + 2, queued);
+            factor_pair(sd, k + 2, queued, queued ? 32 * queued_nres(T3) : 0);
             TGP_HIP(tgp_signal(ctx, sd, 1, ctx->ev[5]));
             if (T3 > 0) {   // U2b: everything from block k+4 on
                 const double m = (double)T3 * TGP_TB;
@@ -668,7 +783,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     if (mode == 0) {
         for (int k = 0; k < nP; ++k) {
             const int64_t mk = Np - (int64_t)TGP_PW * k;
-            factor_panel(st, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, false, n_data);
+            factor_panel(st, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, false, n_data, psync(k), 256);
             const int T = (int)((mk - TGP_PW) / TGP_TB);
             if (T > 0) {
                 const double m = (double)T * TGP_TB;
@@ -766,12 +881,12 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     } else {
         for (int k = 0; k < nP; k += 2) {
             const int64_t mk = Np - (int64_t)TGP_PW * k;
-            factor_panel(st, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, false, n_data);
+            factor_panel(st, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, false, n_data, psync(k), 256);
             if (k + 1 >= nP) break;
             const int T1 = (int)((mk - TGP_PW) / TGP_TB);
             // U1: only the two tile columns of panel k+1, depth 256 (short; not part of the timed set)
             launch_syrk<1>(st, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
-            factor_panel(st, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, false, n_data);
+            factor_panel(st, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, false, n_data, psync(k + 1), 256);
             const int T2 = T1 - 2;
             if (T2 > 0) {
                 const double m = (double)T2 * TGP_TB;
@@ -789,7 +904,7 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     ctx->timings[5] = 0.0;
     // `defer_info`: the caller queues more work behind the factorisation and reads *ctx->h_info after its own
     // synchronisation (one host round trip less per solve; the per-launch profile needs the synchronisation here)
-    if (defer_info && !prof) return 0;
+    if (defer_info && !prof) return 0;       // (the caller maps a negative *h_info through tgp_potrf_info_rc)
     TGP_HIP(hipStreamSynchronize(st));
     if (prof) {
         double tot = 0.0;
@@ -800,7 +915,16 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
         }
         ctx->timings[5] = tot;
     }
-    return *ctx->h_info;
+    return tgp_potrf_info_rc(ctx, *ctx->h_info);
+}
+
+// what the device left in `info` -> return code: > 0 first failing pivot (1-based), 0 fine, -7 (an in-kernel hand-off of
+// panel_mid_kernel gave up after its bounded wait) -> -4 with the reason in tgp_last_error
+int tgp_potrf_info_rc(tgp_ctx *ctx, int info) {
+    if (info >= 0) return info;
+    ctx->err = "Cholesky: an in-kernel hand-off timed out (panel_mid_kernel waited 2 s for workgroups of its own launch); "
+               "the factor is incomplete -- TGP_PANEL_MID=0 selects the schedule without in-kernel waits";
+    return -4;
 }
 
 // 256x256 diagonal block (ld 256): L in place, inverses of its two 128-blocks to W0 / W1

@@ -81,15 +81,18 @@ __device__ __forceinline__ double *tile128_lds_storage() {
     return lds;
 }
 
+// gemm_tile_128_at: the tile with its staging buffers at `lds_base` (2 * 2 * 128 * LS doubles) -- for kernels that alias them
+// over another LDS image (chol.hip: panel_mid_kernel, whose diagonal-block workgroup holds potrf128's 96 KB there);
+// gemm_tile_128: the same on the kernel's own static array.
 template <int MODE, int LDB, int KDEPTH, typename CFG = TileDefault, int NSEG = 1>
-__device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double *b_ptr, double *c_ptr,
-                                              const double *a1_ptr = nullptr, const double *b1_ptr = nullptr, int nseg_rt = 1,
-                                              int64_t seg_stride_a = 0, int64_t seg_stride_b = 0) {
+__device__ __forceinline__ void gemm_tile_128_at(double *lds_base, const double *a_ptr, const double *b_ptr, double *c_ptr,
+                                                 const double *a1_ptr = nullptr, const double *b1_ptr = nullptr, int nseg_rt = 1,
+                                                 int64_t seg_stride_a = 0, int64_t seg_stride_b = 0) {
     constexpr int LDA = TGP_PW, LDC = TGP_PW;
     constexpr int LS = CFG::LS;
     constexpr bool PRELOAD = CFG::PRELOAD && MODE == 1;
     // [buf][A|B][row*LS + k]; one array per LS, shared by every MODE / LDB instantiation a kernel calls in sequence
-    double (*lds)[2][128 * LS] = reinterpret_cast<double (*)[2][128 * LS]>(tile128_lds_storage<LS>());
+    double (*lds)[2][128 * LS] = reinterpret_cast<double (*)[2][128 * LS]>(lds_base);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -218,6 +221,14 @@ __device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double 
                     buf_st1((PRELOAD || MODE == 2) ? -acc[m][n][r] : acc[m][n][r], rc_dst, vc, ((m * 16 + 4 * r) * LDC + n * 16) * 8);
         }
     }
+}
+
+template <int MODE, int LDB, int KDEPTH, typename CFG = TileDefault, int NSEG = 1>
+__device__ __forceinline__ void gemm_tile_128(const double *a_ptr, const double *b_ptr, double *c_ptr,
+                                              const double *a1_ptr = nullptr, const double *b1_ptr = nullptr, int nseg_rt = 1,
+                                              int64_t seg_stride_a = 0, int64_t seg_stride_b = 0) {
+    gemm_tile_128_at<MODE, LDB, KDEPTH, CFG, NSEG>(tile128_lds_storage<CFG::LS>(), a_ptr, b_ptr, c_ptr, a1_ptr, b1_ptr, nseg_rt,
+                                                   seg_stride_a, seg_stride_b);
 }
 
 

@@ -311,13 +311,14 @@ __device__ __forceinline__ void phase2_pair(double *T, double *SC, int rt, int c
 // (measured: 268 VGPRs cost 25 ms of exposed panel time at N = 65536).  The initial load is batched in two halves
 // for that reason; tools/check_potrf_regs.sh (run by the build) fails if the budget is exceeded.
 // -DTGP_GJ16_ONE_ROW: A/B build with the sweep on the 16 lanes of one DPP row and taddr() addressing (round 1)
+// The body works on an LDS image T of POTRF_LDS_DOUBLES doubles handed in by the kernel, so that a kernel that also runs GEMM tiles
+// (chol.hip: panel_mid_kernel) can alias their staging over it.
+constexpr int POTRF_LDS_DOUBLES = T_ELEMS + BLK_ELEMS;
 template <bool DIAG16>
-__global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, double *W, int *info, int base) {
-    __shared__ __attribute__((aligned(16))) double T[T_ELEMS + BLK_ELEMS];
+__device__ __forceinline__ void potrf128_body(double *T, double *A, int lda, double *W, int *info, int base) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const d4v zero4 = {0.0, 0.0, 0.0, 0.0};
-    TGP_CHAIN_PRIO();
     POTRF_STAMP(0);
 
     // block-wise copies between global memory and the LDS image: a pass of the 256 threads covers 16 rows x 16 column pairs = half a
@@ -557,5 +558,12 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, doubl
     if (threadIdx.x == 0)      // where it ran: XCC_ID << 8 | HW_ID[15:8]
         tgp_potrf_stamps[((base >> 7) & 1023) * 20 + 17] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 8) | __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));
 #endif
+}
+
+template <bool DIAG16>
+__global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, double *W, int *info, int base) {
+    __shared__ __attribute__((aligned(16))) double T[POTRF_LDS_DOUBLES];
+    TGP_CHAIN_PRIO();
+    potrf128_body<DIAG16>(T, A, lda, W, info, base);
 }
 }  // namespace potrf_v2

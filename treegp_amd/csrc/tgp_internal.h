@@ -21,6 +21,7 @@
 #define TGP_QUEUE_LEAVE (8 + 32 * TGP_QUEUE_MAXRES)      // word offset of the 8 leave counters
 #define TGP_QUEUE_WORDS (TGP_QUEUE_LEAVE + 8)   // per launch: 8 XCD-class tile counters + 8 x 4 x MAXRES clear-CU words + 8 leave counters
 #define TGP_NQUEUE 128        // persistent bulk-update launches per factorisation (one set of 8 counters each)
+#define TGP_PSYNC_PANELS 1024 // panels with a counter set of their own (Np <= 262144); 16 words = 64 B each
 #define TGP_TB 128            // tile / diagonal-block size
 #define TGP_PW 256            // panel width = trailing-update depth
 
@@ -53,6 +54,7 @@ struct tgp_ctx {
     int dist_nqueue = 0;          // queue sets handed out since tgp_dd_queue_reset (multi-GPU driver)
     int chain_exclusive = 0;      // tgp_dd_set_exclusive: diagonal blocks of this context ask for a compute unit of their own
     unsigned *d_queue = nullptr;  // tile-queue counters of the persistent bulk update (TGP_NQUEUE launches x TGP_QUEUE_WORDS)
+    unsigned *d_psync = nullptr;  // in-kernel hand-off counters of panel_mid_kernel (chol.hip): TGP_PSYNC_PANELS x 16 words, zeroed per factorisation
     int *d_info = nullptr;        // first failing pivot (1-based), 0 = ok
     int *h_info = nullptr;        // pinned mirror
     double *d_scal = nullptr;     // small device scalars (logdet, dot, ...)
@@ -189,6 +191,7 @@ int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, in
 int launch_kernel_dense(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,
                         const double *d_Y, int64_t m, int self, double *d_out);
 int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_info = false, int64_t n_data = -1);
+int tgp_potrf_info_rc(tgp_ctx *ctx, int info);      // device `info` word -> return code (negative: in-kernel hand-off timed out)
 // cross-stream hand-offs (handoff.hip).  Flag ids: 0, 1 the look-ahead of launch_potrf; TGP_FLAG_HEAD the "head columns
 // done" signal of a fused multi-GPU bulk launch, TGP_FLAG_HEAD_COUNT the word its workgroups count themselves in on.
 #define TGP_FLAG_HEAD 8
