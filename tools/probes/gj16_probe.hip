@@ -2,6 +2,8 @@
 //   v0  lanes 0..15, one DPP row, 15 DPP FMAs + the pivot row's scaling per column (gj16_dpp.h)
 //   v1  the work over all four DPP rows: Schur columns replicated, the inverse's columns dealt to the rows, scaling deferred
 //       (gj16s_dpp.h, gen_gj16s.py)
+//   v2  the third form (gj16t_dpp.h, gen_gj16t.py): own-lane reciprocal square roots + one broadcast, nothing masked in the Schur
+//       update, the inverse born from the identity
 // Prints s_memtime ticks per 16x16 block and the largest deviation of L and D from a host fp64 reference.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I treegp_amd/csrc -o tools/probes/gj16_probe tools/probes/gj16_probe.hip
 #include "potrf128.h"
@@ -40,9 +42,10 @@ __global__ __launch_bounds__(64) void probe(const double *A, double *Lout, doubl
             const int i = lane & 15, r = lane >> 4;
             double s[16], w[4] = {0.0, 0.0, 0.0, 0.0}, ls[16];
 #pragma clang loop unroll(full)
-            for (int c = 0; c < 16; ++c) s[c] = (c <= i) ? M[i * 17 + c] : 0.0;
+            for (int c = 0; c < 16; ++c) s[c] = (c <= i || VARIANT == 2) ? M[i * 17 + c] : 0.0;
             int fail = -1;
-            gauss_jordan16s(s, w, ls, i, r, fail);
+            if constexpr (VARIANT == 2) gauss_jordan16t(s, w, ls, i, r, fail);
+            else gauss_jordan16s(s, w, ls, i, r, fail);
 #pragma clang loop unroll(full)
             for (int k = 0; k < 4; ++k) {
                 const int c = 4 * k + r;
@@ -79,10 +82,10 @@ int main() {
     hipMalloc(&dA, 256 * 8); hipMalloc(&dL, 256 * 8); hipMalloc(&dD, 257 * 8); hipMalloc(&dc, 16);
     hipMemcpy(dA, A.data(), 256 * 8, hipMemcpyHostToDevice);
     const int reps = 2000;
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < 3; ++variant) {
         for (int pass = 0; pass < 2; ++pass) {
             hipMemset(dL, 0, 256 * 8); hipMemset(dD, 0, 257 * 8);
-            if (variant == 0) probe<0><<<1, 64>>>(dA, dL, dD, dc, reps); else probe<1><<<1, 64>>>(dA, dL, dD, dc, reps);
+            if (variant == 0) probe<0><<<1, 64>>>(dA, dL, dD, dc, reps); else if (variant == 1) probe<1><<<1, 64>>>(dA, dL, dD, dc, reps); else probe<2><<<1, 64>>>(dA, dL, dD, dc, reps);
             hipDeviceSynchronize();
         }
         std::vector<double> gL(256), gD(256); unsigned long long c[2];

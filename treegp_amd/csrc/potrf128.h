@@ -173,6 +173,49 @@ __device__ __forceinline__ void gauss_jordan16s(double (&s)[16], double (&w)[4],
     for (int k = 0; k < 4; ++k) w[k] *= myinv;
 }
 
+// ---- third form (round 5, gen_gj16t.py): the per-pivot bookkeeping taken out of the instruction stream -------------------------
+// The sweep is issue-bound (tools/probes/issue_probe.hip: 4.5 clocks per 64-bit VALU instruction dependent or not, 16.5 for
+// v_rsq_f64, 12.5 for a DPP read of a fresh result), so what counts is the number of instructions per pivot: 37 in the second
+// form, of which 10.4 are the updates.  Here: every lane takes the reciprocal square root of its OWN s[J] (lane J's is the pivot's;
+// one third-order step instead of two Newton steps), one v_mov_b64_dpp broadcasts it, finished rows are not masked out of the Schur
+// update (nobody reads what they compute), the inverse starts as the identity so that its columns are born by the ordinary
+// update, the failure check is one look at the reciprocals at the end: 26 instructions per pivot.
+#include "gj16t_dpp.h"
+// 1/sqrt(p): hardware estimate y0 (relative error e0 ~ 6e-8), then y = y0 (1 + e + 1.5 e^2) with e = 0.5 - 0.5 p y0^2: error O(e0^3)
+__device__ __forceinline__ double rsqrt_cubic(double p) {
+    const double y0 = __builtin_amdgcn_rsq(p);
+    const double e = __builtin_fma(-0.5 * p * y0, y0, 0.5);
+    return __builtin_fma(y0 * e, __builtin_fma(1.5, e, 1.0), y0);
+}
+template <int J>
+__device__ __forceinline__ void gj16t_column(double (&s)[16], double (&w)[4], double (&ls)[16], double &myinv, const int i) {
+    const double y = rsqrt_cubic(s[J]);                   // lane J: 1 / L[J][J]
+    const double yb = gj16t_bcast<J>(y);
+    const double li = s[J] * yb;                          // L[i][J] for i >= J (lane J: the pivot's square root)
+    const double nl2 = (i > J) ? -(li * yb) : 0.0;        // finished rows of the inverse stay
+    gj16t_update<J>(s, w, li, nl2);
+    myinv = (i == J) ? y : myinv;
+    ls[J] = (i >= J) ? li : 0.0;
+}
+template <int... Js>
+__device__ __forceinline__ void gj16t_all(double (&s)[16], double (&w)[4], double (&ls)[16], double &myinv, const int i,
+                                          std::integer_sequence<int, Js...>) {
+    (gj16t_column<Js>(s, w, ls, myinv, i), ...);
+}
+// lane (r, i): s[] = row i of the block (what lies above the diagonal does not matter).  On exit w[k] = (L^-1)[i][4 k + r] (exact
+// zeros above the diagonal), ls[c] = L[i][c] (zeros above the diagonal); fail = first non-positive (or NaN) pivot, or stays < 0.
+__device__ __forceinline__ void gauss_jordan16t(double (&s)[16], double (&w)[4], double (&ls)[16], const int i, const int r, int &fail) {
+    double myinv = 1.0;
+#pragma clang loop unroll(full)
+    for (int k = 0; k < 4; ++k) w[k] = (4 * k + r == i) ? 1.0 : 0.0;
+    gj16t_all(s, w, ls, myinv, i, std::make_integer_sequence<int, 16>{});
+#pragma clang loop unroll(full)
+    for (int k = 0; k < 4; ++k) w[k] *= myinv;
+    // a pivot <= 0 (or NaN) leaves NaN (or inf) in its reciprocal and in every later one: the first such lane is the failing pivot
+    const unsigned long long bad = __ballot(!(myinv > 0.0 && myinv < __builtin_huge_val())) & 0xffffull;
+    if (bad != 0ull && fail < 0) fail = __builtin_ctzll(bad);
+}
+
 // acc += A[ra.., ca..ca+31] (16 x 32) * B[rb.., cb..cb+31]^T (16 x 32), both row-major in T
 // (splitting these products over two accumulator chains was tried and is slower: the extra adds and LDS
 //  traffic cost more than the dependent-MFMA latency they hide)
@@ -253,6 +296,29 @@ __device__ __forceinline__ void diag16s(double *blk, double *Ag, int lda, int la
     double *wrow = blk + i * BS + r;                                     // D replaces the block: every DPP row its own columns
 #pragma clang loop unroll(full)
     for (int k = 0; k < 4; ++k) wrow[4 * k] = (4 * k + r <= i) ? w[k] : 0.0;
+    if (r == 0) {                                                        // L is final (zeros above the diagonal of the block)
+        double *grow = Ag + (int64_t)i * lda;
+#pragma clang loop unroll(full)
+        for (int c = 0; c < 16; ++c) grow[c] = ls[c];
+    }
+}
+// third form of the sweep: 16-byte LDS reads, nothing masked on the way in or out (gauss_jordan16t)
+__device__ __forceinline__ void diag16t(double *blk, double *Ag, int lda, int lane, int *info, int pos) {
+    const int i = lane & 15, r = lane >> 4;
+    double s[16], w[4], ls[16];
+    const double2 *row = reinterpret_cast<const double2 *>(blk + i * BS);      // BS even and the block's origin even: 16-byte aligned
+#pragma clang loop unroll(full)
+    for (int c = 0; c < 8; ++c) {
+        const double2 v = row[c];
+        s[2 * c] = v.x;
+        s[2 * c + 1] = v.y;
+    }
+    int fail = -1;
+    gauss_jordan16t(s, w, ls, i, r, fail);
+    if (fail >= 0 && lane == 0) atomicCAS(info, 0, pos + fail + 1);
+    double *wrow = blk + i * BS + r;                                     // D replaces the block: every DPP row its own columns
+#pragma clang loop unroll(full)
+    for (int k = 0; k < 4; ++k) wrow[4 * k] = w[k];
     if (r == 0) {                                                        // L is final (zeros above the diagonal of the block)
         double *grow = Ag + (int64_t)i * lda;
 #pragma clang loop unroll(full)
@@ -382,7 +448,11 @@ __device__ __forceinline__ void potrf128_body(double *T, double *A, int lda, dou
 #else
             double *B = T + taddr(r0, r0);                      // the 32x32 diagonal block of this step, row stride BS
             double *Ag = A + (int64_t)r0 * lda + r0;            // the same block in global memory
+#ifdef TGP_GJ16_SECOND
             diag16s(B, Ag, lda, lane, info, base + r0);
+#else
+            diag16t(B, Ag, lda, lane, info, base + r0);
+#endif
             POTRF_FINE(1);
             double *b21 = B + (16 + l4) * BS + l15;             // C fragment of the lower-left 16x16 block: rows 16 + l4 + 4 r
             const d4v x = blk_nt16<16, 0, 0, 0>(B, l15, l4);                           // L21 = A21 D11^T
@@ -396,7 +466,11 @@ __device__ __forceinline__ void potrf128_body(double *T, double *A, int lda, dou
 #pragma unroll
             for (int r = 0; r < 4; ++r) b21[4 * r * BS + 16] -= p[r];
             POTRF_FINE(3);
+#ifdef TGP_GJ16_SECOND
             diag16s(B + 16 * BS + 16, Ag + (int64_t)16 * lda + 16, lda, lane, info, base + r0 + 16);
+#else
+            diag16t(B + 16 * BS + 16, Ag + (int64_t)16 * lda + 16, lda, lane, info, base + r0 + 16);
+#endif
             POTRF_FINE(4);
             const d4v s = blk_nn16<16, 0, 0, 0>(B, l15, l4);                           // S = L21 D11
 #pragma unroll
