@@ -89,6 +89,11 @@ if T:
         per = {}
         for k, v in cus.items():
             per[len(v)] = per.get(len(v), 0) + 1
+        if len(stay):
+            st0, en = (stay[:, 0].astype(np.float64) - t0) / 100.0, (stay[:, 1].astype(np.float64) - t0) / 100.0
+            tl = stay[:, 3].astype(np.float64)
+            print("  xcc %d: staying workgroups start %.1f .. %.1f us, end %.1f .. %.1f us (mean %.1f), %d tiles, us per tile %.1f"
+                  % (xcc, st0.min(), st0.max(), en.min(), en.max(), en.mean(), int(tl.sum()), float(((en - st0).sum()) / max(tl.sum(), 1.0))))
         print("  xcc %d: %3d workgroups, %2d left from CUs %s (arrival %.1f .. %.1f us); staying: CUs x workgroups %s, tiles per workgroup %s"
               % (xcc, len(sel), len(left), {("se%d cu%d" % ((k >> 5) & 7, k & 15)): c for k, c in lcus.items()},
                  (float(left[:, 0].min()) - t0) / 100.0 if len(left) else 0.0, (float(left[:, 0].max()) - t0) / 100.0 if len(left) else 0.0,

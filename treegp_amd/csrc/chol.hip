@@ -265,8 +265,11 @@ __global__ __launch_bounds__(256, 2) void syrk_strip64_kernel(double *Abase, int
 // stay free for the chain.  One counter per XCD class keeps the XCD-aware tile map (blockIdx.x & 7 = XCD of the
 // workgroup); the loop ends for every workgroup once its class has run out of slots.
 template <int NSEG>
-__global__ __launch_bounds__(256, 2) void syrk_dtv_queue_kernel(double *Abase, int64_t Np, int ob, int T, unsigned slots_per_class, int nres,
-                                                                unsigned *__restrict__ queue, const double *P0, const double *P1) {
+// `half_from`: tile slots of a class from this one on are taken as two 64 x 128 half tiles each (two queue entries): the launch
+// ends when its slowest workgroup does, on average half a tile time after the queues run dry (63 us of a 570 us launch at
+// N = 8192), and half tiles in the last round halve that.  `entries` = half_from + 2 (slots - half_from) queue entries per class.
+__global__ __launch_bounds__(256, 2) void syrk_dtv_queue_kernel(double *Abase, int64_t Np, int ob, int T, unsigned entries, unsigned half_from, int nres,
+                                                                unsigned *__restrict__ queue, const double *P0, const double *P1, int steal) {
     __shared__ unsigned s_slot;
     const unsigned xcd = blockIdx.x & 7;
     {   // `nres` compute units per shader engine and XCD (32 nres of 256) are kept clear of this kernel: the first
@@ -308,20 +311,38 @@ __global__ __launch_bounds__(256, 2) void syrk_dtv_queue_kernel(double *Abase, i
 #ifdef TGP_POTRF_STAMPS
     unsigned my_tiles = 0;
 #endif
+    // A class that has run dry helps the next one (TGP_QUEUE_STEAL, default on): the classes hold 248 - 266 tiles at T = 56 (diagonal
+    // super-tiles are not full) and the launch used to end 50 us after its average workgroup (in-kernel stamps, N = 8192).
+    unsigned cls = xcd;
+    int dry = 0;
     for (;;) {
-        if (threadIdx.x == 0) s_slot = atomicAdd(&queue[xcd], 1u);
+        if (threadIdx.x == 0) s_slot = atomicAdd(&queue[cls], 1u);
         __syncthreads();
-        const unsigned n = s_slot;
+        unsigned n = s_slot;
         __syncthreads();                         // s_slot has been read by everyone before the next round overwrites it
-        if (n >= slots_per_class) break;         // uniform
+        if (n >= entries) {                      // uniform
+            if (!steal || ++dry == 8) break;
+            cls = (cls + 1u) & 7u;
+            continue;
+        }
+        int half = -1;
+        if (n >= half_from) {
+            half = (int)((n - half_from) & 1u);
+            n = half_from + ((n - half_from) >> 1);
+        }
         int ti, tj;
-        tilemap(((int64_t)n << 3) | xcd, T, ti, tj);
+        tilemap(((int64_t)n << 3) | cls, T, ti, tj);
         if (ti < 0) continue;
         const int64_t pj = ob + (tj >> 1);
         const int64_t I = (int64_t)TGP_PW * ob + (int64_t)TGP_TB * ti;
         double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
         const int64_t oa = (int64_t)ti * TGP_TB * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
-        gemm_tile_dtv<4, TGP_PW, NSEG>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
+        if (half < 0) {
+            gemm_tile_dtv<4, TGP_PW, NSEG>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
+        } else {
+            const int64_t ho = (int64_t)half * 64 * TGP_PW;
+            gemm_tile_dtv<4, TGP_PW, NSEG, 1>(P0 + oa + ho, P0 + obb, C + ho, NSEG > 1 ? P1 + oa + ho : nullptr, NSEG > 1 ? P1 + obb : nullptr);
+        }
 #ifdef TGP_POTRF_STAMPS
         if (threadIdx.x == 0 && T == tgp_queue_stamp_T) {
             tgp_queue_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -650,18 +671,25 @@ void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int str
 int queued_nres(int T) {
     static const int queue_res = [] { const char *e = getenv("TGP_QUEUE_RES"); return e ? atoi(e) : 0; }();
     if (queue_res > 0) return queue_res > TGP_QUEUE_MAXRES ? TGP_QUEUE_MAXRES : queue_res;
+    static const int bulk_us = [] { const char *e = getenv("TGP_QUEUE_BULK_US"); return e ? atoi(e) : 400; }();
     const int64_t tiles = (int64_t)T * (T + 1) / 2;
     for (int r = 3; r > 1; --r) {
         const int64_t slots = 512 - 64 * r;
-        if ((tiles + slots - 1) / slots * 130 <= 400) return r;
+        if ((tiles + slots - 1) / slots * 130 <= bulk_us) return r;
     }
     return 1;
 }
 void launch_syrk2_queued(tgp_ctx *ctx, hipStream_t st, double *d_A, int64_t Np, int ob, int T, const double *P0, const double *P1,
                          int nqueue) {
     const int nres = queued_nres(T);
-    syrk_dtv_queue_kernel<2><<<512 + 8, 256, 0, st>>>(d_A, Np, ob, T, (unsigned)(tilemap_grid(T) / 8), nres,
-                                                     ctx->d_queue + TGP_QUEUE_WORDS * nqueue, P0, P1);
+    // the last round of a class (as many slots as it has resident workgroups) runs as half tiles; TGP_QUEUE_HALF = slots per class, 0 off
+    static const int half_env = [] { const char *e = getenv("TGP_QUEUE_HALF"); return e ? atoi(e) : -1; }();
+    const unsigned slots = (unsigned)(tilemap_grid(T) / 8);
+    unsigned nhalf = half_env >= 0 ? (unsigned)half_env : (unsigned)(512 - 64 * nres) / 8u;
+    if (nhalf > slots) nhalf = slots;
+    static const int steal = [] { const char *e = getenv("TGP_QUEUE_STEAL"); return e ? atoi(e) : 1; }();
+    syrk_dtv_queue_kernel<2><<<512 + 8, 256, 0, st>>>(d_A, Np, ob, T, slots + nhalf, slots - nhalf, nres,
+                                                     ctx->d_queue + TGP_QUEUE_WORDS * nqueue, P0, P1, steal);
 }
 }  // namespace
 
