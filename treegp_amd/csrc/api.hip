@@ -168,6 +168,15 @@ void tgp_factor_release_to_cache(tgp_ctx *ctx, tgp_factor *f) {
     delete f;
 }
 
+std::atomic<int> tgp_solves_in_flight{0};
+namespace {
+struct SolveInFlight {
+    bool alone;
+    SolveInFlight() : alone(tgp_solves_in_flight.fetch_add(1) == 0) {}
+    ~SolveInFlight() { tgp_solves_in_flight.fetch_sub(1); }
+};
+}  // namespace
+
 extern "C" {
 
 const char *tgp_version(void) { return "treegp_amd libtgp 0.1 (gfx950)"; }
@@ -476,8 +485,25 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
     return 0;
 }
 
+// A factorisation that gave up on an in-kernel hand-off (TGP_RC_HANDOFF: other processes' kernels on the same GPU can keep
+// panel_mid_kernel's workgroups apart for longer than its bounded wait) has left a half-updated matrix: the context switches that
+// kernel off for good and the solve is run once more, K build included.
+static int gp_solve_once(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_y,
+                         const double *d_yerr, double *d_alpha, double *logdet, double *ydota, tgp_factor **keep);
 int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_y,
                    const double *d_yerr, double *d_alpha, double *logdet, double *ydota, tgp_factor **keep) {
+    SolveInFlight here;
+    ctx->mid_allowed = here.alone ? 1 : 0;
+    int rc = gp_solve_once(ctx, k, d_X, n, d_y, d_yerr, d_alpha, logdet, ydota, keep);
+    ctx->mid_allowed = 0;
+    if (rc == TGP_RC_HANDOFF && !ctx->mid_off) {
+        ctx->mid_off = 1;
+        rc = gp_solve_once(ctx, k, d_X, n, d_y, d_yerr, d_alpha, logdet, ydota, keep);
+    }
+    return rc;
+}
+static int gp_solve_once(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n, const double *d_y,
+                         const double *d_yerr, double *d_alpha, double *logdet, double *ydota, tgp_factor **keep) {
     TGP_ARG(k && d_X && d_y && n > 0);
     TGP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -510,8 +536,22 @@ int tgp_d_gp_solve(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t
 // The same for a matrix the CALLER evaluated: any scikit-learn kernel tree that tgp_kernel cannot describe (Sum,
 // WhiteKernel, Matern, ...; treegp/kernels.py:17-59 evals any of them and gp_interp.py:177-183 works with what comes back).
 // d_K: dense (n, n) row-major on the device, lower triangle read; d_yerr^2 (may be NULL) is added to the diagonal.
+static int gp_solve_dense_once(tgp_ctx *ctx, const double *d_K, int64_t n, const double *d_y, const double *d_yerr,
+                               double *d_alpha, double *logdet, double *ydota, tgp_factor **keep);
 int tgp_d_gp_solve_dense(tgp_ctx *ctx, const double *d_K, int64_t n, const double *d_y, const double *d_yerr,
                          double *d_alpha, double *logdet, double *ydota, tgp_factor **keep) {
+    SolveInFlight here;
+    ctx->mid_allowed = here.alone ? 1 : 0;
+    int rc = gp_solve_dense_once(ctx, d_K, n, d_y, d_yerr, d_alpha, logdet, ydota, keep);
+    ctx->mid_allowed = 0;
+    if (rc == TGP_RC_HANDOFF && !ctx->mid_off) {
+        ctx->mid_off = 1;
+        rc = gp_solve_dense_once(ctx, d_K, n, d_y, d_yerr, d_alpha, logdet, ydota, keep);
+    }
+    return rc;
+}
+static int gp_solve_dense_once(tgp_ctx *ctx, const double *d_K, int64_t n, const double *d_y, const double *d_yerr,
+                               double *d_alpha, double *logdet, double *ydota, tgp_factor **keep) {
     TGP_ARG(d_K && d_y && n > 0);
     TGP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;

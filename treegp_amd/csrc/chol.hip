@@ -118,9 +118,10 @@ __global__ __launch_bounds__(256, 2) void diag_mid_kernel(double *R1, const doub
 // hold their compute units spinning for W1.  Hand-off: the producer's waves wait for their stores (vmcnt(0)), barrier, one
 // release fence at agent scope (writes the XCD's L2 back), one relaxed atomic increment; the consumer's thread 0 polls with
 // relaxed agent-scope loads, then one acquire fence (invalidates the XCD's L2 and the CU's L1), barrier.
-// EVERY SPIN IS BOUNDED: after PANEL_SPIN_TICKS of the 100 MHz clock (2 s) the waiter raises sync[2], which ends every other
-// wait of the launch at once, and reports info = -7; launch_potrf turns that into rc < 0.
-constexpr unsigned long long PANEL_SPIN_TICKS = 200000000ull;
+// EVERY SPIN IS BOUNDED: after PANEL_SPIN_TICKS of the 100 MHz clock (50 ms; a wait is a few microseconds) the waiter raises
+// sync[2], which ends every other wait of the launch at once, and reports info = -7; launch_potrf turns that into TGP_RC_HANDOFF
+// and the solve entry points run the solve again without this kernel (api.hip: gp_solve_once).
+constexpr unsigned long long PANEL_SPIN_TICKS = 5000000ull;
 constexpr int PANEL_SYNC_WORDS = 16;           // 64 B per panel: [0] A1 slices done, [1] A2 slices done, [2] abort
 __device__ __forceinline__ void panel_publish(unsigned *counter) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -581,13 +582,16 @@ __global__ __launch_bounds__(256, 2) void syrk_distn_queue_kernel(double *Aloc, 
 // every DEPENDENT instruction of the factorisation's serial chain then waits for one (in-kernel stamps at N = 8192: the
 // 32x32 diagonal steps 14k -> 72-88k cycles, the whole block 44 -> 156 us).  Only used where free compute units are
 // guaranteed (the queued bulk update below keeps one per XCD clear); elsewhere the kernel would wait for a CU to drain.
-inline void run_potrf128(hipStream_t st, double *A, int lda, double *W, int *info, int base, bool exclusive = false) {
-    constexpr unsigned pad = 128 * 1024 - 95744;
-    static const bool pad_ok = [] {
-        return hipFuncSetAttribute((const void *)potrf_v2::potrf128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)pad) == hipSuccess;
+// `solo`: the launch has a compute unit to itself (nothing else on the chip, or `exclusive`): the variant without the register cap
+inline void run_potrf128(hipStream_t st, double *A, int lda, double *W, int *info, int base, bool exclusive = false, bool solo = false) {
+    constexpr unsigned image = potrf_v2::POTRF_LDS_BYTES, full = 128 * 1024;
+    static const bool attr_ok = [] {
+        return hipFuncSetAttribute((const void *)potrf_v2::potrf128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)full) == hipSuccess &&
+               hipFuncSetAttribute((const void *)potrf_v2::potrf128_solo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)full) == hipSuccess;
     }();
-    potrf_v2::potrf128_kernel<true><<<1, 256, (exclusive && pad_ok) ? pad : 0u, st>>>(A, lda, W, info, base);
+    (void)attr_ok;          // (if the attribute could not be set the launch below fails and launch_potrf reports it)
+    if (exclusive || solo) potrf_v2::potrf128_solo_kernel<<<1, 256, exclusive ? full : image, st>>>(A, lda, W, info, base);
+    else potrf_v2::potrf128_kernel<true><<<1, 256, image, st>>>(A, lda, W, info, base);
 }
 }  // namespace
 
@@ -609,7 +613,8 @@ void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_inf
     const int r1 = (int)((mk - TGP_TB) / TGP_TB);
     // few row blocks: 16-row slices spread a block over 8 workgroups (latency); many: 128-row tiles (throughput)
     static const int small_rows = [] { const char *e = getenv("TGP_SMALL_ROWS"); return e ? atoi(e) : 40; }();
-    run_potrf128(st, Pk, TGP_PW, W0, d_info, base, exclusive);
+    const bool solo = cu_budget >= 256 && mid_sync != nullptr;      // callers pass the whole chip only where the chain runs alone
+    run_potrf128(st, Pk, TGP_PW, W0, d_info, base, exclusive, solo);
     if (n_data >= 0 && (int64_t)base + TGP_TB >= n_data && mk == TGP_PW) {
         gemm_col_small_kernel<0, TGP_TB><<<8, 256, 0, st>>>(R1, W0, R1);      // rows 128..255: zero, or the right-hand side row
         set_identity128_kernel<<<64, 256, 0, st>>>(W1);
@@ -633,7 +638,7 @@ void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_inf
             gemm_col_kernel<0, TGP_TB><<<r1, 256, 0, st>>>(R1, W0, R1);
             gemm_col_kernel<1, TGP_PW><<<r1, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
         }
-        run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, d_info, base + TGP_TB, exclusive);
+        run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, d_info, base + TGP_TB, exclusive, solo);
     }
     if (r2 > 0) {
         double *R2 = Pk + (int64_t)TGP_PW * TGP_PW + TGP_TB;    // row 256, column 128
@@ -758,7 +763,8 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     int nqueue = 0;
     // TGP_PANEL_MID=0: the step between a panel's two diagonal blocks as separate launches everywhere (before round 5)
     static const bool mid_env = [] { const char *e = getenv("TGP_PANEL_MID"); return e ? atoi(e) != 0 : true; }();
-    const bool mid_on = mid_env;
+    // ... and only for a solve that started alone and can be run again (tgp_internal.h: tgp_solves_in_flight; api.hip: gp_solve_once)
+    const bool mid_on = mid_env && !ctx->mid_off && ctx->mid_allowed;
     if (mid_on) TGP_HIP(hipMemsetAsync(ctx->d_psync, 0, (size_t)(nP < TGP_PSYNC_PANELS ? nP : TGP_PSYNC_PANELS) * PANEL_SYNC_WORDS * sizeof(unsigned), st));
     if (Np / TGP_TB - 8 > small_t())          // some step can take the queued form (T3 = Np/128 - 8 at the first pair)
         TGP_HIP(hipMemsetAsync(ctx->d_queue, 0, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned), st));
@@ -793,7 +799,8 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             }
             TGP_HIP(tgp_signal(ctx, st, 0, ctx->ev[4]));
             TGP_HIP(tgp_await(ctx, sd, 0, ctx->ev[4]));
-            factor_pair(sd, k + 2, queued, queued ? 32 * queued_nres(T3) : 0);
+            // (steps with at most small_t tile rows have no bulk update to speak of: the chain has the chip to itself)
+            factor_pair(sd, k + 2, queued, queued ? 32 * queued_nres(T3) : (T3 <= small_t() ? 256 : 0));
             TGP_HIP(tgp_signal(ctx, sd, 1, ctx->ev[5]));
             if (T3 > 0) {   // U2b: everything from block k+4 on
                 const double m = (double)T3 * TGP_TB;
@@ -950,9 +957,9 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
 // panel_mid_kernel gave up after its bounded wait) -> -4 with the reason in tgp_last_error
 int tgp_potrf_info_rc(tgp_ctx *ctx, int info) {
     if (info >= 0) return info;
-    ctx->err = "Cholesky: an in-kernel hand-off timed out (panel_mid_kernel waited 2 s for workgroups of its own launch); "
+    ctx->err = "Cholesky: an in-kernel hand-off timed out (panel_mid_kernel waited 50 ms for workgroups of its own launch); "
                "the factor is incomplete -- TGP_PANEL_MID=0 selects the schedule without in-kernel waits";
-    return -4;
+    return TGP_RC_HANDOFF;
 }
 
 // 256x256 diagonal block (ld 256): L in place, inverses of its two 128-blocks to W0 / W1

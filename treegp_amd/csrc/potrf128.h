@@ -194,7 +194,9 @@ __device__ __forceinline__ void gj16t_column(double (&s)[16], double (&w)[4], do
     const double li = s[J] * yb;                          // L[i][J] for i >= J (lane J: the pivot's square root)
     const double nl2 = (i > J) ? -(li * yb) : 0.0;        // finished rows of the inverse stay
     gj16t_update<J>(s, w, li, nl2);
-    myinv = (i == J) ? y : myinv;
+    // lane i keeps the last y it sees here, which is step i's: one family of lane masks (i > J), J = -1 .. 15, serves all three selects
+    // (with (i == J) as well the masks of a sweep no longer fit in the scalar registers, and their spills take VGPRs from the top)
+    myinv = (i >= J) ? y : myinv;
     ls[J] = (i >= J) ? li : 0.0;
 }
 template <int... Js>
@@ -372,6 +374,190 @@ __device__ __forceinline__ void phase2_pair(double *T, double *SC, int rt, int c
     __syncthreads();
 }
 
+// ---- the inversion under the diagonal steps (round 5) ---------------------------------------------------------------------------
+// W = L^-1 used to be a phase of its own after the factorisation: six (block row, block column) pairs, two workgroup barriers each,
+// 6.2 of the kernel's 28 us -- while during the four diagonal steps (13.8 us, wave 0 alone) three waves and their MFMA pipes had
+// nothing to do.  Now the chains of the inverse's block columns
+//     S_IB = sum_{k = CB}^{IB-1} L_IB,k W_k,CB,     W_IB,CB = -D_IB S_IB          (W_CB,CB = D_CB)
+// run on the waves 1..3 UNDER the diagonal steps, in 16-column slices (a column of the inverse depends on nothing but itself): waves
+// 1 and 2 own the two slices of block columns 0 and 2, wave 3 block column 1.  S and then W replace L_IB,CB in the LDS image (the
+// image and the final write-out of W stay as they were) once that block of L is in global memory and everybody has read it:
+//   under step 1 (D0)   w1, w2: S10, S20, S30 = L_i0 D0 (slices, in registers until w3 has written L_i0 out and all have read it)
+//   under step 2 (D1)   w1, w2: W10 = -D1 S10, S20 += L21 W10, S30 += L31 W10;  w3: S21 = L21 D1 -> spare block, S31 = L31 D1
+//   under step 3 (D2)   w1, w2: W20 = -D2 S20, S30 += L32 W20, S32 = L32 D2;    w3: W21 = -D2 S21, S31 += L32 W21
+//   after step 3 (D3)   W30, W31, W32 = -D3 S3x: at most two half products per wave (wave 0 takes one slice of W31)
+// What crosses waves goes through the workgroup barriers of the factorisation loop, except "I have read this block" inside a step:
+// those are flags in LDS (release / acquire at workgroup scope).  Every wait is bounded -- all four waves are resident by
+// construction, the bound only turns a logic error into info = -8 instead of a hang.
+// acc[rt] += A (32 x 32 at Ablk) B[:, 16 h .. 16 h + 15] (B 32 x 32 at Bblk): one wave, a 32 x 16 slice, k = 4 ks + l4.
+// A_LOWER / B_LOWER: that operand is a lower-triangular diagonal block -- products with its zero upper-right tile are skipped.
+template <bool A_LOWER, bool B_LOWER>
+__device__ __forceinline__ void slice_mm(const double *Ablk, const double *Bblk, int h, d4v (&acc)[2], int l15, int l4) {
+    const double *a = Ablk + l15 * BS + l4, *b = Bblk + l4 * BS + 16 * h + l15;
+    // (the scheduler would hoist every operand read of every product of a step to its top: 330 VGPRs, where the kernel has to stay
+    //  within 264 to fit on a SIMD beside a wave of the trailing update -- hence the fences)
+    __builtin_amdgcn_sched_barrier(0);
+    if (B_LOWER && h == 1) {                             // rows 0..15 of those columns of B are zero: k from 16 on
+#pragma unroll
+        for (int ks = 4; ks < 8; ++ks) {
+            const double bv = b[4 * ks * BS];
+            if (!A_LOWER) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * ks], bv, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[16 * BS + 4 * ks], bv, acc[1], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const double bv = b[4 * ks * BS];
+            if (!(A_LOWER && ks >= 4)) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * ks], bv, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[16 * BS + 4 * ks], bv, acc[1], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void slice_zero(d4v (&acc)[2]) {
+    acc[0] = (d4v){0.0, 0.0, 0.0, 0.0};
+    acc[1] = (d4v){0.0, 0.0, 0.0, 0.0};
+}
+__device__ __forceinline__ void slice_load(const double *blk, int h, d4v (&acc)[2], int l15, int l4) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[rt][r] = blk[(16 * rt + l4 + 4 * r) * BS + 16 * h + l15];
+}
+template <bool NEGATE>
+__device__ __forceinline__ void slice_store(double *blk, int h, const d4v (&acc)[2], int l15, int l4) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) blk[(16 * rt + l4 + 4 * r) * BS + 16 * h + l15] = NEGATE ? -acc[rt][r] : acc[rt][r];
+    __builtin_amdgcn_sched_barrier(0);
+}
+// one 32 x 32 block of L from the LDS image to global memory, one wave: lane = (row, half row)
+__device__ __forceinline__ void wave_block_to_global(const double *blk, double *Ag, int lda, int lane) {
+    const int row = lane >> 1, half = lane & 1;
+    const double2 *src = reinterpret_cast<const double2 *>(blk + row * BS + 16 * half);
+    double2 *dst = reinterpret_cast<double2 *>(Ag + (int64_t)row * lda + 16 * half);
+    double2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = src[q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dst[q] = v[q];
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void helper_post(int *flag) {
+    __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void helper_wait(int *flag, int *info) {
+    unsigned it = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++it > (1u << 22)) {                          // cannot happen: the poster is a resident wave of this workgroup
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(info, -8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+// flag words: R0[1..3] "wave w no longer reads L_i0" (step 1), R1[1..2] "... L31" (step 2), R2[1..3] "... L32" (step 3)
+constexpr int HF_R0 = 0, HF_R1 = 4, HF_R2 = 8, HF_WORDS = 12;
+
+// One step of the schedule above for the waves 1..3 (jb = the factorisation's iteration that has just produced D_jb and L_i,jb).
+__device__ __forceinline__ void inversion_step(double *T, double *A, int lda, int *info, int jb, int wave, int lane) {
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double *SC = T + T_ELEMS;
+    int *hflag = reinterpret_cast<int *>(T + T_ELEMS + BLK_ELEMS);
+    const int h = wave - 1;                            // waves 1, 2: their 16-column slice of block columns 0 and 2
+    double *const B10 = T + blk_origin(1, 0), *const B20 = T + blk_origin(2, 0), *const B30 = T + blk_origin(3, 0);
+    double *const B21 = T + blk_origin(2, 1), *const B31 = T + blk_origin(3, 1), *const B32 = T + blk_origin(3, 2);
+    const double *const D0 = T + blk_origin(0, 0), *const D1 = T + blk_origin(1, 1), *const D2 = T + blk_origin(2, 2);
+    if (jb == 0) {
+        if (wave == 3) {                               // L_i0 to global memory, then the slices may replace it; S30 (both slices)
+            wave_block_to_global(B10, A + (int64_t)32 * lda, lda, lane);
+            wave_block_to_global(B20, A + (int64_t)64 * lda, lda, lane);
+            wave_block_to_global(B30, A + (int64_t)96 * lda, lda, lane);
+            d4v t0[2], t1[2];
+            slice_zero(t0); slice_zero(t1);
+            slice_mm<false, true>(B30, D0, 0, t0, l15, l4);            // S30 = L30 D0
+            slice_mm<false, true>(B30, D0, 1, t1, l15, l4);
+            helper_post(hflag + HF_R0 + 3);
+            slice_store<false>(B30, 0, t0, l15, l4);                   // (waves 1 and 2 do not read L30 in this step)
+            slice_store<false>(B30, 1, t1, l15, l4);
+        } else {
+            d4v s1[2], s2[2];
+            slice_zero(s1); slice_zero(s2);
+            slice_mm<false, true>(B10, D0, h, s1, l15, l4);            // S_i0 = L_i0 D0
+            slice_mm<false, true>(B20, D0, h, s2, l15, l4);
+            helper_post(hflag + HF_R0 + wave);
+            helper_wait(hflag + HF_R0 + (3 - wave), info);
+            helper_wait(hflag + HF_R0 + 3, info);
+            slice_store<false>(B10, h, s1, l15, l4);
+            slice_store<false>(B20, h, s2, l15, l4);
+        }
+    } else if (jb == 1) {
+        if (wave == 3) {
+            d4v s[2], t0[2], t1[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {                           // S21 = L21 D1 -> spare block
+                slice_zero(s);
+                slice_mm<false, true>(B21, D1, hh, s, l15, l4);
+                slice_store<false>(SC, hh, s, l15, l4);
+            }
+            slice_zero(t0); slice_zero(t1);
+            slice_mm<false, true>(B31, D1, 0, t0, l15, l4);            // S31 = L31 D1 (the L32 W21 term under the next step)
+            slice_mm<false, true>(B31, D1, 1, t1, l15, l4);
+            helper_wait(hflag + HF_R1 + 1, info);                      // waves 1 and 2 have read L31 (and written it out)
+            helper_wait(hflag + HF_R1 + 2, info);
+            slice_store<false>(B31, 0, t0, l15, l4);
+            slice_store<false>(B31, 1, t1, l15, l4);
+        } else {
+            if (wave == 1) wave_block_to_global(B21, A + (int64_t)64 * lda + 32, lda, lane);
+            else wave_block_to_global(B31, A + (int64_t)96 * lda + 32, lda, lane);
+            d4v acc[2];
+            slice_zero(acc);
+            slice_mm<true, false>(D1, B10, h, acc, l15, l4);           // W10 = -D1 S10
+            slice_store<true>(B10, h, acc, l15, l4);
+            slice_load(B20, h, acc, l15, l4);
+            slice_mm<false, false>(B21, B10, h, acc, l15, l4);         // S20 += L21 W10
+            slice_store<false>(B20, h, acc, l15, l4);
+            slice_load(B30, h, acc, l15, l4);
+            slice_mm<false, false>(B31, B10, h, acc, l15, l4);         // S30 += L31 W10
+            slice_store<false>(B30, h, acc, l15, l4);
+            helper_post(hflag + HF_R1 + wave);
+        }
+    } else if (jb == 2) {
+        if (wave == 3) {
+            d4v acc[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {                           // W21 = -D2 S21 (L21 is in global memory since step 2)
+                slice_zero(acc);
+                slice_mm<true, false>(D2, SC, hh, acc, l15, l4);
+                slice_store<true>(B21, hh, acc, l15, l4);
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {                           // S31 += L32 W21
+                slice_load(B31, hh, acc, l15, l4);
+                slice_mm<false, false>(B32, B21, hh, acc, l15, l4);
+                slice_store<false>(B31, hh, acc, l15, l4);
+            }
+            helper_post(hflag + HF_R2 + 3);
+        } else {
+            if (wave == 1) wave_block_to_global(B32, A + (int64_t)96 * lda + 64, lda, lane);
+            d4v acc[2], s32[2];
+            slice_zero(acc);
+            slice_mm<true, false>(D2, B20, h, acc, l15, l4);           // W20 = -D2 S20
+            slice_store<true>(B20, h, acc, l15, l4);
+            slice_load(B30, h, acc, l15, l4);
+            slice_mm<false, false>(B32, B20, h, acc, l15, l4);         // S30 += L32 W20
+            slice_store<false>(B30, h, acc, l15, l4);
+            slice_zero(s32);
+            slice_mm<false, true>(B32, D2, h, s32, l15, l4);           // S32 = L32 D2
+            helper_post(hflag + HF_R2 + wave);
+            helper_wait(hflag + HF_R2 + (3 - wave), info);
+            helper_wait(hflag + HF_R2 + 3, info);
+            slice_store<false>(B32, h, s32, l15, l4);
+        }
+    }
+}
+
 // Register budget: at most 264 VGPRs (arch + acc), so that a wave of this kernel fits on a SIMD next to one wave of
 // the trailing update (248 of 512) -- with more it has to wait for an EMPTY compute unit during the look-ahead
 // (measured: 268 VGPRs cost 25 ms of exposed panel time at N = 65536).  The initial load is batched in two halves
@@ -379,7 +565,7 @@ __device__ __forceinline__ void phase2_pair(double *T, double *SC, int rt, int c
 // -DTGP_GJ16_ONE_ROW: A/B build with the sweep on the 16 lanes of one DPP row and taddr() addressing (round 1)
 // The body works on an LDS image T of POTRF_LDS_DOUBLES doubles handed in by the kernel, so that a kernel that also runs GEMM tiles
 // (chol.hip: panel_mid_kernel) can alias their staging over it.
-constexpr int POTRF_LDS_DOUBLES = T_ELEMS + BLK_ELEMS;
+constexpr int POTRF_LDS_DOUBLES = T_ELEMS + BLK_ELEMS + 8;     // 10 lower blocks + one spare block + the helper waves' flags (12 words)
 template <bool DIAG16>
 __device__ __forceinline__ void potrf128_body(double *T, double *A, int lda, double *W, int *info, int base) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -391,6 +577,9 @@ __device__ __forceinline__ void potrf128_body(double *T, double *A, int lda, dou
     // 32x32 block, so block and half are compile-time and every address is one per-thread base plus a constant
     const int lrow = tid >> 4, lpair = tid & 15;
     double *tbase = T + lrow * BS + 2 * lpair;
+    double *SC = T + T_ELEMS;                          // the spare 32x32 block
+    int *hflag = reinterpret_cast<int *>(T + T_ELEMS + BLK_ELEMS);      // helper waves' "I have read it" events (see above)
+    if (tid < HF_WORDS) hflag[tid] = 0;
     {   // the 10 lower blocks come in with all 20 loads of a thread in flight at once (one memory round trip), 16-byte LDS writes;
         // the diagonal blocks are masked to their lower triangles
         const double *gbase = A + (int64_t)lrow * lda + 2 * lpair;
@@ -540,6 +729,30 @@ __device__ __forceinline__ void potrf128_body(double *T, double *A, int lda, dou
 #pragma unroll
             for (int r = 0; r < 4; ++r) c[4 * r * BS] -= p[r];
         };
+        auto tile_ij = [](int tt, int &ti, int &tj) {
+            ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= tt) ++ti;
+            tj = tt - ti * (ti + 1) / 2;
+        };
+        auto schur_tile2 = [&](int ta, int tb) {
+            int ai, aj, bi, bj;
+            tile_ij(ta, ai, aj);
+            tile_ij(tb, bi, bj);
+            const double *a0 = T + taddr(r1 + 16 * ai, r0) + l15 * BS + l4, *b0 = T + taddr(r1 + 16 * aj, r0) + l15 * BS + l4;
+            const double *a1 = T + taddr(r1 + 16 * bi, r0) + l15 * BS + l4, *b1 = T + taddr(r1 + 16 * bj, r0) + l15 * BS + l4;
+            d4v p = zero4, q = zero4;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                p = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[4 * ks], b0[4 * ks], p, 0, 0, 0);
+                q = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[4 * ks], b1[4 * ks], q, 0, 0, 0);
+            }
+            double *c0 = T + taddr(r1 + 16 * ai, r1 + 16 * aj) + l4 * BS + l15, *c1 = T + taddr(r1 + 16 * bi, r1 + 16 * bj) + l4 * BS + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                c0[4 * r * BS] -= p[r];
+                c1[4 * r * BS] -= q[r];
+            }
+        };
 #ifdef TGP_POTRF_SCHUR_SOLO          // A/B: wave 0 alone on the three tiles of the next diagonal block, no barrier (round 1)
         if (wave == 0) {
             if (nr16 >= 2) {
@@ -570,42 +783,64 @@ __device__ __forceinline__ void potrf128_body(double *T, double *A, int lda, dou
         if (ntile > 0) {
             if (wave < ntile && wave < 4) schur_tile(wave);
             __syncthreads();
-            if (wave > 0)
-                for (int tt = 4 + (wave - 1); tt < ntile; tt += 3) schur_tile(tt);
+            if (wave > 0) {
+                // two tiles at a time: two independent 8-MFMA chains hide each other's operand reads and read-modify-write
+                int tt = 4 + (wave - 1);
+                for (; tt + 3 < ntile; tt += 6) schur_tile2(tt, tt + 3);
+                if (tt < ntile) schur_tile(tt);
+            }
         }
 #endif
+        // ---- the inversion's share of this iteration, under the next diagonal step (waves 1..3; see above) ----
+        if (DIAG16 && wave > 0 && jb < 3) inversion_step(T, A, lda, info, jb, wave, lane);
     }
     __syncthreads();
 
     POTRF_STAMP(13);
-    // off-diagonal blocks of L are final: write them out (diagonal blocks went out from registers).
-    // Block row bi holds 32 rows x 32 bi columns = 16 bi column pairs per row; 12 pairs per thread in all.
+    if (DIAG16) {
+        // what is left of the inversion once D3 exists: one product per wave
+        POTRF_STAMP(14);
+        {   // waves 1, 2: their slices of W30 and W32; waves 0, 3: the two slices of W31
+            const double *D3 = T + blk_origin(3, 3);
+            const int h = (wave == 0) ? 0 : (wave == 3 ? 1 : wave - 1);
+            d4v acc[2];
+            double *blk = T + ((wave == 0 || wave == 3) ? blk_origin(3, 1) : blk_origin(3, 0));
+            slice_zero(acc);
+            slice_mm<true, false>(D3, blk, h, acc, l15, l4);                                               // W3x = -D3 S3x
+            slice_store<true>(blk, h, acc, l15, l4);
+            if (wave == 1 || wave == 2) {
+                blk = T + blk_origin(3, 2);
+                slice_zero(acc);
+                slice_mm<true, false>(D3, blk, h, acc, l15, l4);
+                slice_store<true>(blk, h, acc, l15, l4);
+            }
+        }
+        __syncthreads();
+    } else {
+        // off-diagonal blocks of L are final: write them out (diagonal blocks went out from registers).
+        // Block row bi holds 32 rows x 32 bi columns = 16 bi column pairs per row; 12 pairs per thread in all.
 #pragma unroll
-    for (int s = 0; s < 12; ++s) {
-        const int bi = s < 2 ? 1 : (s < 6 ? 2 : 3);
-        const int first = s < 2 ? 0 : (s < 6 ? 2 : 6);
-        const int local = tid + 256 * (s - first);
-        const int row = 32 * bi + local / (16 * bi), c = 2 * (local % (16 * bi));
-        double2 v;
-        v.x = T[taddr(row, c)];
-        v.y = T[taddr(row, c + 1)];
-        *reinterpret_cast<double2 *>(A + (int64_t)row * lda + c) = v;
+        for (int s = 0; s < 12; ++s) {
+            const int bi = s < 2 ? 1 : (s < 6 ? 2 : 3);
+            const int first = s < 2 ? 0 : (s < 6 ? 2 : 6);
+            const int local = tid + 256 * (s - first);
+            const int row = 32 * bi + local / (16 * bi), c = 2 * (local % (16 * bi));
+            double2 v;
+            v.x = T[taddr(row, c)];
+            v.y = T[taddr(row, c + 1)];
+            *reinterpret_cast<double2 *>(A + (int64_t)row * lda + c) = v;
+        }
+        __syncthreads();
+        POTRF_STAMP(14);
+        // phase 2 of the !DIAG16 reference path: W = L^-1 in place, block column by block column, all four waves per pair
+        const int rt = wave >> 1, ct = wave & 1;           // this wave's 16x16 tile of a 32x32 block
+        phase2_pair<1, 0>(T, SC, rt, ct, l15, l4);
+        phase2_pair<2, 0>(T, SC, rt, ct, l15, l4);
+        phase2_pair<3, 0>(T, SC, rt, ct, l15, l4);
+        phase2_pair<2, 1>(T, SC, rt, ct, l15, l4);
+        phase2_pair<3, 1>(T, SC, rt, ct, l15, l4);
+        phase2_pair<3, 2>(T, SC, rt, ct, l15, l4);
     }
-    __syncthreads();
-
-    POTRF_STAMP(14);
-    // ---- phase 2: W = L^-1 in place, block column by block column ----------------------------------
-    // All six (block row, block column) pairs spelled out with compile-time block origins: with taddr() on run-time block indices
-    // the integer address arithmetic of a 32-deep product (sixteen operand addresses before its first MFMA) took as long as
-    // its eight MFMAs -- 7.2 us for the phase against 3.4 us of MFMA issue.
-    const int rt = wave >> 1, ct = wave & 1;           // this wave's 16x16 tile of a 32x32 block
-    double *SC = T + T_ELEMS;                          // one spare 32x32 block: S goes there, so W can be written in place
-    phase2_pair<1, 0>(T, SC, rt, ct, l15, l4);
-    phase2_pair<2, 0>(T, SC, rt, ct, l15, l4);
-    phase2_pair<3, 0>(T, SC, rt, ct, l15, l4);
-    phase2_pair<2, 1>(T, SC, rt, ct, l15, l4);
-    phase2_pair<3, 1>(T, SC, rt, ct, l15, l4);
-    phase2_pair<3, 2>(T, SC, rt, ct, l15, l4);
     POTRF_STAMP(15);
     {   // W leaves block by block: lower blocks from the LDS image (diagonal ones masked), zeros above
         double *wbase = W + lrow * 128 + 2 * lpair;
@@ -634,10 +869,22 @@ __device__ __forceinline__ void potrf128_body(double *T, double *A, int lda, dou
 #endif
 }
 
+// The LDS image is DYNAMIC shared memory (POTRF_LDS_BYTES, plus a pad where the launch asks for a compute unit of its own) and the
+// launch bounds name two workgroups per CU: with a 96 KB static array the compiler knows that one workgroup fits, gives the register
+// allocator all 512 registers and it keeps every hoisted LDS address alive (256 architectural VGPRs + 56 accumulators) -- but the
+// kernel has to fit on a SIMD beside a wave of the trailing update (264, tools/check_potrf_regs.sh).  Told "two per CU" the allocator
+// stays within 256 by rematerialising addresses, without a spill.
+constexpr unsigned POTRF_LDS_BYTES = POTRF_LDS_DOUBLES * sizeof(double);
+extern __shared__ __attribute__((aligned(16))) double potrf_lds_image[];
 template <bool DIAG16>
-__global__ __launch_bounds__(256) void potrf128_kernel(double *A, int lda, double *W, int *info, int base) {
-    __shared__ __attribute__((aligned(16))) double T[POTRF_LDS_DOUBLES];
+__global__ __launch_bounds__(256, 2) void potrf128_kernel(double *A, int lda, double *W, int *info, int base) {
     TGP_CHAIN_PRIO();
-    potrf128_body<DIAG16>(T, A, lda, W, info, base);
+    potrf128_body<DIAG16>(potrf_lds_image, A, lda, W, info, base);
+}
+// The same without the register cap (312 registers, no spills: 1 - 2 us faster per block in situ), for launches that get a compute
+// unit to themselves anyway: beside a queued bulk update (clear CUs, 128 KB of LDS asked for), or with nothing else on the chip.
+__global__ __launch_bounds__(256) void potrf128_solo_kernel(double *A, int lda, double *W, int *info, int base) {
+    TGP_CHAIN_PRIO();
+    potrf128_body<true>(potrf_lds_image, A, lda, W, info, base);
 }
 }  // namespace potrf_v2

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <vector>
 #include "../../include/tgp.h"
 
@@ -55,6 +56,8 @@ struct tgp_ctx {
     int chain_exclusive = 0;      // tgp_dd_set_exclusive: diagonal blocks of this context ask for a compute unit of their own
     unsigned *d_queue = nullptr;  // tile-queue counters of the persistent bulk update (TGP_NQUEUE launches x TGP_QUEUE_WORDS)
     unsigned *d_psync = nullptr;  // in-kernel hand-off counters of panel_mid_kernel (chol.hip): TGP_PSYNC_PANELS x 16 words, zeroed per factorisation
+    int mid_off = 0;              // an in-kernel hand-off of this context timed out once: panel_mid_kernel stays off for its life
+    int mid_allowed = 0;          // set by the solve entry points for the factorisation they are about to queue (alone on the chip, retry possible)
     int *d_info = nullptr;        // first failing pivot (1-based), 0 = ok
     int *h_info = nullptr;        // pinned mirror
     double *d_scal = nullptr;     // small device scalars (logdet, dot, ...)
@@ -191,7 +194,16 @@ int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, in
 int launch_kernel_dense(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,
                         const double *d_Y, int64_t m, int self, double *d_out);
 int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_info = false, int64_t n_data = -1);
-int tgp_potrf_info_rc(tgp_ctx *ctx, int info);      // device `info` word -> return code (negative: in-kernel hand-off timed out)
+int tgp_potrf_info_rc(tgp_ctx *ctx, int info);      // device `info` word -> return code (TGP_RC_HANDOFF: in-kernel hand-off timed out)
+#define TGP_RC_HANDOFF (-4)
+// Solves in flight in this process (host-boundary and device-resident solve calls, counted from entry to return).  Kernels whose
+// workgroups wait for each other inside one launch (panel_mid_kernel) are used only by a solve that found itself ALONE when it
+// started: workgroups are dealt to the eight XCDs in turn and each XCD starts its share when it has room, so "producers have
+// lower indices" guarantees progress for one such kernel on the chip, not for several that hold compute units while they wait
+// for workgroups another one keeps out (five contexts side by side did deadlock: bounded wait -> TGP_RC_HANDOFF).  Whoever enters
+// while another solve is in flight runs without it, so at most one solve at a time has waiting workgroups.  (Other PROCESSES on
+// the same GPU are invisible here: that case is what the bounded wait and the retry in api.hip are for.)
+extern std::atomic<int> tgp_solves_in_flight;
 // cross-stream hand-offs (handoff.hip).  Flag ids: 0, 1 the look-ahead of launch_potrf; TGP_FLAG_HEAD the "head columns
 // done" signal of a fused multi-GPU bulk launch, TGP_FLAG_HEAD_COUNT the word its workgroups count themselves in on.
 #define TGP_FLAG_HEAD 8
