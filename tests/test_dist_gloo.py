@@ -217,3 +217,56 @@ def test_sharded_pair_binning_gloo(tmp_path):
     world = 2
     mp.spawn(_pair_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
+
+
+def _stall_worker(rank, world, port, out_dir):
+    """rank 1 goes silent for a while in the middle of the factorisation; the watchdog limit is 1 s"""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["TGP_DIST_WATCHDOG_S"] = "1"
+    os.environ["TGP_DIST_FINISH"] = "0"
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _dist_helpers import NumpyLocalOps
+    from treegp_amd.dist import DistributedCholesky, DistStall, TorchComm
+    n = 1300
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0, 1, (n, 2))
+    d2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
+    K = np.exp(-0.5 * d2 / 0.1 ** 2) + np.diag(0.05 + 0.01 * rng.uniform(size=n))
+    comm = TorchComm()
+    if rank == 1:                                   # the third broadcast this rank takes part in comes 4 s late
+        calls, orig = [0], comm.broadcast
+
+        def late(t, src):
+            calls[0] += 1
+            if calls[0] == 3:
+                time.sleep(4.0)
+            return orig(t, src)
+        comm.broadcast = late
+    ch = DistributedCholesky(NumpyLocalOps(K, n, world, rank), comm)
+    t0 = time.monotonic()
+    try:
+        ch.factorize()
+        verdict = "finished"
+    except DistStall as e:
+        verdict = "stall %.2f %s" % (time.monotonic() - t0, str(e)[:80])
+    open(os.path.join(out_dir, "verdict%d" % rank), "w").write(verdict)
+    os._exit(0)                                     # the group is unusable after a time-out: no orderly shutdown to wait for
+
+
+def test_watchdog_turns_a_stalled_rank_into_an_error_on_every_rank(tmp_path):
+    """a rank that stops taking part must not leave the others waiting for ever.  With
+    TGP_DIST_WATCHDOG_S=1 the ranks that wait for the silent one raise DistStall after about a second (long before it
+    wakes up), and the late rank, whose partners are gone, gets the same error when it comes back -- every rank returns an
+    error, none hangs, none re-executes anything."""
+    world = 3
+    mp.spawn(_stall_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    verdicts = [open(os.path.join(str(tmp_path), "verdict%d" % r)).read() for r in range(world)]
+    for r in (0, 2):
+        assert verdicts[r].startswith("stall"), verdicts
+        assert float(verdicts[r].split()[1]) < 3.5, verdicts          # gave up after ~1 s, not after the 4 s nap
+    assert verdicts[1].startswith("stall"), verdicts

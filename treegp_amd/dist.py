@@ -82,6 +82,26 @@ def gathered_index(b, first, G):
     return r, b // G - first_round(first, r, G)
 
 
+class DistStall(RuntimeError):
+    """A rank saw no progress for TGP_DIST_WATCHDOG_S seconds: a collective whose partner never arrived, or device streams
+    that stopped advancing.  Raised on every rank that observes it (all do: every panel's collectives involve every rank);
+    the process group is unusable afterwards -- tear the processes down and start fresh ones."""
+
+
+def _is_stall(e):
+    """a backend error that means "my partner is late or gone" (time-out, or the connection of a partner that gave up first)"""
+    m = str(e).lower()
+    return any(w in m for w in ("timed out", "timeout", "connection closed", "connection reset", "broken pipe"))
+
+
+def watchdog_seconds():
+    """TGP_DIST_WATCHDOG_S: seconds without progress after which a rank gives up (default 300; 0 = wait for ever)."""
+    try:
+        return max(float(os.environ.get("TGP_DIST_WATCHDOG_S", "300")), 0.0)
+    except ValueError:
+        return 300.0
+
+
 class TorchComm(object):
     """Collectives over torch.distributed (nccl on GPUs; gloo for the CPU tests)."""
 
@@ -154,16 +174,42 @@ class TorchComm(object):
                              "reps": reps, "this_rank": {"allgather_GBps": res["allgather"], "p2p_GBps": res["p2p"]}}
         return self.gather_probe
 
+    def _finish(self, work, what):
+        """A collective of a host-blocking backend (gloo) under the watchdog: wait with a time limit and turn the backend's
+        time-out into DistStall.  RCCL's wait() only orders streams -- a stall there shows where the host synchronises
+        (DistributedCholesky._await_device)."""
+        limit = watchdog_seconds()
+        if self.native_gather or limit <= 0.0:
+            work.wait()
+            return
+        import datetime
+        try:
+            work.wait(datetime.timedelta(seconds=limit))
+        except RuntimeError as e:              # ProcessGroupGloo: "Timed out waiting ... for recv/send operation to complete",
+            if _is_stall(e):                   # or, when the partner has given up already, "Connection closed by peer"
+                raise DistStall("rank %d of %d: %s did not complete (limit %.1f s, TGP_DIST_WATCHDOG_S): %s"
+                                % (self.rank, self.size, what, limit, str(e).splitlines()[0]))
+            raise
+
     def broadcast(self, t, src):
-        self.dist.broadcast(t, src=src, group=self.group)
+        if self.native_gather:
+            self.dist.broadcast(t, src=src, group=self.group)
+        else:
+            self._finish(self.dist.broadcast(t, src=src, group=self.group, async_op=True), "a broadcast from rank %d" % src)
         if src != self.rank:
             self.bytes_in += t.numel() * t.element_size()
 
     def all_reduce_sum(self, t):
-        self.dist.all_reduce(t, group=self.group)
+        if self.native_gather:
+            self.dist.all_reduce(t, group=self.group)
+        else:
+            self._finish(self.dist.all_reduce(t, group=self.group, async_op=True), "an all-reduce")
 
     def all_reduce_max(self, t):
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        if self.native_gather:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        else:
+            self._finish(self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group, async_op=True), "an all-reduce")
 
     def all_gather_start(self, out, inp):
         """Non-blocking all-gather where the backend has one (RCCL runs it on its own stream, so it
@@ -199,7 +245,7 @@ class TorchComm(object):
                 chunk = out[r * n:(r + 1) * n]
                 if r == self.rank:
                     chunk.copy_(inp)
-                self.dist.broadcast(chunk, src=r, group=self.group)
+                self._finish(self.dist.broadcast(chunk, src=r, group=self.group, async_op=True), "a panel exchange (from rank %d)" % r)
 
 
 class _Work(object):
@@ -222,8 +268,18 @@ class _Works(object):
         # RCCL: wait() orders the CURRENT stream behind the transfers, so every stream that reads the panel calls it (side,
         # keep and main stream do).  gloo: wait() blocks the host until completion and must not be repeated on a finished
         # request (a second wait on a gloo send / receive never returns).
+        limit = 0.0 if self.stream_ordered else watchdog_seconds()
         for w in self.works:
-            w.wait()
+            if limit > 0.0:
+                import datetime
+                try:
+                    w.wait(datetime.timedelta(seconds=limit))
+                except RuntimeError as e:
+                    if _is_stall(e):
+                        raise DistStall("a point-to-point panel transfer did not complete (limit %.1f s, TGP_DIST_WATCHDOG_S)" % limit)
+                    raise
+            else:
+                w.wait()
         if not self.stream_ordered:
             self.works = ()
 
@@ -553,6 +609,10 @@ class HipLocalOps(object):
     def potrs_full(self, rhs):             # main stream: rhs (Np) <- L^-T L^-1 rhs with the replicated factor
         self._chk(self.lib.tgp_d_potrs(self.ctx, self._p(self.Afull), self._p(self.W), self.Np, self._p(rhs)), "tgp_d_potrs")
 
+    def streams_idle(self):
+        """everything queued on the rank's three streams has finished (polled by the watchdog instead of a blocking wait)"""
+        return self.main_stream.query() and self.side_stream.query() and self.keep_stream.query()
+
     def info(self):
         a = int(self.lib.tgp_dd_info(self.ctx, 1))
         b = int(self.lib.tgp_dd_info(self.ctx_side, 1))
@@ -831,9 +891,11 @@ class DistributedCholesky(object):
                 self.bytes_received += 8 * (G - 1) * stride
             h = comm.all_gather_start(self._tail_gather[:G * stride], ops.tail_send_view(k_fin, stride))
             h.wait()
+            self._await_device(chain_events)                     # (the finish synchronises the stream: watchdog first)
             tail_info = ops.tail_finish(k_fin, h.tensor, stride)
         # any rank's failure is everybody's failure; report the smallest failing index
         big = 1e18
+        self._await_device(chain_events)
         mine = ops.info()                                        # synchronises the stream
         if tail_info > 0 and not mine > 0:
             mine = tail_info
@@ -847,6 +909,29 @@ class DistributedCholesky(object):
         comm.all_reduce_max(t)
         first = -float(t[0])
         return 0 if first >= big else int(first)
+
+    def _await_device(self, chain_events):
+        """The watchdog of the device side (RCCL: collectives are stream-ordered, the host runs ahead and would block for ever
+        in the final synchronisation if a peer never arrived or a stream were parked on a flag nobody sets): poll instead of
+        blocking, and give up -- DistStall -- when neither the panel chain (its per-group events) nor the streams as a whole
+        have advanced for TGP_DIST_WATCHDOG_S seconds.  Local operations without streams (the tests' NumPy stand-in) have
+        nothing to wait for here: their collectives block on the host and time out in TorchComm."""
+        ops = self.ops
+        idle = getattr(ops, "streams_idle", None)
+        limit = watchdog_seconds()
+        if idle is None or limit <= 0.0:
+            return
+        import time
+        last, seen = time.monotonic(), -1
+        while not idle():
+            done = sum(1 for _, c1 in chain_events if c1.query())
+            now = time.monotonic()
+            if done != seen:
+                seen, last = done, now
+            elif now - last > limit:
+                raise DistStall("rank %d of %d: the device streams have not advanced for %.1f s (%d of %d panel-chain groups "
+                                "finished); TGP_DIST_WATCHDOG_S sets the limit" % (self.g, self.G, limit, max(seen, 0), len(chain_events)))
+            time.sleep(0.0005 if now - last < 0.05 else 0.01)
 
     def solve(self, y_full):
         """alpha (Np, replicated) = (L L^T)^-1 y; y_full is the replicated right-hand side (Np).
