@@ -531,6 +531,10 @@ def main():
                                     "chain_ms = its look-ahead stream (diagonal blocks, broadcasts, local solves, all-gathers, strips); "
                                     "gather_wait_ms = main stream stalled behind the chain between two bulk updates; "
                                     "bytes_received = counted from the tensors handed to the collectives")
+            out["panel_chain"] = {"form": getattr(engine, "chain_form", "gather"),
+                                  "note": "gather: the chain's strips wait for each all-gathered panel; bcast (TGP_DIST_CHAIN_BCAST=1): "
+                                          "their column operand rides on the diagonal block's broadcast and the all-gathers feed the "
+                                          "bulk update only -- the A/B for the first run on a real node"}
             out["gather_probe"] = getattr(engine.comm, "gather_probe", None)
             out["collective_backend"] = collective_backend()
             out["owner_map"] = "256-row blocks dealt block-cyclically, reflected every G blocks"

@@ -276,6 +276,13 @@ int tgp_dd_update2(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t 
  * tile columns col_lo..col_hi count from block kpanel+nseg.  nseg = 1 and 2 are tgp_dd_update / tgp_dd_update2.   */
 int tgp_dd_update_group(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g,
                         int nseg, const double *const *d_gathered, const int *cmax, int col_lo, int col_hi);
+/* Panel chain with the panel exchange off it (dist.py, TGP_DIST_CHAIN_BCAST; the seam is the same treegp/gp_interp.py:180-182):
+ * block b = kgroup + j of a group (1 <= j <= 3) against the j earlier panels of the group in one pass of depth 256 j, this rank's
+ * rows of b's two tile columns.  Rows: the rank's own, where they are stored (h_loff: the host copy of d_loff).  Columns: block
+ * b's rows of those panels, d_ext[s] (256 x 256 doubles, s = panel - kgroup), as appended by b's owner to the broadcast of its
+ * diagonal block; NULL on the owner.  Reads no all-gathered panel.                                                         */
+int tgp_dd_strip_left(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, const int64_t *d_loff, int64_t Np, int kgroup, int b,
+                      int G, int g, const double *d_ext);
 /* The bulk part of the update as a persistent grid that keeps `nres` (1..3) compute units per shader engine and XCD clear for
  * the panel chain (diagonal block, local solves, strips) that runs beside it on another stream; for the steps where this
  * rank's share of the bulk is shorter than the chain.  tgp_dd_queue_reset: once per factorisation, on the launching context;

@@ -83,7 +83,8 @@ class NumpyLocalOps(object):
         Kp[:n, :n] = Kfull
         self.blocks = [block_of(lb, g, G) for lb in range(self.nloc)]
         self.rows = {b: Kp[b * BLK:(b + 1) * BLK, :].copy() for b in self.blocks}     # full-width rows
-        self.bcast = torch.zeros(BCAST_ELEMS, dtype=torch.float64)
+        self.bcast_full = torch.zeros(BCAST_ELEMS + 3 * BLK * BLK, dtype=torch.float64)
+        self.bcast = self.bcast_full[:BCAST_ELEMS]
         self._info = 0
         self.Lfull = np.zeros((self.Np, self.Np)) if replicated else None       # the replicated factor
 
@@ -148,6 +149,32 @@ class NumpyLocalOps(object):
         for b in self.blocks:
             if b > k:
                 self.rows[b][:, k * BLK:(k + 1) * BLK] = self.rows[b][:, k * BLK:(k + 1) * BLK] @ Li.T
+
+    # panel chain with the panel exchange off it (TGP_DIST_CHAIN_BCAST): same interface as HipLocalOps
+    def bcast_payload(self, j):
+        return self.bcast_full[:BCAST_ELEMS + j * BLK * BLK]
+
+    def pack_ext(self, b, kgroup):
+        for m in range(kgroup, b):
+            dst = BCAST_ELEMS + (m - kgroup) * BLK * BLK
+            self.bcast_full[dst:dst + BLK * BLK] = torch.from_numpy(self.rows[b][:, m * BLK:(m + 1) * BLK].ravel())
+
+    def strip_left(self, b, kgroup, from_bcast):
+        """this rank's rows (blocks >= b) of block b's two tile columns -= sum over the panels kgroup .. b-1, one panel after the
+        other -- the products and their order are those of the right-looking strips, so the two forms agree bit for bit"""
+        for m in range(kgroup, b):
+            if from_bcast:
+                o = BCAST_ELEMS + (m - kgroup) * BLK * BLK
+                colop = self.bcast_full[o:o + BLK * BLK].numpy().reshape(BLK, BLK)
+            else:
+                colop = self.rows[b][:, m * BLK:(m + 1) * BLK]
+            for bi in self.blocks:
+                if bi < b:
+                    continue
+                for half in (0, 1):
+                    c0 = b * BLK + half * 128
+                    sl = slice(half * 128, (half + 1) * 128)
+                    self.rows[bi][:, c0:c0 + 128] -= sum([self.rows[bi][:, m * BLK:(m + 1) * BLK] @ colop[sl, :].T])
 
     def panel_send_view(self, k, cmax):
         out = torch.zeros(cmax * BLK * BLK, dtype=torch.float64)

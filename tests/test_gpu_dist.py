@@ -150,6 +150,24 @@ def _run_virtual_ranks(G, n):
     a_o, _ = O.gp_solve(O.kernel_matrix("gauss", X, **kw), y, y_err)
     yp_o = O.gp_predict(O.kernel_matrix("gauss", Xs, X, **kw), a_o)
     np.testing.assert_allclose(results[0][2], yp_o, rtol=0, atol=1e-10 * np.abs(yp_o).max())
+    return results
+
+
+@pytest.mark.parametrize("G,n,group", [(1, 5000, 4), (2, 6000, 4), (3, 7000, 3), (4, 6000, 2), (8, 9000, 4), (5, 2300, 4)])
+def test_panel_exchange_off_the_chain_virtual_ranks(G, n, group, monkeypatch):
+    """TGP_DIST_CHAIN_BCAST=1 with the real kernels: the strips of the panel chain read their column operand
+    from the diagonal block's broadcast (tgp_dd_strip_left) and never wait for an all-gathered panel.  Same results as the
+    single-GPU path and the oracle, and bit for bit the alpha and log-determinant of the default form (same products, same
+    order, one pass of depth 256 j instead of j passes of depth 256)."""
+    monkeypatch.setenv("TGP_DIST_GROUP", str(group))
+    monkeypatch.setenv("TGP_DIST_FINISH", "4")
+    monkeypatch.setenv("TGP_DIST_CHAIN_BCAST", "0")
+    ref = _run_virtual_ranks(G, n)
+    monkeypatch.setenv("TGP_DIST_CHAIN_BCAST", "1")
+    got = _run_virtual_ranks(G, n)
+    for r in range(G):
+        assert np.array_equal(ref[r][0], got[r][0]), "alpha differs on rank %d" % r
+        assert ref[r][1] == got[r][1]
 
 
 @pytest.mark.parametrize("G", [2, 3])

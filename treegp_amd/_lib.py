@@ -87,6 +87,7 @@ SIGNATURES = {
     "tgp_dd_update": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
     "tgp_dd_update2": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
     "tgp_dd_update_group": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int]),
+    "tgp_dd_strip_left": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "tgp_dd_update_group_queued": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "tgp_dd_update_group_fused": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int]),
     "tgp_dd_wait_head": (C.c_int, [_vp, _vp]),

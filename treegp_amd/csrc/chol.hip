@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256, 2) void syrk_segs_kernel(double *Abase, int64_
 // Gathered panel s holds the blocks > kpanel+s ([rank][cmax[s]][256][256]); tiles are counted from block kpanel+NSEG.
 template <int NSEG>
 struct DistSegs {
-    const double *P[NSEG];
+    const double *P[NSEG];    // gathered panel s: where the ROW operand (this rank's rows) is read from
+    const double *PB[NSEG];   // ... and the COLUMN operand (the rows of the tile column's block); == P[s] for a gathered panel
     int cmax[NSEG];
     int frg[NSEG];            // dist_first_round(kpanel + s + 1, g, G): this rank's first local index inside gathered panel s
 };
@@ -515,7 +516,7 @@ __device__ __forceinline__ void syrk_distn_tile(int64_t b, double *Aloc, const i
             const int first = kpanel + s + 1;                     // first block held by gathered panel s
             const int is = qi - S.frg[s], js = qj - first_round32(first, rj, G, M.ginv);
             sp.a[s] = S.P[s] + (((int64_t)g * S.cmax[s] + is) * TGP_PW + hi) * TGP_PW;
-            sp.b[s] = S.P[s] + (((int64_t)rj * S.cmax[s] + js) * TGP_PW + hj) * TGP_PW;
+            sp.b[s] = S.PB[s] + (((int64_t)rj * S.cmax[s] + js) * TGP_PW + hj) * TGP_PW;
         }
         double *c = Aloc + loff[bj] + ((int64_t)(qi - first_round32(bj, g, G, M.ginv)) * TGP_PW + hi) * TGP_PW + hj;
         if (half < 0) {
@@ -1003,10 +1004,11 @@ int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, 
 template <int NSEG>
 static void launch_distn(hipStream_t st, unsigned grid, double *d_Aloc, const int64_t *d_loff, int kpanel, int G, int g,
                          const double *const *P, const int *cmax, int col_lo, int ncol, int nrows, const DistMap &M, int nres,
-                         unsigned *queue) {
+                         unsigned *queue, const double *const *PB) {
     DistSegs<NSEG> S;
     for (int s = 0; s < NSEG; ++s) {
         S.P[s] = P[s];
+        S.PB[s] = PB ? PB[s] : P[s];
         S.cmax[s] = cmax[s];
         S.frg[s] = (int)dist_first_round(kpanel + s + 1, g, G);
     }
@@ -1018,8 +1020,11 @@ static void launch_distn(hipStream_t st, unsigned grid, double *d_Aloc, const in
 
 // `head_cols` > 0: the fused form (DistMap) -- tile columns [col_lo, col_lo + head_cols) first, then the rest up to col_hi,
 // one launch; tgp_head_flag() tells which flag / sequence number the launch publishes when the head is done.
+// d_PB (optional): separate bases for the column operand of each segment (tgp_dd_strip_left: rows from this rank's own
+// storage, columns from the broadcast)
 int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
-                      const double *const *d_P, const int *cmax, int col_lo, int col_hi, int queue_nres, int head_cols) {
+                      const double *const *d_P, const int *cmax, int col_lo, int col_hi, int queue_nres, int head_cols,
+                      const double *const *d_PB) {
     TGP_ARG(nseg >= 1 && nseg <= 4 && head_cols >= 0);
     const int64_t nB = Np / TGP_PW;
     const int64_t nloc = dist_panel_blocks(kpanel + nseg, nB, g, G);      // local blocks > kpanel + nseg - 1
@@ -1104,10 +1109,10 @@ int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64
         ++ctx->dist_nqueue;
     }
     switch (nseg) {
-        case 1: launch_distn<1>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue); break;
-        case 2: launch_distn<2>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue); break;
-        case 3: launch_distn<3>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue); break;
-        default: launch_distn<4>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue); break;
+        case 1: launch_distn<1>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue, d_PB); break;
+        case 2: launch_distn<2>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue, d_PB); break;
+        case 3: launch_distn<3>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue, d_PB); break;
+        default: launch_distn<4>(st, grid, d_Aloc, d_loff, kpanel, G, g, d_P, cmax, col_lo, (int)ncol, nrows, M, nres, queue, d_PB); break;
     }
     TGP_HIP(hipGetLastError());
     return 0;

@@ -111,6 +111,40 @@ int tgp_dd_update_group(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int
     return launch_syrk_distn(ctx, d_Aloc, d_loff, Np, kpanel, G, g, nseg, d_gathered, cmax, col_lo, col_hi);
 }
 
+// Left-looking strip of the panel chain with the panel exchange OFF the chain (dist.py: TGP_DIST_CHAIN_BCAST): block b = kgroup + j
+// (1 <= j <= 3) is brought up to date against the j earlier panels of its group, kgroup .. b-1, in one pass of depth 256 j -- this
+// rank's rows (blocks >= b) of b's two tile columns.  The ROW operand is the rank's own rows of those panels, read where they are
+// stored; the COLUMN operand is block b's rows of them: d_ext[s] (256 x 256, s = panel - kgroup), which the owner of b appends to
+// the broadcast of its diagonal block; d_ext == NULL on the owner itself, whose own rows they are.  No all-gathered panel is
+// read: the panel chain no longer waits for the exchange of whole panels, which then feeds the bulk update only.
+// (Same kernel as tgp_dd_update_group: gathered panel s is [rank][cmax][256][256] and the kernel reads slot g for the rows and
+//  slot owner(b) for the columns, so the two bases are placed such that those slots fall on the local rows / on d_ext[s].)
+int tgp_dd_strip_left(tgp_ctx *ctx, double *d_Aloc, const int64_t *h_loff, const int64_t *d_loff, int64_t Np, int kgroup, int b, int G,
+                      int g, const double *d_ext) {
+    const int j = b - kgroup;
+    TGP_ARG(d_Aloc && h_loff && d_loff && j >= 1 && j <= 3 && G >= 1 && g >= 0 && g < G && Np % TGP_PW == 0 && b < Np / TGP_PW);
+    const int64_t nB = Np / TGP_PW, blk = (int64_t)TGP_PW * TGP_PW;
+    const int rj = dist_owner(b, G);
+    TGP_ARG(d_ext || rj == g);
+    const double *PA[3], *PB[3];
+    int cm[3];
+    for (int s = 0; s < j; ++s) {
+        const int m = kgroup + s;
+        int64_t c = 0;                                              // most blocks > m any rank holds (dist.py: panel_cmax)
+        for (int r = 0; r < G; ++r) {
+            const int64_t n = dist_panel_blocks(m + 1, nB, r, G);
+            c = n > c ? n : c;
+        }
+        cm[s] = (int)c;
+        // this rank's rows of panel m below its diagonal block, as it would send them (dist.py: panel_send_view)
+        const double *mine = d_Aloc + h_loff[m] + (dist_owner(m, G) == g ? blk : 0);
+        PA[s] = mine - (int64_t)g * c * blk;
+        const int64_t js = b / G - dist_first_round(m + 1, rj, G);  // block b among owner(b)'s blocks > m
+        PB[s] = (rj == g && !d_ext) ? PA[s] : d_ext + s * blk - ((int64_t)rj * c + js) * blk;
+    }
+    return launch_syrk_distn(ctx, d_Aloc, d_loff, Np, kgroup, G, g, j, PA, cm, 0, 2, 0, 0, PB);
+}
+
 // The bulk update as a persistent grid that keeps `nres` (1 .. 3) compute units per shader engine clear for the panel chain
 // running on another stream / context (chol.hip: syrk_distn_queue_kernel); tgp_dd_queue_reset once per factorisation, on
 // the stream of the context that launches the bulk; tgp_dd_set_exclusive(ctx, 1) on the CHAIN's context makes its diagonal

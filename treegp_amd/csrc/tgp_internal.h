@@ -221,7 +221,8 @@ int launch_kbuild_lower_dist(tgp_ctx *ctx, const tgp_kernel *k, const double *d_
 int launch_factor_diag256(tgp_ctx *ctx, double *blk, double *W0, double *W1, int base, bool latency = false);
 int launch_trsm_rows(tgp_ctx *ctx, double *rows, int ntiles, const double *Lkk, const double *W0, const double *W1, double *keepW = nullptr);
 int launch_syrk_distn(tgp_ctx *ctx, double *d_Aloc, const int64_t *d_loff, int64_t Np, int kpanel, int G, int g, int nseg,
-                      const double *const *d_P, const int *cmax, int col_lo, int col_hi, int queue_nres = 0, int head_cols = 0);
+                      const double *const *d_P, const int *cmax, int col_lo, int col_hi, int queue_nres = 0, int head_cols = 0,
+                      const double *const *d_PB = nullptr);
 int launch_diag256_fwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y);
 int launch_diag256_bwd(tgp_ctx *ctx, const double *Lkk, const double *W0, const double *W1, double *y, const double *s);
 int launch_fwd_update_rows(tgp_ctx *ctx, const double *Lrows, int64_t rows, const double *z, double *yrows);

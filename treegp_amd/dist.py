@@ -394,7 +394,10 @@ class HipLocalOps(object):
         slack = (max(self.cmax0, FINISH_BLOCKS_MAX) + 1) * BLK * BLK
         self.A = torch.empty(int(self.loff[-1]) + slack, dtype=torch.float64, device=device)
         self.W = torch.empty(self.Np * 128, dtype=torch.float64, device=device)
-        self.bcast = torch.empty(BCAST_ELEMS, dtype=torch.float64, device=device)
+        # [L_kk | W0 | W1] of a panel's diagonal block, and behind it room for the owner's rows of up to three earlier panels of
+        # the group (TGP_DIST_CHAIN_BCAST: the column operands of the chain's strips travel with the diagonal block)
+        self.bcast_full = torch.empty(BCAST_ELEMS + 3 * BLK * BLK, dtype=torch.float64, device=device)
+        self.bcast = self.bcast_full[:BCAST_ELEMS]
         self.d_loff = torch.from_numpy(self.loff).to(device)
         self.kc = spec.to_c()
         self.main_stream = torch.cuda.current_stream(device)
@@ -481,6 +484,23 @@ class HipLocalOps(object):
         skip = BLK if owner(k, self.G) == self.g else 0
         o = int(self.loff[k]) + skip * BLK
         return self.A[o:o + cmax * BLK * BLK]
+
+    # -- panel chain with the panel exchange off it (TGP_DIST_CHAIN_BCAST) -------------------------
+    def bcast_payload(self, j):
+        """what the owner of the j-th panel of a group broadcasts: the diagonal block and its inverses, then its rows of the j
+        earlier panels of the group"""
+        return self.bcast_full[:BCAST_ELEMS + j * BLK * BLK]
+
+    def pack_ext(self, b, kgroup):         # side stream, owner of block b: its rows of panels kgroup .. b-1 behind the diagonal block
+        for m in range(kgroup, b):
+            src = int(self.loff[m]) + (b // self.G - first_round(m, self.g, self.G)) * BLK * BLK
+            dst = BCAST_ELEMS + (m - kgroup) * BLK * BLK
+            self.bcast_full[dst:dst + BLK * BLK].copy_(self.A[src:src + BLK * BLK])
+
+    def strip_left(self, b, kgroup, from_bcast):   # side stream: block b's columns against panels kgroup .. b-1, depth 256 (b - kgroup)
+        ext = self._p(self.bcast_full, BCAST_ELEMS) if from_bcast else None
+        self._chk(self.lib.tgp_dd_strip_left(self.ctx_side, self._p(self.A), self._hl(), self._p(self.d_loff), self.Np, kgroup, b,
+                                             self.G, self.g, ext), "tgp_dd_strip_left", self.ctx_side)
 
     def update(self, k, gathered, cmax, col_lo=0, col_hi=-1, side=False):
         ctx = self.ctx_side if side else self.ctx
@@ -672,6 +692,7 @@ class DistributedCholesky(object):
         self.update_launches = 0
         self.chain_ms = 0.0           # side stream: panel chains (diagonal blocks, broadcasts, local solves, gathers, strips)
         self.wait_ms = 0.0            # main stream: stalled behind the chain / the gathers between two bulk updates
+        self.chain_form = "gather"    # "bcast": the last factorize() ran with the panel exchange off the chain (TGP_DIST_CHAIN_BCAST)
         self.bytes_received = 0       # payload this rank received during the last factorize(): counted by the communicator from
                                       # the tensors handed to its collectives (TorchComm.bytes_in); for communicators that do
                                       # not count (tests' in-process ones) the schedule's own sum, ~ 4 N^2 B (G-1)/G
@@ -705,14 +726,32 @@ class DistributedCholesky(object):
         # also build the replicated factor for the solves (a world of one's share already is that factor: no copies)
         keep = bool(getattr(ops, "replicated", False)) and bool(getattr(ops, "keep_copies", True))
 
-        def factor_and_gather(k, buf):
+        # TGP_DIST_CHAIN_BCAST=1: the panel exchange OFF the chain.  Inside a group, what panel b's factorisation and local solves
+        # need from other ranks of the earlier panels of the group is only block b's rows of them (256 x 256 each, held by b's
+        # owner since its own local solves): the owner appends them to the broadcast of its diagonal block, every rank brings
+        # its rows of b's columns up to date in one left-looking strip (depth 256 j, tgp_dd_strip_left), and the chain per
+        # panel is strip -> diagonal block -> broadcast -> strip -> local solves with no exchange of a whole panel in it: the
+        # all-gathers are started as before but only the bulk update (main stream) and the replicated factor wait for them.
+        # Same arithmetic in the same order as the right-looking strips: the factor is bit-identical.  Off by default until a
+        # real node has measured it.
+        chain_bcast = os.environ.get("TGP_DIST_CHAIN_BCAST", "0") == "1" and hasattr(ops, "strip_left") and GS > 1
+        self.chain_form = "bcast" if chain_bcast else "gather"
+
+        def factor_and_gather(k, buf, kgroup=None):
             """panel k on the side stream: diagonal block on its owner, broadcast, local solves, all-gather"""
             own = owner(k, G)
+            j = (k - kgroup) if (chain_bcast and kgroup is not None) else 0
+            if j > 0 and g == own:
+                ops.strip_left(k, kgroup, False)                 # the owner's own rows: every operand is local
             if g == own:
                 ops.factor_diag(k)
-            comm.broadcast(ops.bcast, own)
+                if j > 0:
+                    ops.pack_ext(k, kgroup)
+            comm.broadcast(ops.bcast_payload(j) if j > 0 else ops.bcast, own)
             if g != own:
-                self.bytes_received += 8 * BCAST_ELEMS
+                self.bytes_received += 8 * (BCAST_ELEMS + j * BLK * BLK)
+                if j > 0:
+                    ops.strip_left(k, kgroup, True)
             if keep:
                 ops.keep_diag(k)
             ops.trsm(k)
@@ -746,7 +785,7 @@ class DistributedCholesky(object):
             for j in range(GS):
                 if k + j >= nB:
                     break
-                if j > 0:
+                if j > 0 and not chain_bcast:
                     w, c = out[j - 1]
                     w.wait()                                     # side stream: panel k+j-1 is on every rank
                     # panel k+j-1 against the tile columns of ALL later panels of the group, depth 256: every strip on the
@@ -754,7 +793,7 @@ class DistributedCholesky(object):
                     # before it, depth 256 j: 24 / 41 / 59 us instead of 3 x 24 in the chain-bound phase,
                     # profiles/r04_strips_ab.txt)
                     ops.update_group(k + j - 1, [w.tensor], [c], 0, 2 * (GS - j), side=True)
-                out.append(factor_and_gather(k + j, bufs[j]))
+                out.append(factor_and_gather(k + j, bufs[j], k))
                 if keep and out[-1][0] is not None:
                     ops.keep_rows(k + j, out[-1][0].tensor, out[-1][1], out[-1][0])   # copied on the keep stream, off this chain
             if keep:
@@ -1190,6 +1229,7 @@ class DistEngine(object):
                             ("chain_ms", chol.chain_ms), ("gather_wait_ms", chol.wait_ms), ("bytes_received", chol.bytes_received),
                             ("solves", 1)):
                 self._add(name, v)
+        self.chain_form = chol.chain_form                    # which panel chain ran (goes into the N > 1 bench line)
         factor = None
         if keep:
             if not o.replicated:
