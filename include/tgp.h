@@ -55,7 +55,11 @@ typedef struct {
 } tgp_kernel;
 
 /* ---- context ------------------------------------------------------------------------ */
-int tgp_init(const int *devices, int ndev, tgp_ctx **out);   /* ndev must be 1 (one process per GPU) */
+/* One context = one GPU: ndev must be 1.  SURVEY 8(b)'s "one process drives the node's GPUs" (ndev > 1) is served one level up:
+ * treegp_amd/dist_pool.py starts one worker process per GPU, each with a context of its own and an RCCL group among them, behind
+ * GPInterpolation(backend="dist") in an ordinary single-process script; the tgp_dd_* entry points below are the
+ * per-rank building blocks those workers (and torchrun ranks) call.                                                          */
+int tgp_init(const int *devices, int ndev, tgp_ctx **out);
 void tgp_destroy(tgp_ctx *ctx);
 const char *tgp_last_error(tgp_ctx *ctx);
 const char *tgp_version(void);

@@ -358,3 +358,21 @@ def test_api_script_on_rccl_world_of_one():
     r = subprocess.run([sys.executable, os.path.join(HERE, "_api_dist_script.py"), "2500", "700"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "api dist ok: world 1" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("G,how", [(2, "explicit"), (4, "explicit"), (2, "env")])
+def test_unmodified_single_process_script_reaches_the_multi_gpu_route(G, how):
+    """VERDICT r4 item 4 / SURVEY 8(b): an ordinary ``python script.py`` -- no torchrun, no torch.distributed in the script --
+    gets the multi-GPU route from ``GPInterpolation(backend="dist")`` (or from TGP_DIST=1 alone): the parent starts G worker
+    processes once (treegp_amd/dist_pool.py; here all on this box's one GPU over gloo), ships the arrays through shared
+    memory and returns rank 0's results -- equal to the single-GPU API at 1e-10, LinAlgError included, workers reused."""
+    env = dict(os.environ, TGP_DIST_BACKEND="gloo", TGP_ONE_DEVICE="1", TGP_DIST_POOL_WORLD=str(G), TGP_DIST_WATCHDOG_S="120")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TGP_DIST"):
+        env.pop(k, None)
+    if how == "env":
+        env["TGP_DIST"] = "1"
+        env["TGP_DIST_MIN_N"] = "1000"
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_api_pool_script.py"), "3000", "1500", how], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "POOL_OK world=%d" % G in r.stdout, r.stdout[-2000:]

@@ -1301,6 +1301,8 @@ def disable():
     if getattr(_tls, "engine", None) is not None:
         _tls.engine = None
     else:
+        if hasattr(_process_engine, "close"):
+            _process_engine.close()                        # a worker pool: stop its processes
         _process_engine = None
     _ops.set_pair_comm(None)
 
@@ -1320,14 +1322,33 @@ def _current_engine(n=None):
         import sys
         td = sys.modules.get("torch.distributed")
         if td is None or not (td.is_available() and td.is_initialized()):
+            eng = _pool_engine(explicit=False)             # an ordinary single-process script: worker pool over the visible GPUs
+            if eng is not None:
+                return eng
             if not _warned_no_group:
                 import warnings
-                warnings.warn("TGP_DIST=1 but torch.distributed is not initialised in this process: staying on the "
-                              "single-GPU path (init_process_group first, or call treegp_amd.dist.enable(comm))",
+                warnings.warn("TGP_DIST=1 but torch.distributed is not initialised in this process and there is one GPU (or "
+                              "TGP_DIST_POOL=0, or this is a rank of a torchrun job): staying on the single-GPU path "
+                              "(init_process_group first, or call treegp_amd.dist.enable(comm))",
                               RuntimeWarning, stacklevel=3)
                 _warned_no_group = True
             return None
         eng = enable()
+    return eng
+
+
+def _pool_engine(explicit):
+    """The worker-pool engine of this process (dist_pool.py), started on first need: for a process that is not a rank of a
+    torchrun job.  ``explicit`` (backend="dist"): even a pool of one worker is started; otherwise (TGP_DIST=1) only with more
+    than one worker to gain from.  None when a pool may not or need not be started."""
+    global _process_engine
+    from . import dist_pool
+    if not dist_pool.pool_allowed():
+        return None
+    if not explicit and dist_pool.default_world() < 2:
+        return None
+    eng = dist_pool.PoolEngine()
+    _process_engine = eng
     return eng
 
 
@@ -1364,7 +1385,11 @@ def engine_for(n):
             if td is not None and td.is_available() and td.is_initialized():
                 eng = enable()
             else:
-                raise RuntimeError('backend="dist" needs treegp_amd.dist.enable(comm) or an initialised torch.distributed')
+                eng = _pool_engine(explicit=True)          # an unmodified single-process script: one worker per visible GPU
+                if eng is None:
+                    raise RuntimeError('backend="dist" needs treegp_amd.dist.enable(comm) or an initialised torch.distributed '
+                                       '(the worker pool of dist_pool.py is switched off here: TGP_DIST_POOL=0, or this process is '
+                                       'a rank of a torchrun job that has not called init_process_group yet)')
         return eng
     eng = _current_engine(n)
     return eng if (eng is not None and n >= eng.min_n) else None
