@@ -390,9 +390,22 @@ def test_multi_gpu_route_selection(monkeypatch):
     finally:
         dist.disable()
     assert dist.engine_for(10 ** 6) is None
-    with pytest.raises(RuntimeError, match="backend"):
-        with dist.scope("dist"):
-            dist.engine_for(5)                                           # no engine, no process group: loud
+    # backend="dist" with no engine and no process group: an ordinary single-process script gets the worker pool
+    # (treegp_amd/dist_pool.py; created here, its processes only start with the first solve) ...
+    for v in ("RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID", "TGP_DIST_POOL"):
+        monkeypatch.delenv(v, raising=False)
+    with dist.scope("dist"):
+        pool_eng = dist.engine_for(5)
+    assert type(pool_eng).__name__ == "PoolEngine" and pool_eng.pool is None
+    assert dist.engine_for(5) is None and dist.engine_for(10 ** 9) is pool_eng     # from then on it is this process's engine
+    dist.disable()
+    # ... unless pools are switched off, or this process is itself a rank of a torchrun job: then it is loud
+    for var, val in (("TGP_DIST_POOL", "0"), ("RANK", "0")):
+        monkeypatch.setenv(var, val)
+        with pytest.raises(RuntimeError, match="backend"):
+            with dist.scope("dist"):
+                dist.engine_for(5)
+        monkeypatch.delenv(var)
     assert dist.engine_for(5) is None                                    # (the scope was left properly)
     monkeypatch.setenv("TGP_DIST", "1")
     monkeypatch.setattr(dist, "_warned_no_group", False)
