@@ -99,6 +99,9 @@ void tgp_factor_free(tgp_ctx *ctx, tgp_factor *f);
 /* gives the handle up but leaves its device memory with the context as the factor cache of the next solve of the same size
  * (no hipFree + hipMalloc of the packed matrix between two fits of one size); freed by tgp_destroy or a solve of another size */
 void tgp_factor_release(tgp_ctx *ctx, tgp_factor *f);
+/* the context gives back the device memory it holds between calls (factor cache, inverse slabs, scratch); they are allocated
+ * again on demand.  For a process that is about to allocate elsewhere on the same GPU.                                     */
+int tgp_release_caches(tgp_ctx *ctx);
 /* a handle on a factor in the CALLER's device memory (d_A: tgp_panel_elems(Np) packed doubles, d_W: Np x 128, as
  * tgp_d_potrf leaves them) -- the multi-GPU driver's replicated factor; tgp_factor_free never frees d_A / d_W of it.
  * Serves the same reference lines as a kept factor: gp_interp.py:184-192 (covariance), README.rst:28 (several fields). */

@@ -29,6 +29,7 @@ _i64 = C.c_int64
 SIGNATURES = {
     "tgp_init": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
     "tgp_destroy": (None, [_vp]),
+    "tgp_release_caches": (C.c_int, [_vp]),
     "tgp_last_error": (C.c_char_p, [_vp]),
     "tgp_version": (C.c_char_p, []),
     "tgp_device_count": (C.c_int, []),
@@ -167,6 +168,14 @@ def set_thread_ctx(ctx):
     """This thread's default context (None = back to the process-wide one).  A context serves one caller at a time, so
     threads that compute side by side -- the virtual ranks of the multi-GPU tests -- each bring their own."""
     _thread.ctx = ctx
+
+
+def release_process_caches(device):
+    """the process-wide context of `device`, if one exists, gives back its factor cache / slabs / scratch (tgp_release_caches)"""
+    with _lock:
+        ctx = _ctx.get(int(device))
+    if ctx is not None:
+        load_library().tgp_release_caches(ctx)
 
 
 def get_ctx(device=None):

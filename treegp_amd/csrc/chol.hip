@@ -372,7 +372,9 @@ __device__ __forceinline__ void head_done(const HeadSignal &h) {
     if (threadIdx.x < 64) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (threadIdx.x == 0) {
-            const unsigned old = __hip_atomic_fetch_add(h.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // acquire + release: the workgroup that sees the target value has then acquired every other head workgroup's
+            // release, so the flag store below orders ALL head tiles by the memory model, not by fence placement
+            const unsigned old = __hip_atomic_fetch_add(h.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             if (old + 1u == h.target) __hip_atomic_store(h.flag, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }

@@ -390,8 +390,17 @@ class HipLocalOps(object):
         self.loff = np.array([self.lib.tgp_dist_panel_off(p, self.Np, G, g) for p in range(self.nB + 1)], dtype=np.int64)
         self.nloc = panel_blocks(0, self.nB, g, G)
         self.cmax0 = panel_cmax(1, self.nB, G)
-        # the padded send views of the panel exchange and of the replicated finish may overrun the share
-        slack = (max(self.cmax0, FINISH_BLOCKS_MAX) + 1) * BLK * BLK
+        # the padded send views of the panel exchange and of the replicated finish may overrun the share: a view is as long as
+        # the LONGEST rank's (panel: cmax blocks; finish from panel k0: the largest tail of any rank), so this rank's needs that
+        # minus its own in slack -- taken over every possible finish start (with a finish of 64 blocks on 3 ranks the difference
+        # reaches 75 blocks, more than the 65 a fixed rule allowed: ADVICE r4)
+        slack_blocks = self.cmax0 + 1
+        own_total = int(self.lib.tgp_dist_local_elems(self.Np, G, g))
+        for k0 in range(max(self.nB - FINISH_BLOCKS_MAX, 0), self.nB):
+            tails = [int(self.lib.tgp_dist_local_elems(self.Np, G, r)) - int(self.lib.tgp_dist_panel_off(k0, self.Np, G, r)) for r in range(G)]
+            need = max(tails) - (own_total - int(self.loff[k0]))
+            slack_blocks = max(slack_blocks, -(-need // (BLK * BLK)) + 1)
+        slack = slack_blocks * BLK * BLK
         self.A = torch.empty(int(self.loff[-1]) + slack, dtype=torch.float64, device=device)
         self.W = torch.empty(self.Np * 128, dtype=torch.float64, device=device)
         # [L_kk | W0 | W1] of a panel's diagonal block, and behind it room for the owner's rows of up to three earlier panels of
@@ -593,7 +602,9 @@ class HipLocalOps(object):
 
     def tail_send_view(self, k0, stride):
         o = int(self.loff[k0])
-        return self.A[o:o + stride]
+        v = self.A[o:o + stride]
+        assert v.numel() == stride, "the share's slack is too small for the finish's send view (%d of %d doubles)" % (v.numel(), stride)
+        return v
 
     def tail_finish(self, k0, gathered, stride):
         """main stream: assemble the packed trailing matrix of order Np - 256 k0 from everybody's shares (`gathered`, [G][stride]),
@@ -621,6 +632,9 @@ class HipLocalOps(object):
         finally:
             self.lib.tgp_set_side_stream(self.ctx, None)
         self._chk(rc, "tgp_d_potrf (finish)")
+        # the tail-LOCAL index of a failed pivot is in `rc`; what tgp_d_potrf left in the context's info word must not be read
+        # as a global index by info() afterwards (a LinAlgError naming minor 3560 for a failure at 65 000: ADVICE r4)
+        self.lib.tgp_dd_info(self.ctx, 1)
         if not own_factor:
             self._chk(self.lib.tgp_dd_tail_scatter(self.ctx, tail, self.Np, k0, self.G, self.g, self._p(self.A), self._p(self.d_loff)),
                       "tgp_dd_tail_scatter")
@@ -936,8 +950,8 @@ class DistributedCholesky(object):
         big = 1e18
         self._await_device(chain_events)
         mine = ops.info()                                        # synchronises the stream
-        if tail_info > 0 and not mine > 0:
-            mine = tail_info
+        if tail_info > 0:
+            mine = min(mine, tail_info) if mine > 0 else tail_info      # an earlier failure of the chain has the smaller index
         self.update_ms = sum(a.elapsed_time(b) for a, b in events) if events else 0.0
         self.chain_ms = sum(a.elapsed_time(b) for a, b in chain_events) if chain_events else 0.0
         self.wait_ms = sum(a.elapsed_time(b) for a, b in wait_events) if wait_events else 0.0
@@ -1158,6 +1172,9 @@ class DistEngine(object):
                 # memory the next vote would see, and a decision that flips under the caller turns return_cov from working into
                 # NotImplementedError after all the collective work is done
                 if Np not in self._replicate:
+                    # what this process's single-GPU context still holds from earlier solves (17 GB per N = 65 536 factor) is
+                    # given back first: memory parked there must not make ONE rank vote "no room" or run out later
+                    self._lib.release_process_caches(self.device.index if self.device.index is not None else 0)
                     self._replicate[Np] = agree_replicate(self.comm, lambda env: local_replicate_vote(self.lib, Np, G, self.device, env))
                 replicate = self._replicate[Np]
             ops = HipLocalOps(self.ctx, spec, n, G, g, self.device, replicate=replicate, streams=self.streams)

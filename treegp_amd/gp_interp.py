@@ -93,9 +93,17 @@ class GPInterpolation(object):
         self._alpha = None
         self._set_factor(None, None)
 
+    def __del__(self):
+        # a dropped object hands its factor's memory to the context (the next fit of this size allocates nothing: at N = 65 536
+        # a hipFree + hipMalloc of 17 GB between two fits otherwise); raw ops.Factor handles free their memory by default
+        try:
+            self._set_factor(None, None)
+        except Exception:
+            pass
+
     def _set_factor(self, factor, key):
         if getattr(self, "_factor", None) is not None:
-            self._factor.free()
+            self._factor.free(keep_memory=True)        # a refit of this object solves the same size next: its memory is reused
         self._factor, self._factor_key = factor, key
 
     @staticmethod
@@ -196,7 +204,7 @@ class GPInterpolation(object):
             try:
                 alphas = ops.factor_solve(factor, R)
             finally:
-                factor.free()
+                factor.free(keep_memory=True)
             if spec is not None:
                 pred = np.stack([ops.gp_predict(spec, self._X, a, X) for a in alphas])
             else:

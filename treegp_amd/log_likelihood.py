@@ -111,7 +111,7 @@ class log_likelihood(object):
                 try:
                     g4 = ops.gp_loglik_grad(spec, factor, self.X, alpha, ctx=ctx)
                 finally:
-                    factor.free()
+                    factor.free(keep_memory=True)          # the next evaluation solves the same size on this context
             ll = -0.5 * chi2 - (0.5 * self.ndata) * np.log(2.0 * np.pi) - 0.5 * log_det
         except (np.linalg.LinAlgError, FloatingPointError, ValueError):
             return -np.inf, np.zeros(ntheta)

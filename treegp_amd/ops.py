@@ -34,10 +34,12 @@ class Factor(object):
         self._ctx, self._h, self.n = ctx, handle, n
         self._keepalive = keepalive          # a borrowed handle (tgp_factor_borrow): the tensors that own its memory
 
-    def free(self, keep_memory=True):
-        """keep_memory: the packed matrix stays with the context as the cache of its next solve of this size (tgp_factor_release)
-        -- dropping one GPInterpolation and fitting the next then costs no 17 GB hipFree + hipMalloc at N = 65 536;
-        False returns it to the device at once (tgp_factor_free; TGP_FACTOR_FREE=1 makes that the default)"""
+    def free(self, keep_memory=False):
+        """Default: the memory goes back to the device at once (tgp_factor_free) -- a dropped handle must not leave 17 GB (N =
+        65 536; 69 GB at 131 072) attached to its context, where it can turn another solve's allocation -- the multi-GPU engine's
+        replicated factor, on one rank only -- into an out-of-memory error.  keep_memory=True (the refit paths of
+        GPInterpolation and the ML loop, which solve the same size again right away): the packed matrix stays with the context
+        as the cache of its next solve of this size (tgp_factor_release), no hipFree + hipMalloc; TGP_FACTOR_FREE=1 overrides."""
         if self._h:
             lib = _lib.load_library()
             if keep_memory and os.environ.get("TGP_FACTOR_FREE") != "1":
