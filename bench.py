@@ -76,6 +76,17 @@ def cpu_baseline(n_s, m_s, n_headline):
     c2 = R.config2_sample(threads)
     key32 = [k for k in c2 if k.startswith("extrapolated_n")][0]
     c2[key32]["cholesky_s_at_configs1_gflops"] = 32768 ** 3 / 3.0 / (gf * 1e9)      # dpotrf at N = 32768 at configs[1]'s measured rate
+    # the pair binning of configs[2] has NO reference CPU baseline here: it lives in TreeCorr (treegp/two_pcf.py:297-305, 330-334),
+    # absent from this image.  What can be timed is the oracle's brute-force restatement -- not the reference -- on a sample.
+    from oracle import gp_oracle as O
+    import time as _time
+    n_pb = 4096
+    Xp, yp, ep, _ = star_field(n_pb, 16)
+    t0 = _time.perf_counter()
+    O.kk_log(Xp[:, 0], Xp[:, 1], yp - yp.mean(), 1.0 / ep ** 2, 1.0 / np.sqrt(n_pb), 0.7, 20)
+    t_pb = _time.perf_counter() - t0
+    c2["pair_binning"] = ("no CPU baseline: TreeCorr absent; oracle brute force %.2f s at N = %d = %.2e pairs/s on one core "
+                          "(restatement, not the reference)" % (t_pb, n_pb, n_pb * (n_pb - 1) / 2.0 / t_pb))
     return {
         "configs": {"configs[0]": dict(c0, sample="in full: 1-D AnisotropicRBF N=512 / M=1024, the reference's call sequence, "
                                                   "1 warm-up + 5 passes, median per phase"),
@@ -266,11 +277,51 @@ def configs_measured(lib, ctx, ops, _lib):
     t0 = time.perf_counter()
     gp.predict(Xs)
     solve_predict_ms = (time.perf_counter() - t0) * 1e3
+    # the fused von Karman predict alone (random alpha: the arithmetic does not depend on it), best of 4, against the evaluator's
+    # register-only ceiling with the table in LDS (profiles/r02_vk_ceiling.txt) -- one evaluation per (query, training point) pair
+    alpha_r = np.random.default_rng(3).standard_normal(n)
+    vk_pred_ms = 1e9
+    for _ in range(4):
+        ops.gp_predict(vk, X, alpha_r, Xs)
+        vk_pred_ms = min(vk_pred_ms, _lib.timings(ctx)[3])
+    vk_pairs = float(n) * float(len(Xs)) / (vk_pred_ms * 1e-3)
+    roofline_predict_vk = {"bound": "valu", "achieved": vk_pairs, "peak": VK_CEILING, "unit": "pairs/s", "frac": vk_pairs / VK_CEILING,
+                           "predict_ms": vk_pred_ms, "note": "N=32768 training, M=32768 query points; peak = register-only K_5/6 "
+                           "evaluations/s of the same evaluator (tools/probes/vk_ceiling.hip)"}
     k = y - y.mean()
     w = 1.0 / y_err ** 2
     ops.kk_log(X[:, 0], X[:, 1], k, w, 1.0 / np.sqrt(n), 0.7, 20)
-    ops.kk_log(X[:, 0], X[:, 1], k, w, 1.0 / np.sqrt(n), 0.7, 20)
+    kk_out = ops.kk_log(X[:, 0], X[:, 1], k, w, 1.0 / np.sqrt(n), 0.7, 20)
     kk_ms = _lib.timings(ctx)[4]
+    ops.kk_twod(X[:, 0], X[:, 1], k, w, 0.0, 0.15, 21)
+    kk2_out = ops.kk_twod(X[:, 0], X[:, 1], k, w, 0.0, 0.15, 21)
+    kk2_ms = _lib.timings(ctx)[4]
+    # pairs/s against a ceiling that bounds the shipped kernels.  Counted are the pairs that REACH a bin (sum of the
+    # kernel's own pair counts; culled tiles and out-of-range pairs cost less and are left out: no ratio above 1 by construction).
+    # VALU ceiling: VALU instructions per pair iteration on the common path (tools/kk_isa_count.py: Log 152, TwoD 52) at 4 clocks
+    # per wave64 instruction on 256 x 4 SIMDs at 2.4 GHz.  LDS-atomic ceiling: 1.5e12 fp64 LDS atomics/s
+    # (profiles/r02_lds_atomic_ceiling.txt: 5.0e11 pairs/s at three sums per pair) over the atomics a binned pair issues -- Log: five,
+    # for the pairs below the four top bins only (those are summed in registers); TwoD: six (both mirrored pixels).
+    VALU_SLOTS = 256 * 4 * 64 * 2.4e9 / 4.0
+    LDS_ATOMICS = 1.5e12
+    log_np = np.asarray(kk_out[4], dtype=np.float64)
+    log_in = float(log_np.sum())
+    log_low = float(log_np[:-4].sum()) / max(log_in, 1.0)
+    log_rate = log_in / (kk_ms * 1e-3)
+    log_ceil = min(VALU_SLOTS / 152.0, LDS_ATOMICS / max(5.0 * log_low, 1e-9))
+    twod_in = float(np.asarray(kk2_out[2]).sum()) / 2.0                 # every pair lands in two (mirrored) pixels
+    twod_rate = twod_in / (kk2_ms * 1e-3)
+    twod_ceil = min(VALU_SLOTS / 52.0, LDS_ATOMICS / 6.0)
+    roofline_kk = {
+        "log": {"bound": "valu" if VALU_SLOTS / 152.0 <= LDS_ATOMICS / max(5.0 * log_low, 1e-9) else "lds_atomics",
+                "achieved": log_rate, "peak": log_ceil, "unit": "binned pairs/s", "frac": log_rate / log_ceil,
+                "binned_pairs": log_in, "ms_incl_copies": kk_ms, "fraction_below_the_register_bins": log_low,
+                "valu_instructions_per_pair": 152, "note": "N=32768, 20 log bins in [1/sqrt(N), 0.7)"},
+        "twod": {"bound": "valu" if VALU_SLOTS / 52.0 <= LDS_ATOMICS / 6.0 else "lds_atomics",
+                 "achieved": twod_rate, "peak": twod_ceil, "unit": "binned pairs/s", "frac": twod_rate / twod_ceil,
+                 "binned_pairs": twod_in, "ms_incl_copies": kk2_ms, "valu_instructions_per_pair": 52,
+                 "note": "N=32768, 21 x 21 pixels, max_sep 0.15 (the anisotropic fit's binning); parity of this binning is "
+                         "unpinned (TreeCorr absent)"}}
     rng = np.random.default_rng(610639139)
     idx = np.stack([rng.integers(0, n - 1, size=n) for _ in range(444)])
     ops.kk_twod_bootstrap(X[:, 0], X[:, 1], y, y_err, idx, 0.0, 0.15, 21)
@@ -285,6 +336,7 @@ def configs_measured(lib, ctx, ops, _lib):
                 "kk_log_ms_incl_copies": kk_ms, "kk_log_pairs_per_sec": n * (n - 1) / 2.0 / (kk_ms * 1e-3),
                 # (round 4: the ratio to the one-LDS-atomic-per-sum rate was dropped -- the kernel accumulates the crowded bins in
                 # registers and issues far fewer atomics, so that rate does not bound it; pairs/s stands alone)
+                "roofline_kk": roofline_kk, "roofline_predict_vk": roofline_predict_vk,
                 "bootstrap_444_resamples_21x21_ms": {"device_incl_copies": boot_dev, "wall": boot_wall}})
     return out
 

@@ -346,6 +346,7 @@ def test_bench_self_launch_rehearsal(G):
     assert gp["chosen"] in ("allgather", "p2p") and gp["allgather_GBps"] > 0 and gp["p2p_GBps"] > 0
     assert out["collective_backend"]["backend"] == "gloo" and out["cpu_baseline"] == "see n_gpus=1 line"
     assert "reflected" in out["owner_map"]
+    assert out["panel_chain"]["form"] == "gather"                # TGP_DIST_CHAIN_BCAST unset: the default chain
     # every rank receives the panels it does not own: ~ 4 N^2 (G-1)/G bytes (+ the diagonal-block broadcasts, + padding)
     exp = out["bytes_received_expected"]
     assert all(0.8 * exp < v < 1.6 * exp for v in pr["bytes_received"]), (pr["bytes_received"], exp)
@@ -420,6 +421,14 @@ def test_bench_line_schema_single_gpu():
                 "bootstrap_444_resamples_21x21_ms", "solve_plus_predict_32768_ms"):
         assert key in c2, key
     assert "N=32768" in c2["config"] and c2["two_pcf_fit_ms"] > 0
+    # SURVEY 8(d) for the pair kernels and the von Karman predict (round 5): a roofline fraction each, none above 1
+    for which in ("log", "twod"):
+        rk = c2["roofline_kk"][which]
+        assert rk["unit"] == "binned pairs/s" and rk["bound"] in ("valu", "lds_atomics") and 0 < rk["frac"] <= 1.0, rk
+        assert abs(rk["frac"] - rk["achieved"] / rk["peak"]) < 1e-12 and rk["binned_pairs"] > 0
+    pv = c2["roofline_predict_vk"]
+    assert pv["bound"] == "valu" and pv["unit"] == "pairs/s" and 0 < pv["frac"] <= 1.0, pv
+    assert "TreeCorr absent" in c2b["pair_binning"] and "restatement" in c2b["pair_binning"]
     assert any(k.startswith("extrapolated_n") for k in cb)
     np.testing.assert_allclose(out["value"], (24576 + 4 * 24576) / (out["ms_per_step"] * 1e-3), rtol=1e-9)
 
