@@ -73,7 +73,7 @@ def test_virtual_ranks_replicated_finish(G, n, group, finish, replicate, monkeyp
 
 
 def test_world_of_one_forced_to_the_fused_launch(monkeypatch):
-    """a world of one takes the two-launch form by default (whole-chip launches: DESIGN A.0); TGP_DIST_FUSED=1 forces the fused one"""
+    """a world of one takes the two-launch form by default (whole-chip launches: LAB_NOTES A.0); TGP_DIST_FUSED=1 forces the fused one"""
     monkeypatch.setenv("TGP_DIST_GROUP", "4")
     monkeypatch.setenv("TGP_DIST_FUSED", "1")
     monkeypatch.setenv("TGP_DIST_FINISH", "0")

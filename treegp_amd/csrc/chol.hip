@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void gemm_col_small_kernel(const double *A, co
 // R1 -= X0 L10^T, X1 = R1 W1^T (R0 | R1 = the two 128-column halves of the rows, L10 = rows 128..255 of the block's first
 // half, W0 / W1 the inverted 128-blocks).  A row tile depends on nothing but itself and the diagonal block.  Used by the
 // multi-GPU panel chain (tgp_dd_trsm), where every launch beside the bulk update waits for workgroup slots: one wait
-// instead of three.  (On one GPU the same fusion did not pay: same number of launches on the chain, see DESIGN.)
+// instead of three.  (On one GPU the same fusion did not pay: same number of launches on the chain, see LAB_NOTES.md A.4.)
 // (keep != nullptr: the grid also copies the two inverted blocks, 2 x 128 x 128 doubles at W0, to `keep` -- a rank that received
 // them in the broadcast keeps them for the solves; as a copy of its own it was one more 5 us kernel on the panel chain)
 __device__ __forceinline__ void keep_w_share(double *__restrict__ keep, const double *__restrict__ W0) {
@@ -713,7 +713,7 @@ void launch_syrk2_queued(tgp_ctx *ctx, hipStream_t st, double *d_A, int64_t Np, 
 // History at N=65536 (same tile): 1694 ms one panel at a time, 1571 pairs, 1551 pairs + look-ahead; with the DTV tile
 // 1423 ms pairs + look-ahead, 1362 ms fours + look-ahead (68.9 TF, 87.6 % of the fp64 MFMA peak).
 // Schedules that were measured and dropped (diagonal-first, a right-hand side riding along, head start for the chain) are
-// in DESIGN.md Appendix A and the git history.
+// in LAB_NOTES.md Appendix A and the git history.
 int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_info, int64_t n_data) {
     TGP_ARG(Np > 0 && Np % TGP_PW == 0);
     hipStream_t st = ctx->stream;

@@ -13,7 +13,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int KB = 16;         // k-chunk depth
 
-// Variant knobs (A/B-measured on MI355X):
+// Variant knobs (A/B-measured on MI355X, see LAB_NOTES.md A.4):
 //   LSV   LDS row stride in doubles.  hipcc fuses the fragment reads of two k-steps into
 //         ds_read2_b64, whose banking is per 16-lane group with (addr/4) mod 32: an odd stride
 //         (17) is conflict-free there, the even stride 18 is 2-way.  Odd stride means 8-byte
@@ -21,7 +21,7 @@ constexpr int KB = 16;         // k-chunk depth
 //   PRE   MODE 1 only: load C into the accumulators (negated) in the prologue, together with the
 //         first operand chunk (one memory latency), instead of a 4-round read-modify-write epilogue.
 //   (An LDS-DMA variant of the staging -- `buffer_load ... lds`, XOR-swizzled source side -- was measured slower, 59.7 vs
-//   63.0 TF on the depth-512 update, and removed in round 4: DESIGN.md A.4, git history.)
+//   63.0 TF on the depth-512 update, and removed in round 4: LAB_NOTES.md A.4, git history.)
 template <int LSV, bool PRE>
 struct TileCfg {
     static constexpr int LS = LSV;

@@ -553,7 +553,7 @@ class HipLocalOps(object):
         env = os.environ.get("TGP_DIST_FUSED")
         if env == "0" or (env is None and self.G == 1):
             # a world of one runs whole-chip launches of dozens of rounds: there the fused form loses 0.6 % (the rest tiles
-            # start in lockstep when the head ends and the chain waits a tile time for a slot; DESIGN A.0); TGP_DIST_FUSED=1 forces it
+            # start in lockstep when the head ends and the chain waits a tile time for a slot; LAB_NOTES A.0); TGP_DIST_FUSED=1 forces it
             return False
         return int(self.lib.tgp_handoff_mode(self.ctx)) == 1
 
