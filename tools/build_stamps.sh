@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../treegp_amd/csrc"
 mkdir -p .stamps
-for f in api handoff kbuild chol pchol trsv trsv_big predict kk kk_boot cov dist knn binstat vcorr; do
+for f in api handoff kbuild chol trsv trsv_big predict kk kk_boot cov dist knn binstat vcorr; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DTGP_POTRF_STAMPS -Wno-unused-function -Wno-unused-variable -c $f.hip -o .stamps/$f.o &
 done
 wait

@@ -12,7 +12,7 @@ mkdir -p "$B"
 FLAGS="--offload-arch=gfx950 -std=c++17 -O1 -g -fPIC -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -w"
 OBJS=""
 N=0
-for f in api handoff kk chol pchol kbuild trsv trsv_big predict kk_boot cov dist knn binstat vcorr; do
+for f in api handoff kk chol kbuild trsv trsv_big predict kk_boot cov dist knn binstat vcorr; do
   $HIPCC $FLAGS -c "$ROOT/treegp_amd/csrc/$f.hip" -o "$B/$f.o" &
   OBJS="$OBJS $B/$f.o"
   N=$((N + 1))

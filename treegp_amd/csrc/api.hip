@@ -28,8 +28,6 @@ struct tgp_ctx_ext {
     Staging hio;                 // pinned host mirror of the front of `io` (same offsets), see h2d / d2h_sync
     Staging hpin;                // pinned host scratch (tgp_ensure_pinned)
     double *A_cache = nullptr;   // packed lower panels, reused across solves of the same size
-    double *A_alt = nullptr;     // second packed matrix of the same size: where the dataflow factorisation (pchol.hip) leaves L
-    int64_t alt_Np = 0;
     double *W_cache = nullptr;
     int64_t cache_Np = 0;
 };
@@ -230,9 +228,6 @@ void tgp_destroy(tgp_ctx *ctx) {
     if (e->hio.buf) (void)hipHostFree(e->hio.buf);
     if (e->hpin.buf) (void)hipHostFree(e->hpin.buf);
     if (e->A_cache) (void)hipFree(e->A_cache);
-    if (e->A_alt) (void)hipFree(e->A_alt);
-    if (ctx->d_pchol) (void)hipFree(ctx->d_pchol);
-    if (ctx->d_pchol_scratch) (void)hipFree(ctx->d_pchol_scratch);
     if (e->W_cache) (void)hipFree(e->W_cache);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
@@ -398,27 +393,8 @@ static int factor_and_solve(tgp_ctx *ctx, int64_t n, int64_t Np, const double *d
     // likelihood evaluation); if a pivot failed they run on a meaningless factor and their result is discarded below.
     static const bool dbg = getenv("TGP_HOST_PHASES") != nullptr;
     const auto h0 = std::chrono::steady_clock::now();
-    // Chain-bound sizes, a solve that is alone (as for panel_mid_kernel) and TGP_CHOL_DATAFLOW=1: the dataflow factorisation
-    // (pchol.hip).  It leaves L in a second matrix, which then becomes the context's cache in place of the one it consumed.
-    static const int dataflow = [] { const char *v = getenv("TGP_CHOL_DATAFLOW"); return v ? atoi(v) : 0; }();
-    int info = 0;
-    if (dataflow && ctx->mid_allowed && !ctx->mid_off && ctx->lookahead && Np >= 2048 && Np <= 16384 && tgp_handoff_by_flags(ctx)) {
-        if (e->A_alt && e->alt_Np != Np) {
-            TGP_HIP(hipFree(e->A_alt));
-            e->A_alt = nullptr;
-        }
-        if (!e->A_alt) {
-            TGP_HIP(hipMalloc((void **)&e->A_alt, (size_t)tgp_panel_elems(Np) * sizeof(double)));
-            e->alt_Np = Np;
-        }
-        info = launch_potrf_dataflow(ctx, d_A, e->A_alt, Np, d_W);
-        if (info < 0) return fail(info);
-        std::swap(e->A_cache, e->A_alt);
-        d_A = e->A_cache;
-    } else {
-        info = launch_potrf(ctx, d_A, Np, d_W, /*defer_info=*/true, /*n_data=*/n);
-        if (info < 0) return fail(info);
-    }
+    int info = launch_potrf(ctx, d_A, Np, d_W, /*defer_info=*/true, /*n_data=*/n);
+    if (info < 0) return fail(info);
     const auto h1 = std::chrono::steady_clock::now();
     TGP_HIP(hipEventRecord(ctx->ev[2], st));
     double sweeps = 0.0;

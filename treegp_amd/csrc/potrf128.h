@@ -883,10 +883,8 @@ __global__ __launch_bounds__(256, 2) void potrf128_kernel(double *A, int lda, do
 }
 // The same without the register cap (312 registers, no spills: 1 - 2 us faster per block in situ), for launches that get a compute
 // unit to themselves anyway: beside a queued bulk update (clear CUs, 128 KB of LDS asked for), or with nothing else on the chip.
-#ifndef TGP_POTRF128_BODY_ONLY        // (a second translation unit that only wants the body: pchol.hip)
 __global__ __launch_bounds__(256) void potrf128_solo_kernel(double *A, int lda, double *W, int *info, int base) {
     TGP_CHAIN_PRIO();
     potrf128_body<true>(potrf_lds_image, A, lda, W, info, base);
 }
-#endif
 }  // namespace potrf_v2

@@ -56,8 +56,6 @@ struct tgp_ctx {
     int chain_exclusive = 0;      // tgp_dd_set_exclusive: diagonal blocks of this context ask for a compute unit of their own
     unsigned *d_queue = nullptr;  // tile-queue counters of the persistent bulk update (TGP_NQUEUE launches x TGP_QUEUE_WORDS)
     unsigned *d_psync = nullptr;  // in-kernel hand-off counters of panel_mid_kernel (chol.hip): TGP_PSYNC_PANELS x 16 words, zeroed per factorisation
-    void *d_pchol = nullptr;      // state of the dataflow factorisation (pchol.hip), allocated on first use
-    void *d_pchol_scratch = nullptr;
     int mid_off = 0;              // an in-kernel hand-off of this context timed out once: panel_mid_kernel stays off for its life
     int mid_allowed = 0;          // set by the solve entry points for the factorisation they are about to queue (alone on the chip, retry possible)
     int *d_info = nullptr;        // first failing pivot (1-based), 0 = ok
@@ -196,7 +194,6 @@ int launch_kbuild_lower(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, in
 int launch_kernel_dense(tgp_ctx *ctx, const tgp_kernel *k, const double *d_X, int64_t n,
                         const double *d_Y, int64_t m, int self, double *d_out);
 int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_info = false, int64_t n_data = -1);
-int launch_potrf_dataflow(tgp_ctx *ctx, double *d_A, double *d_L, int64_t Np, double *d_W);      // pchol.hip
 int tgp_potrf_info_rc(tgp_ctx *ctx, int info);      // device `info` word -> return code (TGP_RC_HANDOFF: in-kernel hand-off timed out)
 #define TGP_RC_HANDOFF (-4)
 // Solves in flight in this process (host-boundary and device-resident solve calls, counted from entry to return).  Kernels whose
