@@ -287,3 +287,28 @@ def test_released_factor_memory_is_reused():
         assert free_bytes() > with_one + (100 << 20)
     finally:
         _lib.load_library().tgp_destroy(ctx)
+
+
+def test_a_solve_has_the_same_bits_with_and_without_panel_mid_kernel():
+    """panel_mid_kernel runs only for a solve that is alone in its process (its workgroups wait for each other inside the
+    launch); what a solve returns must not depend on that.  The launch-by-launch form of the same step therefore does the same
+    arithmetic (16-row slices for rows 128..255, the same tile form for the rows below): alpha and the log-determinant are
+    bit-identical with TGP_PANEL_MID=0 and 1, at sizes that cover the one-stream, look-ahead and chain-bound schedules."""
+    import hashlib
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+            "from treegp_amd import _lib, ops\n"
+            "from treegp_amd.synthetic import star_field, headline_invlam\n"
+            "iL = headline_invlam(); spec = ops.KernelSpec(_lib.TGP_ARBF, amp=1.0, a=iL[0,0], b=iL[0,1], c=iL[1,1])\n"
+            "for n in (700, 1300, 3000, 5000, 8192):\n"
+            "    X, y, ye, _ = star_field(n, 16, seed=n)\n"
+            "    a, ld, yd, _ = ops.gp_solve(spec, X, y - y.mean(), ye)\n"
+            "    print(n, hashlib.sha256(a.tobytes()).hexdigest(), repr(ld))\n" % root)
+    outs = []
+    for mid in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TGP_PANEL_MID=mid), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln and ln[0].isdigit()])
+    assert len(outs[0]) == 5 and outs[0] == outs[1], (outs[0], outs[1])

@@ -610,7 +610,7 @@ __global__ void set_identity128_kernel(double *__restrict__ W) {
 // `mid_sync` != nullptr: the step between the two diagonal blocks runs as panel_mid_kernel (one launch, in-kernel hand-offs, the
 // second diagonal block inside it); `cu_budget` = compute units its workgroups can expect to find free (each takes a whole one)
 void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_info, int base, bool exclusive = false,
-                  int64_t n_data = -1, unsigned *mid_sync = nullptr, int cu_budget = 256) {
+                  int64_t n_data = -1, unsigned *mid_sync = nullptr, int cu_budget = 0) {
     double *W1 = W0 + TGP_TB * TGP_TB;
     double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
     const int r1 = (int)((mk - TGP_TB) / TGP_TB);
@@ -633,6 +633,23 @@ void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_inf
         const unsigned dyn = (exclusive && pad_ok) ? pad : 0u;
         if (17 + 8 * r2 <= cu_budget) panel_mid_kernel<true><<<17 + 8 * r2, 256, dyn, st>>>(Pk, W0, W1, d_info, base, mid_sync);
         else panel_mid_kernel<false><<<17 + r2, 256, dyn, st>>>(Pk, W0, W1, d_info, base, mid_sync);
+    } else if (cu_budget > 0) {
+        // A step that WOULD run as panel_mid_kernel, were this solve alone on the chip: the same arithmetic as separate launches --
+        // rows 128..255 as eight 16-row slices, the rows below in the tile form that kernel would choose -- so that a solve's
+        // bits do not depend on whether another context happened to be busy (the two tile forms sum in different orders).
+        double *R2 = Pk + (int64_t)TGP_PW * TGP_PW;
+        const bool small = 17 + 8 * r2 <= cu_budget;
+        gemm_col_small_kernel<0, TGP_TB><<<8, 256, 0, st>>>(R1, W0, R1);
+        if (r2 > 0) {
+            if (small) gemm_col_small_kernel<0, TGP_TB><<<r2 * 8, 256, 0, st>>>(R2, W0, R2);
+            else gemm_col_kernel<0, TGP_TB><<<r2, 256, 0, st>>>(R2, W0, R2);
+        }
+        gemm_col_small_kernel<1, TGP_PW><<<8, 256, 0, st>>>(R1, R1, R1 + TGP_TB);
+        if (r2 > 0) {
+            if (small) gemm_col_small_kernel<1, TGP_PW><<<r2 * 8, 256, 0, st>>>(R2, R1, R2 + TGP_TB);
+            else gemm_col_kernel<1, TGP_PW><<<r2, 256, 0, st>>>(R2, R1, R2 + TGP_TB);
+        }
+        run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, d_info, base + TGP_TB, exclusive, solo);
     } else {
         if (r1 <= small_rows) {
             gemm_col_small_kernel<0, TGP_TB><<<r1 * 8, 256, 0, st>>>(R1, W0, R1);
