@@ -294,7 +294,7 @@ def test_a_solve_has_the_same_bits_with_and_without_panel_mid_kernel():
     launch); what a solve returns must not depend on that.  The launch-by-launch form of the same step therefore does the same
     arithmetic (16-row slices for rows 128..255, the same tile form for the rows below): alpha and the log-determinant are
     bit-identical with TGP_PANEL_MID=0 and 1, at sizes that cover the one-stream, look-ahead and chain-bound schedules."""
-    import hashlib
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
