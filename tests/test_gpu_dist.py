@@ -427,7 +427,8 @@ def test_bench_line_schema_single_gpu():
         assert rk["unit"] == "binned pairs/s" and rk["bound"] in ("valu", "lds_atomics") and 0 < rk["frac"] <= 1.0, rk
         assert abs(rk["frac"] - rk["achieved"] / rk["peak"]) < 1e-12 and rk["binned_pairs"] > 0
     pv = c2["roofline_predict_vk"]
-    assert pv["bound"] == "valu" and pv["unit"] == "pairs/s" and 0 < pv["frac"] <= 1.0, pv
+    # (its peak is a probe's measured figure, not a data-sheet number: 3 % of room for the clocks of another box)
+    assert pv["bound"] == "valu" and pv["unit"] == "pairs/s" and 0 < pv["frac"] <= 1.03, pv
     assert "TreeCorr absent" in c2b["pair_binning"] and "restatement" in c2b["pair_binning"]
     assert any(k.startswith("extrapolated_n") for k in cb)
     np.testing.assert_allclose(out["value"], (24576 + 4 * 24576) / (out["ms_per_step"] * 1e-3), rtol=1e-9)
