@@ -258,6 +258,22 @@ __global__ __launch_bounds__(256, 2) void syrk_strip64_kernel(double *Abase, int
     gemm_tile_dtv<4, TGP_PW, NSEG, 1>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
 }
 
+// ... and with 32-row tiles (gemm_tile_dtv32) where twice as many workgroups again still find the chip in one round
+template <int NSEG>
+__global__ __launch_bounds__(256, 2) void syrk_strip32_kernel(double *Abase, int64_t Np, int ob, int T, int strip, const double *P0,
+                                                              const double *P1) {
+    const int tj = (int)(blockIdx.x % strip);        // 128-column tile
+    const int tq = (int)(blockIdx.x / strip);        // 32-row quarter tile
+    const int ti = tq >> 2;
+    if (ti < tj || ti >= T) return;
+    TGP_CHAIN_PRIO();
+    const int64_t pj = ob + (tj >> 1);
+    const int64_t I = (int64_t)TGP_PW * ob + (int64_t)32 * tq;
+    double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
+    const int64_t oa = (int64_t)tq * 32 * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
+    gemm_tile_dtv32<TGP_PW, NSEG>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
+}
+
 // The depth-512 bulk update as a PERSISTENT grid that leaves part of the chip free, for steps where the serial panel
 // chain (side stream) is longer than the update.  A bulk workgroup lives ~126 us and a plain launch fills both
 // workgroup slots of all 256 CUs at once, so the chain's kernels -- potrf128 needs a CU with a free slot, the panel
@@ -681,6 +697,11 @@ void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int str
         return;
     }
     static const int strip64_t = [] { const char *e = getenv("TGP_STRIP64_T"); return e ? atoi(e) : 128; }();
+    static const int strip32_t = [] { const char *e = getenv("TGP_STRIP32_T"); return e ? atoi(e) : 64; }();
+    if (strip > 0 && T <= strip32_t) {
+        syrk_strip32_kernel<NSEG><<<(unsigned)((int64_t)4 * T * strip), 256, 0, st>>>(d_A, Np, ob, T, strip, P0, P1);
+        return;
+    }
     if (strip > 0 && T <= strip64_t) {
         syrk_strip64_kernel<NSEG><<<(unsigned)((int64_t)2 * T * strip), 256, 0, st>>>(d_A, Np, ob, T, strip, P0, P1);
         return;
@@ -793,16 +814,24 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
         hipStream_t sd = ctx->side_stream;
         // `cus` > 0: the chain has that many compute units to itself (the whole chip, or the ones a queued bulk update keeps
         // clear) -- the step between a panel's two diagonal blocks then runs as panel_mid_kernel
-        auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false, int cus = 0) {       // F(k), U1(k), F(k+1)
+        // `tell`: say on flag 2 when panel k is complete (its part of the next U2a is then applied early, see below)
+        auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false, int cus = 0, bool tell = false) {       // F(k), U1(k), F(k+1)
             const int64_t mk = Np - (int64_t)TGP_PW * k;
             auto sync = [&](int kk) { return (cus > 0 && mid_on && kk < TGP_PSYNC_PANELS) ? ctx->d_psync + PANEL_SYNC_WORDS * kk : nullptr; };
             factor_panel(s, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, exclusive, n_data, sync(k), cus);
+            if (tell) (void)tgp_signal(ctx, s, 2, ctx->ev[6]);
             if (k + 1 >= nP) return;
             const int T1 = (int)((mk - TGP_PW) / TGP_TB);
             launch_syrk<1>(s, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
             factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, exclusive, n_data, sync(k + 1), cus);
         };
         factor_pair(st, kstart, false, 256);
+        // Chain-bound steps (T3 <= split_t): U2a -- the 4 tile columns of the next pair, depth 512, between F(k+1) and F(k+2) on
+        // the critical path -- is taken in two halves of depth 256: panel k's half as soon as panel k is complete, on the bulk's
+        // stream beside U1 and F(k+1); only panel k+1's half is left between the pairs (a strip tile of depth 256 takes ~22 us,
+        // one of depth 512 ~42).
+        static const int split_t = [] { const char *e = getenv("TGP_U2A_SPLIT_T"); return e ? atoi(e) : 64; }();
+        bool early = false;         // panel k's half of U2a(k) has been applied already
         for (int k = kstart; k + 2 < nP; k += 2) {
             const int T2 = (int)((Np - (int64_t)TGP_PW * (k + 2)) / TGP_TB);       // tiles from block k+2
             const double *P0 = panel(k) + (int64_t)2 * TGP_PW * TGP_PW;
@@ -814,13 +843,17 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             {   // U2a: tile columns 0..3 (panels k+2, k+3)
                 const double rows = (double)T2 * TGP_TB, w = (T2 < 4 ? T2 : 4) * (double)TGP_TB;
                 const double elems = w * (rows - w) + w * (w + 1.0) / 2.0;
-                int rc = timed([&] { launch_syrk<2>(st, d_A, Np, k + 2, T2, 4, P0, P1); }, 2.0 * 2.0 * TGP_PW * elems);
+                int rc = timed([&] {
+                    if (early) launch_syrk<1>(st, d_A, Np, k + 2, T2, 4, P1, nullptr);
+                    else launch_syrk<2>(st, d_A, Np, k + 2, T2, 4, P0, P1);
+                }, (early ? 1.0 : 2.0) * 2.0 * TGP_PW * elems);
                 if (rc) return rc;
             }
             TGP_HIP(tgp_signal(ctx, st, 0, ctx->ev[4]));
             TGP_HIP(tgp_await(ctx, sd, 0, ctx->ev[4]));
+            const bool early_next = T3 > 0 && T3 <= split_t;
             // (steps with at most small_t tile rows have no bulk update to speak of: the chain has the chip to itself)
-            factor_pair(sd, k + 2, queued, queued ? 32 * queued_nres(T3) : (T3 <= small_t() ? 256 : 0));
+            factor_pair(sd, k + 2, queued, queued ? 32 * queued_nres(T3) : (T3 <= small_t() ? 256 : 0), early_next);
             TGP_HIP(tgp_signal(ctx, sd, 1, ctx->ev[5]));
             if (T3 > 0) {   // U2b: everything from block k+4 on
                 const double m = (double)T3 * TGP_TB;
@@ -831,6 +864,11 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
                 }, 2.0 * TGP_PW * m * (m + 1.0));
                 if (rc) return rc;
             }
+            if (early_next) {       // panel k+2's half of the next U2a (tile columns of blocks k+4, k+5), once that panel is complete
+                TGP_HIP(tgp_await(ctx, st, 2, ctx->ev[6]));
+                launch_syrk<1>(st, d_A, Np, k + 4, T3, 4, panel(k + 2) + (int64_t)2 * TGP_PW * TGP_PW, nullptr);
+            }
+            early = early_next;
             TGP_HIP(tgp_await(ctx, st, 1, ctx->ev[5]));
         }
         return 0;

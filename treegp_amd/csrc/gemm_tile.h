@@ -370,6 +370,103 @@ __device__ __forceinline__ void gemm_tile_dtv(const double *a_ptr, const double 
 }
 
 
+// ---- the DTV tile for the chain's strips: 32 x 128 of C per workgroup -------------------------------------------------------
+// Waves 2 (rows) x 2 (column halves): wave (wr, wc) owns rows 16 wr .. 16 wr + 15 and columns 64 wc .. 64 wc + 63 (1 x 4 MFMA
+// tiles).  Same staging of B, same k order per element as gemm_tile_dtv -- the results have the same bits -- but a quarter of
+// the 128 x 128 tile's matrix instructions per wave: a strip that the panel chain waits for is a single round of workgroups,
+// and its duration is one workgroup's (depth 256: 64 x 128 tiles ~22 us, these ~15).  Twice the B traffic per flop of the
+// 64-row tile; the strips' operands sit in L2.
+template <int KDEPTH, int NSEG>
+__device__ __forceinline__ void gemm_tile_dtv32(const double *a_ptr, const double *b_ptr, double *c_ptr, const double *a1_ptr,
+                                                const double *b1_ptr) {
+    static_assert(NSEG == 1 || NSEG == 2, "one or two operand pairs");
+    constexpr int LD = TGP_PW;
+    constexpr int LSB = DTV_LSB;
+    constexpr int BPT = 4, BROWS = 32;
+    double (*ldsB)[128 * LSB] = reinterpret_cast<double (*)[128 * LSB]>(dtv_lds_storage());
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w & 1, wc = w >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    const __amdgpu_buffer_rsrc_t ra0 = tile_rsrc(a_ptr, 32 * LD * 8);
+    const __amdgpu_buffer_rsrc_t rb0 = tile_rsrc(b_ptr, 128 * LD * 8);
+    const __amdgpu_buffer_rsrc_t ra1 = tile_rsrc(NSEG > 1 ? a1_ptr : a_ptr, 32 * LD * 8);
+    const __amdgpu_buffer_rsrc_t rb1 = tile_rsrc(NSEG > 1 ? b1_ptr : b_ptr, 128 * LD * 8);
+    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(c_ptr, 32 * LD * 8);
+    const int va = ((16 * wr + l15) * LD + 2 * l4) * 8;
+    const int srow = tid >> 3, kp = (tid & 7) * 2;
+    const int vb = (srow * LD + kp) * 8;
+    const int vc = ((16 * wr + l4) * LD + 64 * wc + l15) * 8;
+    const int fb = (64 * wc + l15) * LSB + 2 * l4;
+
+    double2 areg[2][2];                                          // [set][h]
+    double2 rbst[BPT];
+    auto load_a = [&](double2 (&dst)[2], __amdgpu_buffer_rsrc_t src, int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) dst[h] = buf_ld2(src, va, (k0 + 8 * h) * 8);
+    };
+    auto load_b = [&](__amdgpu_buffer_rsrc_t src, int k0) {
+#pragma unroll
+        for (int s = 0; s < BPT; ++s) rbst[s] = buf_ld2(src, vb, (s * BROWS * LD + k0) * 8);
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < BPT; ++s) *reinterpret_cast<double2 *>(&ldsB[buf][(srow + BROWS * s) * LSB + kp]) = rbst[s];
+    };
+    load_a(areg[0], ra0, 0);
+    load_b(rb0, 0);
+    d4 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[n][r] = buf_ld1(rc, vc, (4 * r * LD + n * 16) * 8);
+    store_b(0);
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = -acc[n];
+
+    constexpr int cps = KDEPTH / KB;
+    static_assert(cps % 2 == 0, "chunks are processed in register-set pairs");
+    constexpr int nchunk = NSEG * cps;
+    auto step = [&](const int c, double2 (&cur)[2], double2 (&nxt)[2]) {
+        const int buf = c & 1;
+        const bool more = (c + 1 < nchunk);
+        if (more) {
+            const int cn = c + 1;
+            const int k0 = (cn % cps) * KB;
+            const bool second = NSEG > 1 && cn >= cps;           // wave-uniform
+            load_a(nxt, second ? ra1 : ra0, k0);
+            load_b(second ? rb1 : rb0, k0);
+        }
+        const double *Bs = ldsB[buf];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double2 bf[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bf[n] = *reinterpret_cast<const double2 *>(&Bs[fb + n * 16 * LSB + 8 * h]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[h].x, bf[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[h].y, bf[n].y, acc[n], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) store_b(buf ^ 1);
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int c = 0; c < nchunk; c += 2) {
+        step(c, areg[0], areg[1]);
+        step(c + 1, areg[1], areg[0]);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf_st1(-acc[n][r], rc, vc, (4 * r * LD + n * 16) * 8);
+}
+
+
 // ---- latency tile for small problems ----------------------------------------------------------------------
 // One workgroup = 16 rows x 128 columns of C, wave w the columns 32w .. 32w+31 (1 x 2 MFMA tiles, two
 // independent accumulator chains).  No LDS: A (16 x K) and B (128 x K) fragments come straight from global
