@@ -52,6 +52,13 @@ def solve_phases(n):
     de = ops.DeviceBuffer.from_array(ctx, y_err); dXs = ops.DeviceBuffer.from_array(ctx, Xs)
     da = ops.DeviceBuffer(ctx, n * 8); dys = ops.DeviceBuffer(ctx, 4 * n * 8)
     ld, yd = C.c_double(), C.c_double()
+    # the factorisation's time as it ships (best of 4; the per-launch events of profiling mode sit on the bulk stream and cost a
+    # chain-bound size ~8 %: 5.3 -> 5.8 ms at N = 8192), then one profiled pass for the bulk kernel's own time
+    chol_ms = 1e9
+    for _ in range(4):
+        rc = lib.tgp_d_gp_solve(ctx, C.byref(spec.to_c()), dX.ptr, n, dy.ptr, de.ptr, da.ptr, C.byref(ld), C.byref(yd), None)
+        assert rc == 0
+        chol_ms = min(chol_ms, _lib.timings(ctx)[1])
     lib.tgp_set_profiling(ctx, 1)
     for _ in range(2):
         rc = lib.tgp_d_gp_solve(ctx, C.byref(spec.to_c()), dX.ptr, n, dy.ptr, de.ptr, da.ptr, C.byref(ld), C.byref(yd), None)
@@ -59,9 +66,10 @@ def solve_phases(n):
         tm = _lib.timings(ctx)
         lib.tgp_d_gp_predict(ctx, C.byref(spec.to_c()), dX.ptr, n, da.ptr, dXs.ptr, 4 * n, dys.ptr)
         tp = _lib.timings(ctx)[3]
+    lib.tgp_set_profiling(ctx, 0)
     Np = lib.tgp_padded_n(n)
-    out(kernel="cholesky", n=n, ms=tm[1], TFLOPs=n ** 3 / 3 / tm[1] / 1e9, syrk_ms=tm[5], syrk_TFLOPs=tm[7] / tm[5] / 1e9,
-        frac_mfma_78_6=tm[7] / tm[5] / 1e9 / 78.6)
+    out(kernel="cholesky", n=n, ms=chol_ms, TFLOPs=n ** 3 / 3 / chol_ms / 1e9, frac_mfma_78_6_whole=n ** 3 / 3 / chol_ms / 1e9 / 78.6,
+        ms_with_per_launch_events=tm[1], syrk_ms=tm[5], syrk_TFLOPs=tm[7] / tm[5] / 1e9, frac_mfma_78_6=tm[7] / tm[5] / 1e9 / 78.6)
     out(kernel="potrs(trsv)+logdet+dot", n=n, ms=tm[2], bytes_alg=8.0 * Np * Np, GBps=8.0 * Np * Np / tm[2] / 1e6,
         frac_hbm_8TBps=8.0 * Np * Np / tm[2] / 1e6 / 8000)
     pairs = 4.0 * n * n
@@ -109,7 +117,7 @@ if __name__ == "__main__":
     if "kbuild" in which:
         kbuild("gauss", 65536); kbuild("gauss", 32768); kbuild("vk", 32768); kbuild("avk", 32768)
     if "solve" in which:
-        solve_phases(8192); solve_phases(32768)
+        solve_phases(8192); solve_phases(16384); solve_phases(32768)
     if "kk" in which:
         pair_binning(32768, 444)
     if "cov" in which:

@@ -935,7 +935,8 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
         };
         // Below `tail_tiles` rows of trailing matrix the deeper grouping no longer pays (its strips and the longer
         // serial chain cost more than the per-tile overhead it saves: crossover at N ~ 24k): the tail runs in pairs.
-        static const int tail_tiles = [] { const char *e = getenv("TGP_QUAD_TAIL_TILES"); return e ? atoi(e) : 128; }();
+        // (96 against 128 tile rows: 77.7 / 174.3 / 1321.8 ms against 78.1 / 174.7 / 1323.5 at N = 24 576 / 32 768 / 65 536; 64: 78.3 / 175.1)
+        static const int tail_tiles = [] { const char *e = getenv("TGP_QUAD_TAIL_TILES"); return e ? atoi(e) : 96; }();
         factor_group(st, 0);
         for (int k = 0; k + 4 < nP; k += 4) {
             const int T4 = (int)((Np - (int64_t)TGP_PW * (k + 4)) / TGP_TB);        // tiles from block k+4
