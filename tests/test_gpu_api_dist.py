@@ -59,6 +59,9 @@ def _virtual_ranks(G, fn):
                 dist.disable()
                 _lib.set_thread_ctx(None)
         except BaseException as e:            # noqa: BLE001 - surface any failure of a virtual rank
+            import sys
+            import traceback
+            sys.stderr.write("virtual rank %d:\n%s\n" % (rank, traceback.format_exc()))
             errors.append(e)
             try:
                 shared.barrier.abort()

@@ -172,10 +172,11 @@ def set_thread_ctx(ctx):
 
 def release_process_caches(device):
     """the process-wide context of `device`, if one exists, gives back its factor cache / slabs / scratch (tgp_release_caches)"""
-    with _lock:
+    lib = load_library()
+    with _lock:                     # (virtual ranks are threads of one process and all come here at once: one at a time)
         ctx = _ctx.get(int(device))
-    if ctx is not None:
-        load_library().tgp_release_caches(ctx)
+        if ctx is not None:
+            lib.tgp_release_caches(ctx)
 
 
 def get_ctx(device=None):
