@@ -59,14 +59,6 @@ int tgp_ensure_side_stream(tgp_ctx *ctx) {
     return 0;
 }
 
-int tgp_ensure_aux_stream(tgp_ctx *ctx) {
-    if (ctx->aux_stream) return 0;
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    TGP_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, hi));
-    return 0;
-}
-
 int tgp_ensure_scratch2(tgp_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->scratch2_bytes) return 0;
     if (ctx->scratch2) TGP_HIP(hipFree(ctx->scratch2));
@@ -219,7 +211,6 @@ int tgp_init(const int *devices, int ndev, tgp_ctx **out) {
         if (hipMemcpy(ctx->d_flags, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return -2; }
         for (unsigned &q : ctx->flag_seq) q = v0;
         ctx->head_count = v0;
-        ctx->urgent_count = v0;
     }
     if (hipHostMalloc((void **)&ctx->h_info, 256, hipHostMallocDefault) != hipSuccess) { delete ctx; return -2; }
     if (hipMalloc((void **)&ctx->d_scal, 16 * sizeof(double)) != hipSuccess) { delete ctx; return -2; }
@@ -256,7 +247,6 @@ void tgp_destroy(tgp_ctx *ctx) {
     for (auto &ev : ctx->prof_events) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->side_stream && !ctx->ext_side_stream) (void)hipStreamDestroy(ctx->side_stream);
-    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     delete static_cast<tgp_ctx_full *>(ctx);
 }
 

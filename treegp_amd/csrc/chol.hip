@@ -15,8 +15,6 @@
 // into VGPRs; panel solves: the 2x2-wave tile; few-tile steps: the latency tile); two workgroups per CU.
 #include "tgp_internal.h"
 
-#include <functional>
-
 #include "gemm_tile.h"
 #include "potrf128.h"
 
@@ -201,14 +199,12 @@ __global__ __launch_bounds__(256) void panel_mid_kernel(double *Pk, const double
     }
 }
 
-// `skip00`: without the tile the panel chain has updated itself already (run_pairs: the boundary between two panels)
 template <int NSEG>
 __global__ __launch_bounds__(256) void syrk_small_kernel(double *Abase, int64_t Np, int ob, int T, const double *P0,
-                                                         const double *P1, int skip00 = 0) {
+                                                         const double *P1) {
     const int ri = blockIdx.x;                   // 16-row slice of the trailing matrix
     const int tj = blockIdx.y;                   // 128-column tile
     if (tj > (ri >> 3) || (ri >> 3) >= T) return;
-    if (skip00 && tj == 0 && ri < 8) return;
     TGP_CHAIN_PRIO();
     const int64_t pj = ob + (tj >> 1);
     const int64_t I = (int64_t)TGP_PW * ob + 16 * (int64_t)ri;
@@ -265,12 +261,11 @@ __global__ __launch_bounds__(256, 2) void syrk_strip64_kernel(double *Abase, int
 // ... and with 32-row tiles (gemm_tile_dtv32) where twice as many workgroups again still find the chip in one round
 template <int NSEG>
 __global__ __launch_bounds__(256, 2) void syrk_strip32_kernel(double *Abase, int64_t Np, int ob, int T, int strip, const double *P0,
-                                                              const double *P1, int skip00 = 0) {
+                                                              const double *P1) {
     const int tj = (int)(blockIdx.x % strip);        // 128-column tile
     const int tq = (int)(blockIdx.x / strip);        // 32-row quarter tile
     const int ti = tq >> 2;
     if (ti < tj || ti >= T) return;
-    if (skip00 && ti == 0) return;                   // (tile (0, 0): the only valid one in tile row 0)
     TGP_CHAIN_PRIO();
     const int64_t pj = ob + (tj >> 1);
     const int64_t I = (int64_t)TGP_PW * ob + (int64_t)32 * tq;
@@ -286,33 +281,12 @@ __global__ __launch_bounds__(256, 2) void syrk_strip32_kernel(double *Abase, int
 // cycle).  Here only gridDim.x < 512 workgroups exist and they take tiles from a queue: the slots they do not occupy
 // stay free for the chain.  One counter per XCD class keeps the XCD-aware tile map (blockIdx.x & 7 = XCD of the
 // workgroup); the loop ends for every workgroup once its class has run out of slots.
-// Work that fills the ragged end of the launch (round 5, work-bound steps): panel k+2's half of the NEXT U2a -- the four tile
-// columns of blocks k+4, k+5, depth 256 -- used to be a launch of its own behind this one (45 us with the whole chip waiting,
-// while this launch's workgroups had run dry over its last 85 us, 50 us before its end on average: in-kernel stamps).  With
-// `fill.P` set, a workgroup whose tile queues have run dry takes 32-row pieces of that strip (the arithmetic, and the bits, of
-// syrk_strip32_kernel<1>) from one more counter.  They update tiles this launch updates first, so its first entries are the
-// dense grid of those `fill.cols` head columns and every head entry counts itself in when its tile is stored; and they read
-// panel k+2, which the chain's stream completes meanwhile: a piece is started once head entries == target AND the chain's flag
-// has reached `seq`.  Both are long true when the queues run dry in the steps this is used for; the wait is bounded all the same
-// (PANEL_SPIN_TICKS -> info = -7 -> TGP_RC_HANDOFF -> the solve is run again without it, as for panel_mid_kernel) and cannot
-// hold the chain up: its kernels run on the compute units this launch keeps clear.
-struct QueueFill {
-    const double *P = nullptr;      // row of panel k+2 that belongs to block k+4; nullptr: no fill, plain tile order
-    int cols = 0;                   // head columns (4)
-    unsigned head_per_class = 0;    // ceil(cols T / 8) head entries in front of each class's tile slots
-    unsigned pieces = 0;            // 4 T cols quarter-tile pieces
-    const unsigned *flag = nullptr; // the chain's "panel k+2 complete" flag ...
-    unsigned seq = 0;               // ... and the value it will carry
-    int *info = nullptr;
-};
 template <int NSEG>
 // `half_from`: tile slots of a class from this one on are taken as two 64 x 128 half tiles each (two queue entries): the launch
 // ends when its slowest workgroup does, on average half a tile time after the queues run dry (63 us of a 570 us launch at
-// N = 8192), and half tiles in the last round halve that.  `entries` = head entries + half_from + 2 (slots - half_from) queue
-// entries per class; half_from counts from the first tile slot.
+// N = 8192), and half tiles in the last round halve that.  `entries` = half_from + 2 (slots - half_from) queue entries per class.
 __global__ __launch_bounds__(256, 2) void syrk_dtv_queue_kernel(double *Abase, int64_t Np, int ob, int T, unsigned entries, unsigned half_from, int nres,
-                                                                unsigned *__restrict__ queue, const double *P0, const double *P1, int steal,
-                                                                QueueFill fill) {
+                                                                unsigned *__restrict__ queue, const double *P0, const double *P1, int steal) {
     __shared__ unsigned s_slot;
     const unsigned xcd = blockIdx.x & 7;
     {   // `nres` compute units per shader engine and XCD (32 nres of 256) are kept clear of this kernel: the first
@@ -356,8 +330,6 @@ __global__ __launch_bounds__(256, 2) void syrk_dtv_queue_kernel(double *Abase, i
 #endif
     // A class that has run dry helps the next one (TGP_QUEUE_STEAL, default on): the classes hold 248 - 266 tiles at T = 56 (diagonal
     // super-tiles are not full) and the launch used to end 50 us after its average workgroup (in-kernel stamps, N = 8192).
-    const int hc = fill.P ? fill.cols : 0;
-    const unsigned head_pc = fill.P ? fill.head_per_class : 0u;
     unsigned cls = xcd;
     int dry = 0;
     for (;;) {
@@ -371,101 +343,29 @@ __global__ __launch_bounds__(256, 2) void syrk_dtv_queue_kernel(double *Abase, i
             continue;
         }
         int half = -1;
+        if (n >= half_from) {
+            half = (int)((n - half_from) & 1u);
+            n = half_from + ((n - half_from) >> 1);
+        }
         int ti, tj;
-        const bool head = n < head_pc;
-        if (head) {                              // dense grid of the head columns, row-major
-            const unsigned h = (n << 3) | cls;
-            ti = (int)(h / (unsigned)hc);
-            tj = (int)(h - (unsigned)ti * (unsigned)hc);
-            if (ti >= T || tj > ti) ti = -1;
+        tilemap(((int64_t)n << 3) | cls, T, ti, tj);
+        if (ti < 0) continue;
+        const int64_t pj = ob + (tj >> 1);
+        const int64_t I = (int64_t)TGP_PW * ob + (int64_t)TGP_TB * ti;
+        double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
+        const int64_t oa = (int64_t)ti * TGP_TB * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
+        if (half < 0) {
+            gemm_tile_dtv<4, TGP_PW, NSEG>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
         } else {
-            n -= head_pc;
-            if (n >= half_from) {
-                half = (int)((n - half_from) & 1u);
-                n = half_from + ((n - half_from) >> 1);
-            }
-            tilemap(((int64_t)n << 3) | cls, T - hc, ti, tj);
-            if (ti >= 0) {
-                ti += hc;
-                tj += hc;
-            }
-        }
-        if (ti >= 0) {
-            const int64_t pj = ob + (tj >> 1);
-            const int64_t I = (int64_t)TGP_PW * ob + (int64_t)TGP_TB * ti;
-            double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
-            const int64_t oa = (int64_t)ti * TGP_TB * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
-            if (half < 0) {
-                gemm_tile_dtv<4, TGP_PW, NSEG>(P0 + oa, P0 + obb, C, NSEG > 1 ? P1 + oa : nullptr, NSEG > 1 ? P1 + obb : nullptr);
-            } else {
-                const int64_t ho = (int64_t)half * 64 * TGP_PW;
-                gemm_tile_dtv<4, TGP_PW, NSEG, 1>(P0 + oa + ho, P0 + obb, C + ho, NSEG > 1 ? P1 + oa + ho : nullptr, NSEG > 1 ? P1 + obb : nullptr);
-            }
-        }
-        if (head) {                              // counted in, valid or not (the target is the number of head ENTRIES), once the tile is in memory
-            if (ti >= 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            }
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(queue + TGP_QUEUE_HEAD, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const int64_t ho = (int64_t)half * 64 * TGP_PW;
+            gemm_tile_dtv<4, TGP_PW, NSEG, 1>(P0 + oa + ho, P0 + obb, C + ho, NSEG > 1 ? P1 + oa + ho : nullptr, NSEG > 1 ? P1 + obb : nullptr);
         }
 #ifdef TGP_POTRF_STAMPS
-        if (ti >= 0 && threadIdx.x == 0 && T == tgp_queue_stamp_T) {
+        if (threadIdx.x == 0 && T == tgp_queue_stamp_T) {
             tgp_queue_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
             tgp_queue_stamps[blockIdx.x * 4 + 3] = ++my_tiles;
         }
 #endif
-    }
-    if (!fill.P) return;
-    // ---- the queues are dry: pieces of the next strip --------------------------------------------------------------------
-    {
-        unsigned *hq = queue + TGP_QUEUE_HEAD;
-        if (threadIdx.x == 0) {
-            unsigned ok = 1u;
-            const unsigned target = 8u * head_pc;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            unsigned it = 0;
-            for (;;) {
-                const unsigned done = __hip_atomic_load(hq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned fv = __hip_atomic_load(fill.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (done >= target && (int)(fv - fill.seq) >= 0) break;
-                __builtin_amdgcn_s_sleep(8);
-                if ((++it & 63u) == 0u) {
-                    const bool late = __builtin_amdgcn_s_memrealtime() - t0 > PANEL_SPIN_TICKS;
-                    if (late || __hip_atomic_load(hq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                        __hip_atomic_store(hq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (late) __hip_atomic_store(fill.info, -7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = 0u;
-                        break;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            s_slot = ok;
-        }
-        __syncthreads();
-        const bool ok = s_slot != 0u;
-        __syncthreads();
-        if (!ok) return;
-        for (;;) {
-            if (threadIdx.x == 0) s_slot = atomicAdd(hq + 1, 1u);
-            __syncthreads();
-            const unsigned p = s_slot;
-            __syncthreads();
-            if (p >= fill.pieces) break;
-            const int tj = (int)(p % (unsigned)hc);       // as syrk_strip32_kernel: 128-column tile, 32-row quarter tile
-            const int tq = (int)(p / (unsigned)hc);
-            const int ti = tq >> 2;
-            if (ti < tj || ti >= T) continue;
-            const int64_t pj = ob + (tj >> 1);
-            const int64_t I = (int64_t)TGP_PW * ob + (int64_t)32 * tq;
-            double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
-            gemm_tile_dtv32<TGP_PW, 1>(fill.P + (int64_t)tq * 32 * TGP_PW, fill.P + (int64_t)tj * TGP_TB * TGP_PW, C, nullptr, nullptr);
-#ifdef TGP_POTRF_STAMPS
-            if (threadIdx.x == 0 && T == tgp_queue_stamp_T) tgp_queue_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
-        }
     }
 }
 
@@ -494,18 +394,6 @@ __device__ __forceinline__ void head_done(const HeadSignal &h) {
             if (old + 1u == h.target) __hip_atomic_store(h.flag, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-}
-
-// gemm_col_small_kernel whose workgroups count themselves in and whose last one publishes a flag (h.done == nullptr: no
-// hand-off by flags, the caller records an event behind the launch): the rows' last step X1 = R1 W1^T for the FIRST tile row
-// below a panel.  That tile row is all the next diagonal block needs of it; the other rows' solve and the rest of the strip
-// run on another stream from the moment this flag is up (run_pairs).
-template <int MODE, int LDB>
-__global__ __launch_bounds__(256) void gemm_col_small_sig_kernel(const double *A, const double *B, double *C, HeadSignal h) {
-    const int64_t o = (int64_t)blockIdx.x * 16 * TGP_PW;
-    TGP_CHAIN_PRIO();
-    nt_small_tile<MODE, TGP_TB, 1>(A + o, TGP_PW, B, LDB, C + o, TGP_PW, nullptr, nullptr);
-    if (h.done) head_done(h);
 }
 
 // Trailing update with a compile-time list of NSEG factored panels (depth 256 * NSEG): P.a[s] points at the row of
@@ -733,35 +621,19 @@ __global__ void set_identity128_kernel(double *__restrict__ W) {
     W[t] = (t >> 7) == (t & 127) ? 1.0 : 0.0;
 }
 
-// the rows' last step X1 = R1 W1^T for tile rows [t0, t1) below the panel's 256 x 256 diagonal block
-inline int panel_small_rows() {          // few row blocks: 16-row slices spread a block over 8 workgroups (latency); many: 128-row tiles (throughput)
-    static const int v = [] { const char *e = getenv("TGP_SMALL_ROWS"); return e ? atoi(e) : 40; }();
-    return v;
-}
-void rows_last_step(hipStream_t st, double *Pk, const double *W1, int t0, int t1) {
-    if (t1 <= t0) return;
-    double *R2 = Pk + (int64_t)TGP_PW * TGP_PW + TGP_TB + (int64_t)t0 * TGP_TB * TGP_PW;    // row 256 + 128 t0, column 128
-    const int r = t1 - t0;
-    if (r <= panel_small_rows()) gemm_col_small_kernel<0, TGP_TB><<<r * 8, 256, 0, st>>>(R2, W1, R2);
-    else gemm_col_kernel<0, TGP_TB><<<r, 256, 0, st>>>(R2, W1, R2);
-}
-
 // `n_data` (>= 0): order of the matrix before padding.  When the second 128-block of a panel lies entirely in the padding
 // (possible for the last panel only) it is the identity and its own factor: no potrf128, no update of it, W1 = I.
 // `mid_sync` != nullptr: the step between the two diagonal blocks runs as panel_mid_kernel (one launch, in-kernel hand-offs, the
 // second diagonal block inside it); `cu_budget` = compute units its workgroups can expect to find free (each takes a whole one)
-// `rows_last` false: without the rows' last step (X1 = R1 W1^T for the rows below the diagonal block): the caller splits it
-// (run_pairs).  `after_diag0`: called between the first diagonal block and the rest (a stream wait for what only the rest needs).
 void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_info, int base, bool exclusive = false,
-                  int64_t n_data = -1, unsigned *mid_sync = nullptr, int cu_budget = 0, bool rows_last = true,
-                  const std::function<void()> *after_diag0 = nullptr) {
+                  int64_t n_data = -1, unsigned *mid_sync = nullptr, int cu_budget = 0) {
     double *W1 = W0 + TGP_TB * TGP_TB;
     double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
     const int r1 = (int)((mk - TGP_TB) / TGP_TB);
-    const int small_rows = panel_small_rows();
+    // few row blocks: 16-row slices spread a block over 8 workgroups (latency); many: 128-row tiles (throughput)
+    static const int small_rows = [] { const char *e = getenv("TGP_SMALL_ROWS"); return e ? atoi(e) : 40; }();
     const bool solo = cu_budget >= 256 && mid_sync != nullptr;      // callers pass the whole chip only where the chain runs alone
     run_potrf128(st, Pk, TGP_PW, W0, d_info, base, exclusive, solo);
-    if (after_diag0) (*after_diag0)();
     if (n_data >= 0 && (int64_t)base + TGP_TB >= n_data && mk == TGP_PW) {
         gemm_col_small_kernel<0, TGP_TB><<<8, 256, 0, st>>>(R1, W0, R1);      // rows 128..255: zero, or the right-hand side row
         set_identity128_kernel<<<64, 256, 0, st>>>(W1);
@@ -804,7 +676,11 @@ void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_inf
         }
         run_potrf128(st, R1 + TGP_TB, TGP_PW, W1, d_info, base + TGP_TB, exclusive, solo);
     }
-    if (r2 > 0 && rows_last) rows_last_step(st, Pk, W1, 0, r2);
+    if (r2 > 0) {
+        double *R2 = Pk + (int64_t)TGP_PW * TGP_PW + TGP_TB;    // row 256, column 128
+        if (r2 <= small_rows) gemm_col_small_kernel<0, TGP_TB><<<r2 * 8, 256, 0, st>>>(R2, W1, R2);
+        else gemm_col_kernel<0, TGP_TB><<<r2, 256, 0, st>>>(R2, W1, R2);
+    }
 }
 
 inline int small_t() {          // steps with at most this many tile rows run on the latency tile (16-row slices)
@@ -812,19 +688,18 @@ inline int small_t() {          // steps with at most this many tile rows run on
     return v;
 }
 
-// `skip00` (strips of at most strip32_t tile rows only): without tile (0, 0)
 template <int NSEG>
-void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int strip, const double *P0, const double *P1, int skip00 = 0) {
+void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int strip, const double *P0, const double *P1) {
     if (T <= 0) return;
     if (T <= small_t()) {
         const int cols = strip == 0 ? T : (strip < T ? strip : T);
-        syrk_small_kernel<NSEG><<<dim3((unsigned)(T * 8), (unsigned)cols), 256, 0, st>>>(d_A, Np, ob, T, P0, P1, skip00);
+        syrk_small_kernel<NSEG><<<dim3((unsigned)(T * 8), (unsigned)cols), 256, 0, st>>>(d_A, Np, ob, T, P0, P1);
         return;
     }
     static const int strip64_t = [] { const char *e = getenv("TGP_STRIP64_T"); return e ? atoi(e) : 128; }();
     static const int strip32_t = [] { const char *e = getenv("TGP_STRIP32_T"); return e ? atoi(e) : 64; }();
     if (strip > 0 && T <= strip32_t) {
-        syrk_strip32_kernel<NSEG><<<(unsigned)((int64_t)4 * T * strip), 256, 0, st>>>(d_A, Np, ob, T, strip, P0, P1, skip00);
+        syrk_strip32_kernel<NSEG><<<(unsigned)((int64_t)4 * T * strip), 256, 0, st>>>(d_A, Np, ob, T, strip, P0, P1);
         return;
     }
     if (strip > 0 && T <= strip64_t) {
@@ -836,43 +711,33 @@ void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int str
 }
 
 // The depth-512 bulk update after the pair (k, k+1) as the persistent grid that keeps compute units clear for the chain.
-// How many of them (1 .. 3 per shader engine = 32 .. 96 CUs): as many as leave the bulk -- tiles x ~130 us over the
-// remaining slots -- shorter than the chain (~400 us per pair of panels): with 64 CUs the panel GEMMs run one workgroup
-// per CU (22 instead of 40 us) and the strips in one round.
+// How many of them (1 .. 3 per shader engine and XCD = 32 .. 96 CUs) by the trailing matrix's tile rows T, from the chain's own
+// timeline (tools/chain_gaps.py: in-kernel stamps of the diagonal blocks, no profiler) with 1, 2 and 3 forced, per pair of
+// panels at N = 8192 (profiles/r05_queue_res_per_pair.txt; cycle = chain + what it waits for the bulk's stream):
+//   T       56    52    48    44    40    36    32    28    24    20
+//   1      613   557   482   449   419   368   316   271   268   235    us per cycle
+//   2      670   601   526   453   388   333   284   270   253   238
+//   3      749   676   569   500   434   369   293   260   243   235
+// Until round 5 the rule was "as many as leave the bulk shorter than the chain's ~400 us" with one threshold for both steps
+// (TGP_QUEUE_BULK_US): 3 from T = 43 down, where the chain then waited 150 - 220 us per pair for the bulk.
 int queued_nres(int T) {
     static const int queue_res = [] { const char *e = getenv("TGP_QUEUE_RES"); return e ? atoi(e) : 0; }();
     if (queue_res > 0) return queue_res > TGP_QUEUE_MAXRES ? TGP_QUEUE_MAXRES : queue_res;
-    static const int bulk_us = [] { const char *e = getenv("TGP_QUEUE_BULK_US"); return e ? atoi(e) : 400; }();
-    const int64_t tiles = (int64_t)T * (T + 1) / 2;
-    for (int r = 3; r > 1; --r) {
-        const int64_t slots = 512 - 64 * r;
-        if ((tiles + slots - 1) / slots * 130 <= bulk_us) return r;
-    }
-    return 1;
+    static const int t1 = [] { const char *e = getenv("TGP_QUEUE_T1"); return e ? atoi(e) : 42; }();      // one from here up
+    static const int t2 = [] { const char *e = getenv("TGP_QUEUE_T2"); return e ? atoi(e) : 30; }();      // two from here up
+    return T >= t1 ? 1 : (T >= t2 ? 2 : 3);
 }
-// `fillP` != nullptr: the launch takes its head columns first and fills its ragged end with the pieces of the next strip
-// (QueueFill above); `fill_flag`: the flag id on which the chain's stream announces panel k+2
 void launch_syrk2_queued(tgp_ctx *ctx, hipStream_t st, double *d_A, int64_t Np, int ob, int T, const double *P0, const double *P1,
-                         int nqueue, const double *fillP = nullptr, int fill_flag = 0) {
+                         int nqueue) {
     const int nres = queued_nres(T);
     // the last round of a class (as many slots as it has resident workgroups) runs as half tiles; TGP_QUEUE_HALF = slots per class, 0 off
     static const int half_env = [] { const char *e = getenv("TGP_QUEUE_HALF"); return e ? atoi(e) : -1; }();
-    QueueFill fill;
-    if (fillP) {
-        fill.P = fillP;
-        fill.cols = 4;
-        fill.head_per_class = (unsigned)((4 * T + 7) / 8);
-        fill.pieces = (unsigned)(4 * T * 4);
-        fill.flag = ctx->d_flags + 16 * fill_flag;
-        fill.seq = ctx->flag_seq[fill_flag];
-        fill.info = ctx->d_info;
-    }
-    const unsigned slots = (unsigned)(tilemap_grid(T - fill.cols) / 8);
+    const unsigned slots = (unsigned)(tilemap_grid(T) / 8);
     unsigned nhalf = half_env >= 0 ? (unsigned)half_env : (unsigned)(512 - 64 * nres) / 8u;
     if (nhalf > slots) nhalf = slots;
     static const int steal = [] { const char *e = getenv("TGP_QUEUE_STEAL"); return e ? atoi(e) : 1; }();
-    syrk_dtv_queue_kernel<2><<<512 + 8, 256, 0, st>>>(d_A, Np, ob, T, fill.head_per_class + slots + nhalf, slots - nhalf, nres,
-                                                     ctx->d_queue + TGP_QUEUE_WORDS * nqueue, P0, P1, steal, fill);
+    syrk_dtv_queue_kernel<2><<<512 + 8, 256, 0, st>>>(d_A, Np, ob, T, slots + nhalf, slots - nhalf, nres,
+                                                     ctx->d_queue + TGP_QUEUE_WORDS * nqueue, P0, P1, steal);
 }
 }  // namespace
 
@@ -913,7 +778,6 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     const int mode = mode_env >= 0 ? mode_env : (!ctx->lookahead ? 1 : (Np >= 22528 ? 3 : (Np <= 1280 ? 1 : 2)));
     if (mode >= 2) {
         int rc = tgp_ensure_side_stream(ctx);
-        if (!rc) rc = tgp_ensure_aux_stream(ctx);
         if (rc) return rc;
     }
     double flops = 0.0;
@@ -948,124 +812,28 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
     if (Np / TGP_TB - 8 > small_t())          // some step can take the queued form (T3 = Np/128 - 8 at the first pair)
         TGP_HIP(hipMemsetAsync(ctx->d_queue, 0, TGP_NQUEUE * TGP_QUEUE_WORDS * sizeof(unsigned), st));
     auto psync = [&](int k) { return (mid_on && k < TGP_PSYNC_PANELS) ? ctx->d_psync + PANEL_SYNC_WORDS * k : nullptr; };
-    // ---- the boundaries of the panel chain (round 5) -------------------------------------------------------------------------
-    // Behind a panel the chain used to run the rows' last step (X1 = R1 W1^T, all rows) and then the strip that brings the next
-    // panel's columns up to date (all rows; between two pairs on the other stream, with a hand-over each way) before the next
-    // diagonal block could start: 27 us between the panels of a pair, 35 us between pairs where everything else is 4 x (25 + 19).
-    // That block needs one TILE of the strip, and the tile needs one tile row of X1.  With `usplit` the chain runs just those --
-    // eight 16-row slices each, `urgent_rows` and `urgent_tile` -- and goes on with the diagonal block; the other rows and the
-    // rest of the strip run beside it on a third stream (between pairs: on the bulk's), from the moment the urgent rows'
-    // workgroups have counted themselves in (flag 5, published inside the kernel), and the chain waits for them after the
-    // diagonal block, before the first kernel that needs more than that tile.  Pure scheduling: the same launches whatever the
-    // hand-off mode and whether or not the solve is alone (with events the flag is an event record behind the urgent rows).
-    static const bool us_env = [] { const char *e = getenv("TGP_USPLIT"); return e ? atoi(e) != 0 : true; }();
-    static const int us_t = [] {            // tile rows up to which (the strips then run as 32-row tiles or 16-row slices: skip00)
-        const char *e = getenv("TGP_USPLIT_T");
-        const char *s32 = getenv("TGP_STRIP32_T");
-        const int lim = s32 ? atoi(s32) : 64, v = e ? atoi(e) : 64;
-        return v < lim ? v : (lim > small_t() ? lim : small_t());
-    }();
-    const bool byflags = mode >= 2 && tgp_handoff_by_flags(ctx);
-    int us_rc = 0;          // first failure of a hand-off call inside the lambdas below
-    auto hip_ok = [&](hipError_t e) {
-        if (e != hipSuccess && !us_rc) {
-            ctx->err = std::string("panel boundary hand-off: ") + hipGetErrorString(e);
-            us_rc = -2;
-        }
-    };
-    // rows' last step for the first tile row below panel kk, announcing itself on flag 5
-    auto urgent_rows = [&](hipStream_t s, int kk) {
-        HeadSignal hs;
-        if (byflags) {
-            hipError_t e = hipSuccess;
-            hs.seq = tgp_next_seq(ctx, 5, &e);
-            hip_ok(e);
-            hs.flag = ctx->d_flags + 16 * 5;
-            hs.done = ctx->d_flags + 16 * TGP_FLAG_URGENT_COUNT;
-            ctx->urgent_count += 8u;
-            hs.target = ctx->urgent_count;
-        }
-        double *R2 = panel(kk) + (int64_t)TGP_PW * TGP_PW + TGP_TB;
-        gemm_col_small_sig_kernel<0, TGP_TB><<<8, 256, 0, s>>>(R2, Wk(kk) + TGP_TB * TGP_TB, R2, hs);
-        if (!byflags) hip_ok(hipEventRecord(ctx->ev[7], s));
-    };
-    auto rest_rows = [&](hipStream_t s, int kk) {
-        const int r2 = (int)((Np - (int64_t)TGP_PW * (kk + 1)) / TGP_TB);
-        rows_last_step(s, panel(kk), Wk(kk) + TGP_TB * TGP_TB, 1, r2);
-    };
-    // tile (0, 0) of the trailing matrix at block ob (its first diagonal tile) -= P P^T over the 128 rows of P, depth 256
-    auto urgent_tile = [&](hipStream_t s, int ob, const double *P) {
-        const int T = (int)((Np - (int64_t)TGP_PW * ob) / TGP_TB);
-        syrk_small_kernel<1><<<dim3(8u, 1u), 256, 0, s>>>(d_A, Np, ob, T, P, nullptr);
-    };
     auto run_pairs = [&](int kstart) -> int {
-        hipStream_t sd = ctx->side_stream, sa = ctx->aux_stream;
+        hipStream_t sd = ctx->side_stream;
         // `cus` > 0: the chain has that many compute units to itself (the whole chip, or the ones a queued bulk update keeps
         // clear) -- the step between a panel's two diagonal blocks then runs as panel_mid_kernel
-        struct PairArgs {
-            bool exclusive = false;
-            int cus = 0;
-            bool tell = false;          // say on flag 2 when panel k is complete (its part of the next U2a is then applied early, see below)
-            bool split_in = false;      // the boundary between the pair's panels is split (urgent tile on the chain, the rest on the aux stream)
-            bool split_out = false;     // ... and the one behind the pair (the rest on the bulk's stream)
-            int await0 = -1;            // flag the chain waits for after panel k's first diagonal block (the rest of the boundary before the pair)
-        };
-        auto sync_of = [&](const PairArgs &a, int kk) { return (a.cus > 0 && mid_on && kk < TGP_PSYNC_PANELS) ? ctx->d_psync + PANEL_SYNC_WORDS * kk : nullptr; };
-        const hipEvent_t ev_of[8] = {ctx->ev[4], ctx->ev[5], ctx->ev[6], nullptr, nullptr, ctx->ev[7], ctx->ev[8], ctx->ev[9]};
-        // F(k) and what follows it up to (not including) F(k+1)
-        auto pair_first = [&](hipStream_t s, int k, const PairArgs &a) {
+        // `tell`: say on flag 2 when panel k is complete (its part of the next U2a is then applied early, see below)
+        auto factor_pair = [&](hipStream_t s, int k, bool exclusive = false, int cus = 0, bool tell = false) {       // F(k), U1(k), F(k+1)
             const int64_t mk = Np - (int64_t)TGP_PW * k;
-            const std::function<void()> wait0 = [&] { hip_ok(tgp_await(ctx, s, a.await0, ev_of[a.await0])); };
-            const bool has_next = k + 1 < nP;
-            const bool split = a.split_in && has_next;
-            factor_panel(s, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, a.exclusive, n_data, sync_of(a, k), a.cus, !split,
-                         a.await0 >= 0 ? &wait0 : nullptr);
-            if (!split) {
-                if (a.tell) hip_ok(tgp_signal(ctx, s, 2, ctx->ev[6]));
-                if (!has_next) return;
-                const int T1 = (int)((mk - TGP_PW) / TGP_TB);
-                launch_syrk<1>(s, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
-                return;
-            }
-            const int T1 = (int)((mk - TGP_PW) / TGP_TB);
-            const double *P = panel(k) + (int64_t)TGP_PW * TGP_PW;
-            urgent_rows(s, k);
-            urgent_tile(s, k + 1, P);
-            hip_ok(tgp_await(ctx, sa, 5, ctx->ev[7]));
-            rest_rows(sa, k);
-            if (a.tell) hip_ok(tgp_signal(ctx, sa, 2, ctx->ev[6]));
-            launch_syrk<1>(sa, d_A, Np, k + 1, T1, 2, P, nullptr, 1);
-            hip_ok(tgp_signal(ctx, sa, 6, ctx->ev[8]));
-        };
-        // F(k+1) and, where the boundary behind the pair is split, its urgent part (the rest is the bulk stream's: see the loop)
-        auto pair_second = [&](hipStream_t s, int k, const PairArgs &a) {
+            auto sync = [&](int kk) { return (cus > 0 && mid_on && kk < TGP_PSYNC_PANELS) ? ctx->d_psync + PANEL_SYNC_WORDS * kk : nullptr; };
+            factor_panel(s, panel(k), mk, Wk(k), ctx->d_info, k * TGP_PW, exclusive, n_data, sync(k), cus);
+            if (tell) (void)tgp_signal(ctx, s, 2, ctx->ev[6]);
             if (k + 1 >= nP) return;
-            const int64_t mk = Np - (int64_t)TGP_PW * k;
-            const std::function<void()> wait6 = [&] { hip_ok(tgp_await(ctx, s, 6, ctx->ev[8])); };
-            factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, a.exclusive, n_data, sync_of(a, k + 1), a.cus,
-                         !a.split_out, a.split_in ? &wait6 : nullptr);
-            if (!a.split_out) return;
-            urgent_rows(s, k + 1);
-            hip_ok(tgp_await(ctx, s, 7, ctx->ev[9]));          // panel k's half of this U2a is in (bulk stream)
-            urgent_tile(s, k + 2, panel(k + 1) + (int64_t)TGP_PW * TGP_PW);
+            const int T1 = (int)((mk - TGP_PW) / TGP_TB);
+            launch_syrk<1>(s, d_A, Np, k + 1, T1, 2, panel(k) + (int64_t)TGP_PW * TGP_PW, nullptr);
+            factor_panel(s, panel(k + 1), mk - TGP_PW, Wk(k + 1), ctx->d_info, (k + 1) * TGP_PW, exclusive, n_data, sync(k + 1), cus);
         };
-        {
-            PairArgs first;
-            first.cus = 256;
-            pair_first(st, kstart, first);
-            pair_second(st, kstart, first);
-        }
+        factor_pair(st, kstart, false, 256);
         // Chain-bound steps (T3 <= split_t): U2a -- the 4 tile columns of the next pair, depth 512, between F(k+1) and F(k+2) on
         // the critical path -- is taken in two halves of depth 256: panel k's half as soon as panel k is complete, on the bulk's
         // stream beside U1 and F(k+1); only panel k+1's half is left between the pairs (a strip tile of depth 256 takes ~22 us,
         // one of depth 512 ~42).
         static const int split_t = [] { const char *e = getenv("TGP_U2A_SPLIT_T"); return e ? atoi(e) : 64; }();
         bool early = false;         // panel k's half of U2a(k) has been applied already
-        bool split_prev = false;    // the boundary behind pair (k, k+1) is split: its urgent part is on the chain's stream already
-        // TGP_QUEUE_FILL=0: never inside the bulk launch; TGP_QUEUE_FILL_T: from that many tile rows on
-        static const bool fill_env = [] { const char *e = getenv("TGP_QUEUE_FILL"); return e ? atoi(e) != 0 : true; }();
-        static const int fill_t = [] { const char *e = getenv("TGP_QUEUE_FILL_T"); return e ? atoi(e) : 0; }();
-        const bool fill_on = fill_env && mid_on && byflags;
         for (int k = kstart; k + 2 < nP; k += 2) {
             const int T2 = (int)((Np - (int64_t)TGP_PW * (k + 2)) / TGP_TB);       // tiles from block k+2
             const double *P0 = panel(k) + (int64_t)2 * TGP_PW * TGP_PW;
@@ -1076,60 +844,36 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
             const bool queued = T3 <= queue_t && T3 > small_t() && nqueue < TGP_NQUEUE;
             {   // U2a: tile columns 0..3 (panels k+2, k+3)
                 const double rows = (double)T2 * TGP_TB, w = (T2 < 4 ? T2 : 4) * (double)TGP_TB;
-                double elems = w * (rows - w) + w * (w + 1.0) / 2.0;
-                if (split_prev) {       // the chain has done tile (0, 0) and the first tile row of panel k+1's last step
-                    elems -= (double)TGP_TB * (TGP_TB + 1.0) / 2.0;
-                    hip_ok(tgp_await(ctx, st, 5, ctx->ev[7]));
-                    rest_rows(st, k + 1);
-                }
+                const double elems = w * (rows - w) + w * (w + 1.0) / 2.0;
                 int rc = timed([&] {
-                    if (early) launch_syrk<1>(st, d_A, Np, k + 2, T2, 4, P1, nullptr, split_prev ? 1 : 0);
+                    if (early) launch_syrk<1>(st, d_A, Np, k + 2, T2, 4, P1, nullptr);
                     else launch_syrk<2>(st, d_A, Np, k + 2, T2, 4, P0, P1);
                 }, (early ? 1.0 : 2.0) * 2.0 * TGP_PW * elems);
                 if (rc) return rc;
             }
             TGP_HIP(tgp_signal(ctx, st, 0, ctx->ev[4]));
-            if (!split_prev) TGP_HIP(tgp_await(ctx, sd, 0, ctx->ev[4]));
+            TGP_HIP(tgp_await(ctx, sd, 0, ctx->ev[4]));
             const bool early_next = T3 > 0 && T3 <= split_t;
-            const bool us_here = us_env && T2 - 2 <= us_t && T3 > 0;
-            PairArgs a;
-            a.exclusive = queued;
             // (steps with at most small_t tile rows have no bulk update to speak of: the chain has the chip to itself)
-            a.cus = queued ? 32 * queued_nres(T3) : (T3 <= small_t() ? 256 : 0);
-            a.tell = early_next;
-            a.split_in = us_here && k + 3 < nP;
-            a.split_out = us_here && early_next && k + 4 < nP;       // (only where panel k+2's half of the next U2a goes early, and a next step exists)
-            a.await0 = split_prev ? 0 : -1;
-            pair_first(sd, k + 2, a);
-            // Work-bound steps: panel k+2's half of the next U2a is done by the bulk launch's own workgroups as their queues run dry
-            // (QueueFill) instead of a launch behind it.  Flag hand-offs only (the kernel reads the chain's flag word), and under
-            // panel_mid_kernel's policy: a solve that is alone and can be run again.
-            const bool fill = queued && early_next && fill_on && T3 >= fill_t && fill_t > 0;
+            factor_pair(sd, k + 2, queued, queued ? 32 * queued_nres(T3) : (T3 <= small_t() ? 256 : 0), early_next);
+            TGP_HIP(tgp_signal(ctx, sd, 1, ctx->ev[5]));
             if (T3 > 0) {   // U2b: everything from block k+4 on
                 const double m = (double)T3 * TGP_TB;
                 const int64_t skip = (int64_t)4 * TGP_TB * TGP_PW;
                 int rc = timed([&] {
-                    if (queued) launch_syrk2_queued(ctx, st, d_A, Np, k + 4, T3, P0 + skip, P1 + skip, nqueue++,
-                                                    fill ? panel(k + 2) + (int64_t)2 * TGP_PW * TGP_PW : nullptr, 2);
+                    if (queued) launch_syrk2_queued(ctx, st, d_A, Np, k + 4, T3, P0 + skip, P1 + skip, nqueue++);
                     else launch_syrk<2>(st, d_A, Np, k + 4, T3, 0, P0 + skip, P1 + skip);
                 }, 2.0 * TGP_PW * m * (m + 1.0));
                 if (rc) return rc;
             }
-            if (early_next && !fill) {       // panel k+2's half of the next U2a (tile columns of blocks k+4, k+5), once that panel is complete
+            if (early_next) {       // panel k+2's half of the next U2a (tile columns of blocks k+4, k+5), once that panel is complete
                 TGP_HIP(tgp_await(ctx, st, 2, ctx->ev[6]));
                 launch_syrk<1>(st, d_A, Np, k + 4, T3, 4, panel(k + 2) + (int64_t)2 * TGP_PW * TGP_PW, nullptr);
             }
-            if (a.split_out) TGP_HIP(tgp_signal(ctx, st, 7, ctx->ev[9]));
-            pair_second(sd, k + 2, a);
-            if (!a.split_out) {
-                TGP_HIP(tgp_signal(ctx, sd, 1, ctx->ev[5]));
-                TGP_HIP(tgp_await(ctx, st, 1, ctx->ev[5]));
-            }
             early = early_next;
-            split_prev = a.split_out;
-            if (us_rc) return us_rc;
+            TGP_HIP(tgp_await(ctx, st, 1, ctx->ev[5]));
         }
-        return us_rc;
+        return 0;
     };
     if (mode == 0) {
         for (int k = 0; k < nP; ++k) {

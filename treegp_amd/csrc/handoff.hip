@@ -92,7 +92,6 @@ unsigned tgp_next_seq(tgp_ctx *ctx, int id, hipError_t *err) {
         }
         for (unsigned &q : ctx->flag_seq) q = 0;
         ctx->head_count = 0;
-        ctx->urgent_count = 0;
     }
     return ++ctx->flag_seq[id];
 }

@@ -20,8 +20,7 @@
 
 #define TGP_QUEUE_MAXRES 6    // most compute units per shader engine and XCD (of 8) a queued bulk update can keep clear
 #define TGP_QUEUE_LEAVE (8 + 32 * TGP_QUEUE_MAXRES)      // word offset of the 8 leave counters
-#define TGP_QUEUE_HEAD (TGP_QUEUE_LEAVE + 8)       // word offset of: [0] head entries done, [1] fill-piece counter, [2] abort (chol.hip: QueueFill)
-#define TGP_QUEUE_WORDS (TGP_QUEUE_HEAD + 8)   // per launch: 8 XCD-class tile counters + 8 x 4 x MAXRES clear-CU words + 8 leave counters + 8 head / fill words
+#define TGP_QUEUE_WORDS (TGP_QUEUE_LEAVE + 8)   // per launch: 8 XCD-class tile counters + 8 x 4 x MAXRES clear-CU words + 8 leave counters
 #define TGP_NQUEUE 128        // persistent bulk-update launches per factorisation (one set of 8 counters each)
 #define TGP_PSYNC_PANELS 1024 // panels with a counter set of their own (Np <= 262144); 16 words = 64 B each
 #define TGP_TB 128            // tile / diagonal-block size
@@ -32,11 +31,9 @@ struct tgp_ctx {
     hipStream_t stream = nullptr;      // the stream every kernel is launched on
     hipStream_t own_stream = nullptr;  // created by tgp_init
     hipStream_t side_stream = nullptr; // high-priority stream for the Cholesky look-ahead
-    hipStream_t aux_stream = nullptr;  // second high-priority stream: what the panel chain hands off at a panel boundary (chol.hip: run_pairs)
     unsigned *d_flags = nullptr;       // cross-stream hand-off flags (handoff.hip: hand-offs by stream wait-value), 16 x 64 B
     unsigned flag_seq[16] = {0};       // last value signalled on each (monotonic over the context's life)
     unsigned head_count = 0;           // value of the head-tile counter (flag word TGP_FLAG_HEAD_COUNT) after the last fused launch
-    unsigned urgent_count = 0;         // ... and of the word TGP_FLAG_URGENT_COUNT, on which the slices of a panel's urgent row solve count themselves in
     int handoff = 0;                   // 0 undecided, 1 flags + stream wait-value, 2 events (tgp_handoff_by_flags)
     bool ext_stream = false;           // stream was set by tgp_set_stream
     bool ext_side_stream = false;      // side_stream was lent by tgp_set_side_stream
@@ -44,7 +41,7 @@ struct tgp_ctx {
     double timings[TGP_NTIMINGS] = {0};
     int profiling = 0;
     int lookahead = 1;                 // 0: factorise on the one stream (tgp_set_lookahead; for contexts that run side by side)
-    hipEvent_t ev[12] = {nullptr};
+    hipEvent_t ev[8] = {nullptr};
     // grow-only scratch
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -187,7 +184,6 @@ __host__ __device__ inline void tilemap(int64_t b, int64_t T, int &ti, int &tj) 
 
 // implemented across the .hip files
 int tgp_ensure_side_stream(tgp_ctx *ctx);
-int tgp_ensure_aux_stream(tgp_ctx *ctx);
 int tgp_ensure_scratch(tgp_ctx *ctx, size_t bytes);
 int tgp_ensure_scratch2(tgp_ctx *ctx, size_t bytes);
 // grow-only PINNED host scratch of the context (api.hip): host-built tables that are uploaded whole are built in it, so that the
@@ -212,9 +208,6 @@ extern std::atomic<int> tgp_solves_in_flight;
 // done" signal of a fused multi-GPU bulk launch, TGP_FLAG_HEAD_COUNT the word its workgroups count themselves in on.
 #define TGP_FLAG_HEAD 8
 #define TGP_FLAG_HEAD_COUNT 9
-// 2: "panel k+2 complete"; 5: "first tile row below a panel solved" (published inside the kernel), 6: aux stream -> chain,
-// 7: "panel k's half of the next U2a applied" (bulk stream -> chain); TGP_FLAG_URGENT_COUNT: counter word of flag 5
-#define TGP_FLAG_URGENT_COUNT 10
 bool tgp_handoff_by_flags(tgp_ctx *ctx);
 unsigned tgp_next_seq(tgp_ctx *ctx, int id, hipError_t *err);
 hipError_t tgp_signal_value(tgp_ctx *ctx, hipStream_t from, int id, unsigned v);
