@@ -145,6 +145,7 @@ def test_golden_config1_and_aniso2d(tg, golden):
                                  {"TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "0"}, {"TGP_CHOL_MODE": "3", "TGP_QUAD_TAIL_TILES": "8"},
                                  {"TGP_CHOL_MODE": "3", "TGP_SMALL_T": "0", "TGP_SMALL_ROWS": "0"}, {"TGP_PREDICT_GENERIC": "1"},
                                  {"TGP_QUEUE_T": "0"}, {"TGP_QUEUE_T": "200"}, {"TGP_STRIP64_T": "0"}, {"TGP_NO_AUGMENT": "1"},
+                                 {"TGP_QUEUE_T1": "0"}, {"TGP_QUEUE_T1": "200", "TGP_QUEUE_T2": "0"}, {"TGP_QUEUE_T1": "200", "TGP_QUEUE_T2": "200"},
                                  {"TGP_U2A_SPLIT_T": "0"}, {"TGP_STRIP32_T": "0"}, {"TGP_U2A_SPLIT_T": "200", "TGP_STRIP32_T": "200"},
                                  {"TGP_U2A_SPLIT_T": "200", "TGP_SYNC_EVENTS": "1"}, {"TGP_U2A_SPLIT_T": "200", "TGP_PANEL_MID": "0"},
                                  {"TGP_PREDICT_EXP": "0"}, {"TGP_PREDICT_EXP": "32"}, {"TGP_PREDICT_EXP": "64"},

@@ -724,7 +724,7 @@ int queued_nres(int T) {
     static const int queue_res = [] { const char *e = getenv("TGP_QUEUE_RES"); return e ? atoi(e) : 0; }();
     if (queue_res > 0) return queue_res > TGP_QUEUE_MAXRES ? TGP_QUEUE_MAXRES : queue_res;
     static const int t1 = [] { const char *e = getenv("TGP_QUEUE_T1"); return e ? atoi(e) : 42; }();      // one from here up
-    static const int t2 = [] { const char *e = getenv("TGP_QUEUE_T2"); return e ? atoi(e) : 30; }();      // two from here up
+    static const int t2 = [] { const char *e = getenv("TGP_QUEUE_T2"); return e ? atoi(e) : 26; }();      // two from here up (30, 26, 22: equal within the spread; profiles/r05_queue_rule_ab.txt)
     return T >= t1 ? 1 : (T >= t2 ? 2 : 3);
 }
 void launch_syrk2_queued(tgp_ctx *ctx, hipStream_t st, double *d_A, int64_t Np, int ob, int T, const double *P0, const double *P1,
