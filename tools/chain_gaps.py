@@ -29,4 +29,5 @@ tot_gap = 0.0
 for p in range(0, nblk // 4):
     b = 4 * p
     nxt = st[b + 4] if b + 4 < nblk else float("nan")
-    print("  pair %2d (T3 %3d)  %8.1f  %7.1f  %7.1f  %7.1f" % (p, n // 128 - 4 * p - 8, st[b], en[b + 3] - st[b], nxt - en[b + 3], nxt - st[b]))
+    # (T3: tile rows of the bulk update that runs beside this pair's chain -- the one after the pair before it)
+    print("  pair %2d (T3 %3d)  %8.1f  %7.1f  %7.1f  %7.1f" % (p, max(n // 128 - 4 * p - 4, 0) if p else 0, st[b], en[b + 3] - st[b], nxt - en[b + 3], nxt - st[b]))
