@@ -23,6 +23,14 @@ __device__ unsigned long long tgp_gemm_stamps[1024 * 4];
 __device__ int tgp_gemm_stamp_grid = 43;
 __device__ unsigned long long tgp_queue_stamps[1024 * 4];      // queued bulk update with T == tgp_queue_stamp_T: per workgroup
 __device__ int tgp_queue_stamp_T = 40;
+__device__ unsigned long long tgp_mid_stamps[17 * 8];          // panel_mid_kernel of the panel whose first row is tgp_mid_stamp_base: workgroups 0 .. 16
+__device__ int tgp_mid_stamp_base = 5120;
+#define TGP_MID_STAMP(i)                                                                                   \
+    do {                                                                                                   \
+        if (threadIdx.x == 0 && base == tgp_mid_stamp_base && blockIdx.x < 17) tgp_mid_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define TGP_MID_STAMP(i) ((void)0)
 #endif
 
 namespace {
@@ -165,22 +173,30 @@ __global__ __launch_bounds__(256) void panel_mid_kernel(double *Pk, const double
     TGP_CHAIN_PRIO();
     const int b = blockIdx.x;
     double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
+    TGP_MID_STAMP(0);
     if (b < 8) {
         double *rows = R1 + (int64_t)b * 16 * TGP_PW;
         nt_small_tile<0, TGP_TB, 1>(rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
+        TGP_MID_STAMP(1);
         panel_publish(sync + 0);
+        TGP_MID_STAMP(2);
         return;
     }
     if (b < 16) {
         if (!panel_wait(sync, 0, 8u, info)) return;
+        TGP_MID_STAMP(1);
         double *rows = R1 + (int64_t)(b - 8) * 16 * TGP_PW;
         nt_small_tile<1, TGP_TB, 1>(rows, TGP_PW, R1, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
+        TGP_MID_STAMP(2);
         panel_publish(sync + 1);
+        TGP_MID_STAMP(3);
         return;
     }
     if (b == 16) {
         if (!panel_wait(sync, 1, 8u, info)) return;
+        TGP_MID_STAMP(1);
         potrf_v2::potrf128_body<true>(T, R1 + TGP_TB, TGP_PW, W1, info, base + TGP_TB);
+        TGP_MID_STAMP(2);
         return;
     }
     if constexpr (SMALLROWS) {
@@ -1223,6 +1239,10 @@ extern "C" int tgp_debug_gemm_stamps(unsigned long long *out, int grid) {
 extern "C" int tgp_debug_queue_stamps(unsigned long long *out, int T) {
     if (T > 0) return (int)hipMemcpyToSymbol(HIP_SYMBOL(tgp_queue_stamp_T), &T, sizeof(int));
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_queue_stamps), 1024 * 4 * sizeof(unsigned long long));
+}
+extern "C" int tgp_debug_mid_stamps(unsigned long long *out, int base) {
+    if (base >= 0) return (int)hipMemcpyToSymbol(HIP_SYMBOL(tgp_mid_stamp_base), &base, sizeof(int));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_mid_stamps), 17 * 8 * sizeof(unsigned long long));
 }
 extern "C" int tgp_debug_potrf_fine(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_potrf_fine), 1024 * 8 * sizeof(unsigned long long));      // [block][sub-step]
