@@ -57,7 +57,7 @@ template <int MODE, int LDB>
 __global__ __launch_bounds__(256) void gemm_col_small_kernel(const double *A, const double *B, double *C) {
     const int64_t o = (int64_t)blockIdx.x * 16 * TGP_PW;
     TGP_CHAIN_PRIO();
-    nt_small_tile<MODE, TGP_TB, 1>(A + o, TGP_PW, B, LDB, C + o, TGP_PW, nullptr, nullptr);
+    nt_slice_tile<MODE, TGP_TB, 1>(nt_slice_lds_storage(), A + o, TGP_PW, B, LDB, C + o, TGP_PW, nullptr, nullptr);
 }
 // Rows below a factored 256 x 256 diagonal block, all three steps of their solve in one launch: X0 = R0 W0^T,
 // R1 -= X0 L10^T, X1 = R1 W1^T (R0 | R1 = the two 128-column halves of the rows, L10 = rows 128..255 of the block's first
@@ -94,13 +94,14 @@ __global__ __launch_bounds__(256) void panel_tall_small_kernel(double *rows0, co
     double *rows = rows0 + (int64_t)blockIdx.x * 16 * TGP_PW;
     TGP_CHAIN_PRIO();
     keep_w_share(keep, W0);
-    nt_small_tile<0, TGP_TB, 1>(rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
+    double *lds = nt_slice_lds_storage();
+    nt_slice_tile<0, TGP_TB, 1>(lds, rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's X0 is in the L2 before the others read it
     __syncthreads();
-    nt_small_tile<1, TGP_TB, 1>(rows, TGP_PW, L10, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
+    nt_slice_tile<1, TGP_TB, 1>(lds, rows, TGP_PW, L10, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    nt_small_tile<0, TGP_TB, 1>(rows + TGP_TB, TGP_PW, W1, TGP_TB, rows + TGP_TB, TGP_PW, nullptr, nullptr);
+    nt_slice_tile<0, TGP_TB, 1>(lds, rows + TGP_TB, TGP_PW, W1, TGP_TB, rows + TGP_TB, TGP_PW, nullptr, nullptr);
 }
 
 // rows 128..255 of a 256 x 256 diagonal block between its two potrf128 calls, one workgroup, one launch:
@@ -170,13 +171,14 @@ __global__ __launch_bounds__(256) void panel_mid_kernel(double *Pk, const double
     // one LDS image for every role: potrf128's 96 KB; the 128-row GEMM tile stages its operands in the first 70 KB of it
     __shared__ __attribute__((aligned(16))) double T[potrf_v2::POTRF_LDS_DOUBLES];
     static_assert(potrf_v2::POTRF_LDS_DOUBLES >= 2 * 2 * 128 * TileDefault::LS, "the GEMM tile's staging fits in potrf128's image");
+    static_assert(potrf_v2::POTRF_LDS_DOUBLES >= NT_SLICE_LDS_DOUBLES, "... and the latency tile's");
     TGP_CHAIN_PRIO();
     const int b = blockIdx.x;
     double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
     TGP_MID_STAMP(0);
     if (b < 8) {
         double *rows = R1 + (int64_t)b * 16 * TGP_PW;
-        nt_small_tile<0, TGP_TB, 1>(rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
+        nt_slice_tile<0, TGP_TB, 1>(T, rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
         TGP_MID_STAMP(1);
         panel_publish(sync + 0);
         TGP_MID_STAMP(2);
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void panel_mid_kernel(double *Pk, const double
         if (!panel_wait(sync, 0, 8u, info)) return;
         TGP_MID_STAMP(1);
         double *rows = R1 + (int64_t)(b - 8) * 16 * TGP_PW;
-        nt_small_tile<1, TGP_TB, 1>(rows, TGP_PW, R1, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
+        nt_slice_tile<1, TGP_TB, 1>(T, rows, TGP_PW, R1, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
         TGP_MID_STAMP(2);
         panel_publish(sync + 1);
         TGP_MID_STAMP(3);
@@ -201,11 +203,11 @@ __global__ __launch_bounds__(256) void panel_mid_kernel(double *Pk, const double
     }
     if constexpr (SMALLROWS) {
         double *rows = Pk + (int64_t)TGP_PW * TGP_PW + (int64_t)(b - 17) * 16 * TGP_PW;
-        nt_small_tile<0, TGP_TB, 1>(rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
+        nt_slice_tile<0, TGP_TB, 1>(T, rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's X0 is in the L2 before the others read it
         __syncthreads();
         if (!panel_wait(sync, 0, 8u, info)) return;
-        nt_small_tile<1, TGP_TB, 1>(rows, TGP_PW, R1, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
+        nt_slice_tile<1, TGP_TB, 1>(T, rows, TGP_PW, R1, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
     } else {
         double *rows = Pk + (int64_t)TGP_PW * TGP_PW + (int64_t)(b - 17) * 128 * TGP_PW;
         gemm_tile_128_at<0, TGP_TB, TGP_TB>(T, rows, W0, rows);
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void syrk_small_kernel(double *Abase, int64_t 
     const int64_t I = (int64_t)TGP_PW * ob + 16 * (int64_t)ri;
     double *C = Abase + panel_off(pj, Np) + (I - pj * TGP_PW) * TGP_PW + (tj & 1) * TGP_TB;
     const int64_t oa = (int64_t)ri * 16 * TGP_PW, obb = (int64_t)tj * TGP_TB * TGP_PW;
-    nt_small_tile<1, TGP_PW, NSEG>(P0 + oa, TGP_PW, P0 + obb, TGP_PW, C, TGP_PW, NSEG > 1 ? P1 + oa : nullptr,
+    nt_slice_tile<1, TGP_PW, NSEG>(nt_slice_lds_storage(), P0 + oa, TGP_PW, P0 + obb, TGP_PW, C, TGP_PW, NSEG > 1 ? P1 + oa : nullptr,
                                    NSEG > 1 ? P1 + obb : nullptr);
 }
 

@@ -522,6 +522,98 @@ __device__ __forceinline__ void nt_small_tile(const double *a, int lda, const do
 }
 
 
+// ---- the latency tile staged through LDS ------------------------------------------------------------------------------------
+// The same 16 x 128 slice of C, the same matrix instructions in the same order (same bits), but the operands are fetched with
+// whole-row loads -- a wave's load instruction covers two 512-byte row pieces instead of 16-byte pieces of 16 different rows --
+// into registers, written to LDS in blocks of 64 k (B 128 x 64, A 16 x 64, row stride 66 doubles: the fragment reads of eight
+// consecutive lanes fall into eight different 16-byte bank groups) and read back in MFMA layout.  The direct-from-global form
+// above spends 6.7 us on a K = 128 slice whose matrix instructions take 1.7 (in-kernel stamps, profiles/r05_mid_stamps.txt),
+// with all its loads in flight at once or not: the vector-memory pipeline's rate on 192 wave instructions that touch 16 cache
+// lines each.  `lds`: NT_SLICE_LDS_DOUBLES doubles, 16-byte aligned, not used by anyone else during the call.
+typedef double d2v __attribute__((ext_vector_type(2)));
+constexpr int NT_SLICE_LS = 66;
+constexpr int NT_SLICE_LDS_DOUBLES = (128 + 16) * NT_SLICE_LS;
+template <int MODE, int KDEPTH, int NSEG>
+__device__ __forceinline__ void nt_slice_tile(double *lds, const double *a, int lda, const double *b, int ldb, double *c, int ldc,
+                                              const double *a1, const double *b1) {
+    constexpr int LS = NT_SLICE_LS, KBLK = 64;
+    constexpr int BPS = KDEPTH / KBLK, NB = NSEG * BPS;          // blocks per segment / in all
+    static_assert(KDEPTH % KBLK == 0 && NB >= 1, "whole blocks of 64 k");
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int prow = t >> 5, pc = 2 * (t & 31);                  // this thread's 16-byte piece: rows prow + 8 i, doubles pc, pc + 1 of the block
+    d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    d2v rb0[16], ra0[2], rb1[16], ra1[2];                    // two blocks in flight (named sets, macros: no dynamic register indexing)
+#define NT_SLICE_FETCH(RB, RA, BLK)                                                                                    \
+    {                                                                                                                  \
+        constexpr int seg_ = (BLK) / BPS, k0_ = ((BLK) - seg_ * BPS) * KBLK;                                           \
+        const double *bp_ = (seg_ ? b1 : b) + k0_ + pc, *ap_ = (seg_ ? a1 : a) + k0_ + pc;                             \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) RB[i] = *reinterpret_cast<const d2v *>(bp_ + (int64_t)(prow + 8 * i) * ldb); \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) RA[i] = *reinterpret_cast<const d2v *>(ap_ + (int64_t)(prow + 8 * i) * lda);  \
+    }
+#define NT_SLICE_STAGE(RB, RA)                                                                                         \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) *reinterpret_cast<d2v *>(lds + (prow + 8 * i) * LS + pc) = RB[i];             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) *reinterpret_cast<d2v *>(lds + (128 + prow + 8 * i) * LS + pc) = RA[i];        \
+    }
+    auto multiply = [&] {
+        const double *As = lds + (128 + l15) * LS + 2 * l4;
+        const double *B0 = lds + (32 * w + l15) * LS + 2 * l4, *B1 = B0 + 16 * LS;
+#pragma unroll
+        for (int u = 0; u < KBLK / KB; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = u * KB + 8 * h;
+                const d2v af = *reinterpret_cast<const d2v *>(As + k);
+                const d2v b0 = *reinterpret_cast<const d2v *>(B0 + k), b1v = *reinterpret_cast<const d2v *>(B1 + k);
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, b0.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, b1v.x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, b0.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, b1v.y, acc[1], 0, 0, 0);
+            }
+    };
+    // blocks 2 j (set 0) and 2 j + 1 (set 1), j = 0 .. 3: written out, the block numbers are compile-time constants
+#define NT_SLICE_PAIR(J)                                                                                               \
+    if constexpr (2 * (J) < NB) {                                                                                      \
+        if constexpr ((J) > 0) __syncthreads();                                                                        \
+        NT_SLICE_STAGE(rb0, ra0)                                                                                       \
+        if constexpr (2 * (J) + 2 < NB) NT_SLICE_FETCH(rb0, ra0, 2 * (J) + 2)                                          \
+        __syncthreads();                                                                                               \
+        multiply();                                                                                                    \
+        if constexpr (2 * (J) + 1 < NB) {                                                                              \
+            __syncthreads();                                                                                           \
+            NT_SLICE_STAGE(rb1, ra1)                                                                                   \
+            if constexpr (2 * (J) + 3 < NB) NT_SLICE_FETCH(rb1, ra1, 2 * (J) + 3)                                      \
+            __syncthreads();                                                                                           \
+            multiply();                                                                                                \
+        }                                                                                                              \
+    }
+    static_assert(NB <= 8, "K up to 256, one or two operand pairs");
+    NT_SLICE_FETCH(rb0, ra0, 0)
+    if constexpr (NB > 1) NT_SLICE_FETCH(rb1, ra1, 1)
+    NT_SLICE_PAIR(0)
+    NT_SLICE_PAIR(1)
+    NT_SLICE_PAIR(2)
+    NT_SLICE_PAIR(3)
+#undef NT_SLICE_PAIR
+#undef NT_SLICE_STAGE
+#undef NT_SLICE_FETCH
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double *p = c + (int64_t)(l4 + 4 * r) * ldc + 32 * w + 16 * n + l15;
+            if constexpr (MODE == 1) *p = *p - acc[n][r];
+            else if constexpr (MODE == 2) *p = -acc[n][r];
+            else *p = acc[n][r];
+        }
+}
+__device__ __forceinline__ double *nt_slice_lds_storage() {
+    __shared__ __attribute__((aligned(16))) double lds[NT_SLICE_LDS_DOUBLES];
+    return lds;
+}
+
 // The same tile for a compile-time list of NSEG operand pairs (segment s: A = ap[s], B = bp[s], both 256-wide
 // panels): C -= sum_s A_s B_s^T in one pass of depth NSEG * KDEPTH.  Used by the single-GPU trailing update
 // with NSEG = 4 (depth 1024 after a group of four panels): per-tile fixed costs (C read + write, pipeline fill)
