@@ -23,11 +23,11 @@ __device__ unsigned long long tgp_gemm_stamps[1024 * 4];
 __device__ int tgp_gemm_stamp_grid = 43;
 __device__ unsigned long long tgp_queue_stamps[1024 * 4];      // queued bulk update with T == tgp_queue_stamp_T: per workgroup
 __device__ int tgp_queue_stamp_T = 40;
-__device__ unsigned long long tgp_mid_stamps[17 * 8];          // panel_mid_kernel of the panel whose first row is tgp_mid_stamp_base: workgroups 0 .. 16
+__device__ unsigned long long tgp_mid_stamps[25 * 8];          // panel_mid_kernel of the panel whose first row is tgp_mid_stamp_base: workgroups 0 .. 24
 __device__ int tgp_mid_stamp_base = 5120;
 #define TGP_MID_STAMP(i)                                                                                   \
     do {                                                                                                   \
-        if (threadIdx.x == 0 && base == tgp_mid_stamp_base && blockIdx.x < 17) tgp_mid_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        if (threadIdx.x == 0 && base == tgp_mid_stamp_base && blockIdx.x < 25) tgp_mid_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #else
 #define TGP_MID_STAMP(i) ((void)0)
@@ -118,11 +118,14 @@ __global__ __launch_bounds__(256, 2) void diag_mid_kernel(double *R1, const doub
 // A1 -= X0 L10^T), 24 + 25 us at N = 8192, although the second diagonal block needs only its own 128 rows of them.  Here the
 // workgroups of one launch are, in dispatch order (every wait is on workgroups with LOWER indices, which the dispatcher has
 // started before: progress never depends on how many workgroups are resident):
-//   0 ..  7   A1: sixteen-row slices of rows 128..255:  L10 = A10 W0^T                     -> count sync[0]
-//   8 .. 15   A2: the same slices, after sync[0] == 8:  A11 -= L10 L10^T                   -> count sync[1]
-//   16        after sync[1] == 8: potrf128 of block (1,1): L11 in place, W1 = L11^-1
-//   17 ..     the rows below the 256 x 256 block (128-row tiles, or 16-row slices where SMALLROWS): X0 = A0 W0^T, then -- after
-//             sync[0] == 8 -- A1 -= X0 L10^T, both under the diagonal block's 33 us
+//   0 ..  7   A1: sixteen-row slices of rows 128..255:  L10 = A10 W0^T (in place: whole slices)            -> count sync[0]
+//   8 .. 23   A2: the same slices as two column halves each, after sync[0] == 8:  A11 -= L10 L10^T         -> count sync[1]
+//   24        after sync[1] == 16: potrf128 of block (1,1): L11 in place, W1 = L11^-1
+//   25 ..     the rows below the 256 x 256 block (128-row tiles, or 16-row slices where SMALLROWS): X0 = A0 W0^T, then -- after
+//             sync[0] == 8 -- A1 -= X0 L10^T, both under the diagonal block's 25 us
+// (Second session of round 5, in-kernel stamps tools/mid_stamps.py: from the end of the first diagonal block to the start of the
+// second one's body 18.2 us with eight whole slices per step on the direct-from-global latency tile, 14.2 us on the LDS-staged
+// one, ~12 us with the second step's slices in column halves: profiles/r05_mid_stamps.txt.)
 // The third product of the rows (X1 = A1 W1^T) stays a launch of its own behind this one: folded in, its workgroups would
 // hold their compute units spinning for W1.  Hand-off: the producer's waves wait for their stores (vmcnt(0)), barrier, one
 // release fence at agent scope (writes the XCD's L2 back), one relaxed atomic increment; the consumer's thread 0 polls with
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void panel_mid_kernel(double *Pk, const double
     const int b = blockIdx.x;
     double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
     TGP_MID_STAMP(0);
-    if (b < 8) {
+    if (b < 8) {            // (whole slices: X overwrites the rows it is computed from, a column half would race with its sibling's loads)
         double *rows = R1 + (int64_t)b * 16 * TGP_PW;
         nt_slice_tile<0, TGP_TB, 1>(T, rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
         TGP_MID_STAMP(1);
@@ -184,32 +187,33 @@ __global__ __launch_bounds__(256) void panel_mid_kernel(double *Pk, const double
         TGP_MID_STAMP(2);
         return;
     }
-    if (b < 16) {
+    if (b < 24) {           // slice (b - 8) >> 1, column half b & 1
         if (!panel_wait(sync, 0, 8u, info)) return;
         TGP_MID_STAMP(1);
-        double *rows = R1 + (int64_t)(b - 8) * 16 * TGP_PW;
-        nt_slice_tile<1, TGP_TB, 1>(T, rows, TGP_PW, R1, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
+        double *rows = R1 + (int64_t)((b - 8) >> 1) * 16 * TGP_PW;
+        const int64_t ch = (int64_t)(b & 1) * 64;
+        nt_slice_tile<1, TGP_TB, 1, 64>(T, rows, TGP_PW, R1 + ch * TGP_PW, TGP_PW, rows + TGP_TB + ch, TGP_PW, nullptr, nullptr);
         TGP_MID_STAMP(2);
         panel_publish(sync + 1);
         TGP_MID_STAMP(3);
         return;
     }
-    if (b == 16) {
-        if (!panel_wait(sync, 1, 8u, info)) return;
+    if (b == 24) {
+        if (!panel_wait(sync, 1, 16u, info)) return;
         TGP_MID_STAMP(1);
         potrf_v2::potrf128_body<true>(T, R1 + TGP_TB, TGP_PW, W1, info, base + TGP_TB);
         TGP_MID_STAMP(2);
         return;
     }
     if constexpr (SMALLROWS) {
-        double *rows = Pk + (int64_t)TGP_PW * TGP_PW + (int64_t)(b - 17) * 16 * TGP_PW;
+        double *rows = Pk + (int64_t)TGP_PW * TGP_PW + (int64_t)(b - 25) * 16 * TGP_PW;
         nt_slice_tile<0, TGP_TB, 1>(T, rows, TGP_PW, W0, TGP_TB, rows, TGP_PW, nullptr, nullptr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's X0 is in the L2 before the others read it
         __syncthreads();
         if (!panel_wait(sync, 0, 8u, info)) return;
         nt_slice_tile<1, TGP_TB, 1>(T, rows, TGP_PW, R1, TGP_PW, rows + TGP_TB, TGP_PW, nullptr, nullptr);
     } else {
-        double *rows = Pk + (int64_t)TGP_PW * TGP_PW + (int64_t)(b - 17) * 128 * TGP_PW;
+        double *rows = Pk + (int64_t)TGP_PW * TGP_PW + (int64_t)(b - 25) * 128 * TGP_PW;
         gemm_tile_128_at<0, TGP_TB, TGP_TB>(T, rows, W0, rows);
         __syncthreads();
         if (!panel_wait(sync, 0, 8u, info)) return;
@@ -665,8 +669,8 @@ void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_inf
                    hipFuncSetAttribute((const void *)panel_mid_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad) == hipSuccess;
         }();
         const unsigned dyn = (exclusive && pad_ok) ? pad : 0u;
-        if (17 + 8 * r2 <= cu_budget) panel_mid_kernel<true><<<17 + 8 * r2, 256, dyn, st>>>(Pk, W0, W1, d_info, base, mid_sync);
-        else panel_mid_kernel<false><<<17 + r2, 256, dyn, st>>>(Pk, W0, W1, d_info, base, mid_sync);
+        if (17 + 8 * r2 <= cu_budget) panel_mid_kernel<true><<<25 + 8 * r2, 256, dyn, st>>>(Pk, W0, W1, d_info, base, mid_sync);
+        else panel_mid_kernel<false><<<25 + r2, 256, dyn, st>>>(Pk, W0, W1, d_info, base, mid_sync);
     } else if (cu_budget > 0) {
         // A step that WOULD run as panel_mid_kernel, were this solve alone on the chip: the same arithmetic as separate launches --
         // rows 128..255 as eight 16-row slices, the rows below in the tile form that kernel would choose -- so that a solve's
@@ -709,7 +713,10 @@ inline int small_t() {          // steps with at most this many tile rows run on
 template <int NSEG>
 void launch_syrk(hipStream_t st, double *d_A, int64_t Np, int ob, int T, int strip, const double *P0, const double *P1) {
     if (T <= 0) return;
-    if (T <= small_t()) {
+    // strips the panel chain waits for also run as 16-row slices further up (TGP_STRIP_SMALL_T tile rows): since the latency tile is
+    // staged through LDS a depth-256 slice takes 7.8 us where a 32-row tile of the strip takes 15
+    static const int strip_small_t = [] { const char *e = getenv("TGP_STRIP_SMALL_T"); return e ? atoi(e) : 16; }();      // (8 / 16 / 24 / 32 / 48: profiles/r05_slice_tile_ab.txt)
+    if (T <= small_t() || (strip > 0 && T <= strip_small_t)) {
         const int cols = strip == 0 ? T : (strip < T ? strip : T);
         syrk_small_kernel<NSEG><<<dim3((unsigned)(T * 8), (unsigned)cols), 256, 0, st>>>(d_A, Np, ob, T, P0, P1);
         return;
@@ -1244,7 +1251,7 @@ extern "C" int tgp_debug_queue_stamps(unsigned long long *out, int T) {
 }
 extern "C" int tgp_debug_mid_stamps(unsigned long long *out, int base) {
     if (base >= 0) return (int)hipMemcpyToSymbol(HIP_SYMBOL(tgp_mid_stamp_base), &base, sizeof(int));
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_mid_stamps), 17 * 8 * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_mid_stamps), 25 * 8 * sizeof(unsigned long long));
 }
 extern "C" int tgp_debug_potrf_fine(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_potrf_fine), 1024 * 8 * sizeof(unsigned long long));      // [block][sub-step]

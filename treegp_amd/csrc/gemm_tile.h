@@ -533,43 +533,53 @@ __device__ __forceinline__ void nt_small_tile(const double *a, int lda, const do
 typedef double d2v __attribute__((ext_vector_type(2)));
 constexpr int NT_SLICE_LS = 66;
 constexpr int NT_SLICE_LDS_DOUBLES = (128 + 16) * NT_SLICE_LS;
-template <int MODE, int KDEPTH, int NSEG>
+// NCOL = 64: a 16 x 64 slice (wave w the columns 16 w .. 16 w + 15, one accumulator chain): half the matrix instructions and
+// half of B per workgroup, for the steps in which twice the workgroups find a compute unit each (panel_mid_kernel).
+template <int MODE, int KDEPTH, int NSEG, int NCOL = 128>
 __device__ __forceinline__ void nt_slice_tile(double *lds, const double *a, int lda, const double *b, int ldb, double *c, int ldc,
                                               const double *a1, const double *b1) {
     constexpr int LS = NT_SLICE_LS, KBLK = 64;
     constexpr int BPS = KDEPTH / KBLK, NB = NSEG * BPS;          // blocks per segment / in all
     static_assert(KDEPTH % KBLK == 0 && NB >= 1, "whole blocks of 64 k");
+    static_assert(NCOL == 128 || NCOL == 64, "slices of 128 or 64 columns");
+    constexpr int NRB = NCOL / 8, NT = NCOL / 64, WC = NCOL / 4;      // B pieces per thread and block / MFMA tiles per wave / columns per wave
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int prow = t >> 5, pc = 2 * (t & 31);                  // this thread's 16-byte piece: rows prow + 8 i, doubles pc, pc + 1 of the block
     d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    d2v rb0[16], ra0[2], rb1[16], ra1[2];                    // two blocks in flight (named sets, macros: no dynamic register indexing)
+    d2v rb0[NRB], ra0[2], rb1[NRB], ra1[2];                    // two blocks in flight (named sets, macros: no dynamic register indexing)
 #define NT_SLICE_FETCH(RB, RA, BLK)                                                                                    \
     {                                                                                                                  \
         constexpr int seg_ = (BLK) / BPS, k0_ = ((BLK) - seg_ * BPS) * KBLK;                                           \
         const double *bp_ = (seg_ ? b1 : b) + k0_ + pc, *ap_ = (seg_ ? a1 : a) + k0_ + pc;                             \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) RB[i] = *reinterpret_cast<const d2v *>(bp_ + (int64_t)(prow + 8 * i) * ldb); \
+        _Pragma("unroll") for (int i = 0; i < NRB; ++i) RB[i] = *reinterpret_cast<const d2v *>(bp_ + (int64_t)(prow + 8 * i) * ldb); \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) RA[i] = *reinterpret_cast<const d2v *>(ap_ + (int64_t)(prow + 8 * i) * lda);  \
     }
 #define NT_SLICE_STAGE(RB, RA)                                                                                         \
     {                                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) *reinterpret_cast<d2v *>(lds + (prow + 8 * i) * LS + pc) = RB[i];             \
+        _Pragma("unroll") for (int i = 0; i < NRB; ++i) *reinterpret_cast<d2v *>(lds + (prow + 8 * i) * LS + pc) = RB[i];             \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) *reinterpret_cast<d2v *>(lds + (128 + prow + 8 * i) * LS + pc) = RA[i];        \
     }
     auto multiply = [&] {
         const double *As = lds + (128 + l15) * LS + 2 * l4;
-        const double *B0 = lds + (32 * w + l15) * LS + 2 * l4, *B1 = B0 + 16 * LS;
+        const double *B0 = lds + (WC * w + l15) * LS + 2 * l4, *B1 = B0 + 16 * LS;
 #pragma unroll
         for (int u = 0; u < KBLK / KB; ++u)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = u * KB + 8 * h;
                 const d2v af = *reinterpret_cast<const d2v *>(As + k);
-                const d2v b0 = *reinterpret_cast<const d2v *>(B0 + k), b1v = *reinterpret_cast<const d2v *>(B1 + k);
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, b0.x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, b1v.x, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, b0.y, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, b1v.y, acc[1], 0, 0, 0);
+                const d2v b0 = *reinterpret_cast<const d2v *>(B0 + k);
+                if constexpr (NT == 2) {
+                    const d2v b1v = *reinterpret_cast<const d2v *>(B1 + k);
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, b0.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, b1v.x, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, b0.y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, b1v.y, acc[1], 0, 0, 0);
+                } else {
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, b0.x, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, b0.y, acc[0], 0, 0, 0);
+                }
             }
     };
     // blocks 2 j (set 0) and 2 j + 1 (set 1), j = 0 .. 3: written out, the block numbers are compile-time constants
@@ -600,10 +610,10 @@ __device__ __forceinline__ void nt_slice_tile(double *lds, const double *a, int 
 #undef NT_SLICE_FETCH
     __syncthreads();
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            double *p = c + (int64_t)(l4 + 4 * r) * ldc + 32 * w + 16 * n + l15;
+            double *p = c + (int64_t)(l4 + 4 * r) * ldc + WC * w + 16 * n + l15;
             if constexpr (MODE == 1) *p = *p - acc[n][r];
             else if constexpr (MODE == 2) *p = -acc[n][r];
             else *p = acc[n][r];

@@ -118,15 +118,15 @@ __global__ __launch_bounds__(256) void vprod_kernel(const double *__restrict__ A
     gemm_tile_128<XPROD ? 2 : 0, TGP_PW, KD, TileDefault, 0>(p.a, p.b, p.c, nullptr, nullptr, p.nseg, p.sa, p.sb);
 }
 
-// the same products on the latency tile (16 x 128 of C per workgroup, operands straight from L2): a 128 x 128 x 512 tile alone
+// the same products on the latency tile (16 x 128 of C per workgroup, gemm_tile.h: nt_slice_tile): a 128 x 128 x 512 tile alone
 // takes 60 - 100 us, which is what a level costs when the matrix has too few tiles to fill the chip
 template <int KD, bool XPROD>
 __global__ __launch_bounds__(256) void vprod_small_kernel(const double *__restrict__ A, double *V, const double *Vt, double *TT,
                                                           int64_t Np, int S, int h, int qoff) {
     const Prod p = level_prod<KD, XPROD>(A, V, Vt, TT, Np, S, h, 16, qoff);
     if (!p.valid) return;
-    if (p.nseg >= 2) nt_small_tile<XPROD ? 2 : 0, KD, 2>(p.a, 256, p.b, 256, p.c, 256, p.a + p.sa, p.b + p.sb);
-    else nt_small_tile<XPROD ? 2 : 0, KD, 1>(p.a, 256, p.b, 256, p.c, 256, nullptr, nullptr);
+    if (p.nseg >= 2) nt_slice_tile<XPROD ? 2 : 0, KD, 2>(nt_slice_lds_storage(), p.a, 256, p.b, 256, p.c, 256, p.a + p.sa, p.b + p.sb);
+    else nt_slice_tile<XPROD ? 2 : 0, KD, 1>(nt_slice_lds_storage(), p.a, 256, p.b, 256, p.c, 256, nullptr, nullptr);
 }
 
 // Vt(o + cs + c, lo + h + rs + r) = V(o + h + rs + r, lo + cs + c) for the 128 x 128 tiles of the h x h off-diagonal block
