@@ -653,7 +653,7 @@ void factor_panel(hipStream_t st, double *Pk, int64_t mk, double *W0, int *d_inf
     double *R1 = Pk + (int64_t)TGP_TB * TGP_PW;                 // row 128 of the panel
     const int r1 = (int)((mk - TGP_TB) / TGP_TB);
     // few row blocks: 16-row slices spread a block over 8 workgroups (latency); many: 128-row tiles (throughput)
-    static const int small_rows = [] { const char *e = getenv("TGP_SMALL_ROWS"); return e ? atoi(e) : 40; }();
+    static const int small_rows = [] { const char *e = getenv("TGP_SMALL_ROWS"); return e ? atoi(e) : 80; }();      // (40 until the latency tile was staged through LDS; 24 / 40 / 56 / 64 / 80 / 96: profiles/r05_slice_tile_ab.txt)
     const bool solo = cu_budget >= 256 && mid_sync != nullptr;      // callers pass the whole chip only where the chain runs alone
     run_potrf128(st, Pk, TGP_PW, W0, d_info, base, exclusive, solo);
     if (n_data >= 0 && (int64_t)base + TGP_TB >= n_data && mk == TGP_PW) {
