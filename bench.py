@@ -612,15 +612,15 @@ def main():
                     traffic = traffic / (launches / K)
                 else:
                     traffic, src = measured_traffic(n, "syrk_hbm_bytes_per_launch")
-                alg_bytes = 16.0 * (acc["syrk_flops"] / (2.0 * 1024.0)) / launches if n >= 22528 else None
+                alg_bytes = 16.0 * (acc["syrk_flops"] / (2.0 * 1024.0)) / launches if n >= 18432 else None
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": src,
                                "algorithmic_bytes": alg_bytes,
                                "traffic_over_algorithmic": (traffic / alg_bytes) if (traffic and alg_bytes) else None,
-                               "kernel": ("syrk_segs_kernel<4>" if n >= 22528 else "syrk_dtv_kernel<4, 2>") if not use_dist else "syrk_distn_kernel (rank 0)",
+                               "kernel": ("syrk_segs_kernel<4>" if n >= 18432 else "syrk_dtv_kernel<4, 2>") if not use_dist else "syrk_distn_kernel (rank 0)",
                                "launches": int(acc["syrk_launches"]),
                                "avg_launch_ms": acc["syrk_ms"] / launches}
-            if not use_dist and n >= 22528:
+            if not use_dist and n >= 18432:
                 # `frac` is against the 2.4 GHz peak; the chip runs this kernel at ~2.3 GHz (DVFS) with the MFMA pipe
                 # busy `mfma_busy_frac` of the cycles -- frac ~ busy x clock / 2.4 (PMC passes, profiles/r*_pmc_sq.json)
                 out["roofline"]["pipe"] = measured_pipe()

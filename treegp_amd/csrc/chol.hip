@@ -7,7 +7,7 @@
 //   gemm<1>   column half 1    A[:,128:256] -= X X_d^T (depth 128)
 //   potrf128  diag block 1     L22, W22
 //   gemm<0>   rows below       X = A W22^T
-// Schedule (launch_potrf): panels in groups of four (pairs below N = 22528): inside a group every panel is first
+// Schedule (launch_potrf): panels in groups of four (pairs below N = 18432): inside a group every panel is first
 // brought up to date by one strip launch against the panels before it, then factored; everything to the right of
 // the group is updated in ONE pass of depth 1024 (512) -- that is where the N^3/3 flops are -- split so that the
 // next group is factored on a priority side stream underneath it.
@@ -793,14 +793,15 @@ int launch_potrf(tgp_ctx *ctx, double *d_A, int64_t Np, double *d_W, bool defer_
         }
     }
     // TGP_CHOL_MODE: 3 = groups of four panels (depth-1024 bulk update) with a pair-wise tail, 2 = pairs with look-ahead,
-    // 1 = pairs without look-ahead, 0 = one panel at a time.  Default: 3 from N = 22528 on (measured crossover: equal at 20480, 83.3 vs 84.2 ms at 24576), else 2.
+    // 1 = pairs without look-ahead, 0 = one panel at a time.  Default: 3 from N = 18432 on (crossover re-measured with the faster panel
+    // chain of round 5: equal at 16384, 46.8 vs 47.5 ms at 20480, 76.7 vs 78.7 at 24576; it was 22528 before), else 2.
     static const int mode_env = [] { const char *e = getenv("TGP_CHOL_MODE"); return e ? atoi(e) : -1; }();
     // Up to N = 1280 there is no bulk update worth a second stream (with flag hand-offs the look-ahead pays from Np = 1536 on
     // -- 0.650 vs 0.657 ms there, 0.906 vs 0.935 ms at 2048; with events it lost up to 2048: 0.51 vs 0.56 ms at N = 1024).
     // Contexts that run side by side (the concurrent likelihood evaluations of the ML fit) ask for
     // one stream each: the runtime has 4 hardware queues, and with two streams per context three contexts already share
     // queues and serialise (6 contexts at N = 1024: 0.60 ms per evaluation with look-ahead, 0.22 ms without).
-    const int mode = mode_env >= 0 ? mode_env : (!ctx->lookahead ? 1 : (Np >= 22528 ? 3 : (Np <= 1280 ? 1 : 2)));
+    const int mode = mode_env >= 0 ? mode_env : (!ctx->lookahead ? 1 : (Np >= 18432 ? 3 : (Np <= 1280 ? 1 : 2)));
     if (mode >= 2) {
         int rc = tgp_ensure_side_stream(ctx);
         if (rc) return rc;
