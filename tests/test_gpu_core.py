@@ -315,3 +315,26 @@ def test_a_solve_has_the_same_bits_with_and_without_panel_mid_kernel():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln and ln[0].isdigit()])
     assert len(outs[0]) == 5 and outs[0] == outs[1], (outs[0], outs[1])
+
+
+def test_staged_latency_tile_has_the_bits_of_the_direct_one():
+    """nt_slice_tile (operands through LDS with whole-row loads: what the panel chain's 16-row slices run on since round 5) must
+    return, value for value, what nt_small_tile (operands straight from global memory in MFMA layout) returns: same matrix
+    instructions in the same order.  The stand-alone probe runs both on cold operands for the three shapes the chain uses and
+    counts the values that differ."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "slice_probe")
+        r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "treegp_amd", "csrc"), "-o", exe,
+                            os.path.join(root, "tools", "probes", "slice_probe.hip")], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+    counts = [int(m) for m in re.findall(r"(\d+) of \d+ values differ", r.stdout)]
+    assert len(counts) == 3 and counts == [0, 0, 0], r.stdout
